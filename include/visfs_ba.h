@@ -1,0 +1,230 @@
+/*
+ * visfs_ba.h — C ABI of the MI355X sliding-window bundle-adjustment backend.
+ *
+ * This is the drop-in boundary for VISFS's `Optimizer::localOptimize`
+ * (reference: corelib/include/Optimizer/Optimizer.h:29-73, implementation
+ * corelib/src/Optimizer/Optimizer.cpp:58-364, g2o branch).  The reference has no
+ * FFI of its own; every entry point below cites the reference code it replaces.
+ * Plain pointers and sizes only: no C++/Eigen/OpenCV/torch types cross this line.
+ *
+ * Two layers are exported:
+ *   1. the WINDOW layer  — same inputs/outputs as `localOptimize`, flattened
+ *      (`visfs_ba_solve_window`, `visfs_ba_solve_batch`);
+ *   2. the GRAPH layer   — the factor graph the reference builds at
+ *      Optimizer.cpp:100-223 as flat arrays, kept resident in HBM
+ *      (`visfs_ba_graph_*`, `visfs_ba_optimize`), plus stage hooks used by the
+ *      parity tests to compare every intermediate against the CPU oracle.
+ *
+ * Threading: a handle is NOT thread-safe and owns one HIP stream, matching the
+ * reference's single-caller contract (Estimator thread only, Estimator.cpp:254).
+ * No exceptions cross the ABI.  All floating point is IEEE fp64 unless stated.
+ */
+#ifndef VISFS_BA_H
+#define VISFS_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VISFS_BA_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+/* The reference signals failure by returning an EMPTY pose map
+ * (Optimizer.cpp:143-147, 272-280, 315-318, 330-334).  The C++ shim maps every
+ * status != VISFS_BA_OK (except PASSTHROUGH) to that empty map. */
+enum {
+    VISFS_BA_OK = 0,
+    VISFS_BA_PASSTHROUGH = 1,      /* poses.size()==1 || iterations<=0 → input poses returned (Optimizer.cpp:360-361) */
+    VISFS_BA_ERR_TOO_FEW_POSES = 2,/* "should be called at least with 1 pose" (Optimizer.cpp:362-364), or first id == 0 (:74) */
+    VISFS_BA_ERR_NAN_CHI2 = 3,     /* Optimizer.cpp:272-275 */
+    VISFS_BA_ERR_HUGE_CHI2_1 = 4,  /* Optimizer.cpp:277-280 */
+    VISFS_BA_ERR_HUGE_CHI2_2 = 5,  /* Optimizer.cpp:315-318 */
+    VISFS_BA_ERR_BAD_ARGUMENT = 6,
+    VISFS_BA_ERR_UNSUPPORTED = 7,  /* framework != g2o-algorithm, laser factor, ... (out of scope) */
+    VISFS_BA_ERR_DEVICE = 8,       /* HIP runtime error / no MI355X present */
+    VISFS_BA_ERR_NOT_LOADED = 9    /* no graph resident in the handle */
+};
+
+/* ---- parameters: the eight Optimizer keys (Parameters.h:184-191, read at Optimizer.cpp:37-54) */
+typedef struct visfs_ba_params {
+    int32_t framework;            /* Optimizer/Framework: 0 = g2o algorithm (the only one implemented) */
+    int32_t solver;               /* Optimizer/Solver: 0 csparse, 1 cholmod, 3 eigen → direct Cholesky of S; 2 → block-Jacobi PCG */
+    int32_t trust_region;         /* Optimizer/TrustRegion: 0 Levenberg, 1 GaussNewton */
+    int32_t iterations;           /* Optimizer/Iterations (run as iterations/2 + iterations/2) */
+    double  pixel_variance;       /* Optimizer/PixelVariance      (default 1.5)  */
+    double  odometry_covariance;  /* Optimizer/OdometryCovariance (default 5e-5) */
+    double  laser_covariance;     /* Optimizer/LaserCovariance    (default 0.1, unused: laser factor out of scope) */
+    double  robust_kernel_delta;  /* Optimizer/RobustKernelDelta  (default 8.0; <=0 disables Huber and phase 2) */
+} visfs_ba_params;
+
+/* Fills the reference defaults (Parameters.h:184-191). */
+void visfs_ba_default_params(visfs_ba_params* p);
+
+/* ---- WINDOW layer: the arguments of localOptimize, flattened -------------- */
+/* 3x4 transforms are ROW-MAJOR [r00 r01 r02 tx  r10 r11 r12 ty  r20 r21 r22 tz]
+ * (the top three rows of Eigen::Isometry3d::matrix()). */
+typedef struct visfs_ba_window {
+    uint64_t root_id;             /* _rootId: pose fixed iff id == root_id (Optimizer.cpp:111) */
+
+    int32_t  n_poses;             /* _poses, in std::map (ascending id) order */
+    const uint64_t* pose_ids;     /* [n_poses] */
+    const double*   pose_Twr;     /* [n_poses][12] robot pose in world */
+
+    int32_t  n_links;             /* _links, in std::map order */
+    const uint64_t* link_from;    /* [n_links] */
+    const uint64_t* link_to;      /* [n_links] */
+    const double*   link_T;       /* [n_links][12] T_r1r2 */
+
+    int32_t  n_cameras;           /* _cameraModels.size(); baseline is used only if > 1 (Optimizer.cpp:181-183) */
+    double   fx, fy, cx, cy;      /* cameraModels.front()->eigenKdouble() (Optimizer.cpp:176,191-194) */
+    float    baseline;            /* getBaseLine() — float in the reference (PinholeModel.cpp:75-77) */
+    double   Trc[12];             /* getTansformImageToRobot() (GeometricCamera.h:15-19) */
+
+    int32_t  n_points;            /* _points3D, ascending feature id */
+    const uint64_t* point_ids;    /* [n_points] */
+    double*         point_xyz;    /* [n_points][3]  IN/OUT (Optimizer.cpp:343-358) */
+    const uint8_t*  point_fixed;  /* [n_points] fixSymbol */
+
+    int32_t  n_refs;              /* _wordReferences leaves, feature-major then pose-major (nested std::map order) */
+    const uint64_t* ref_feature;  /* [n_refs] */
+    const uint64_t* ref_pose;     /* [n_refs] */
+    const float*    ref_u;        /* [n_refs] kpt.pt.x */
+    const float*    ref_v;        /* [n_refs] kpt.pt.y */
+    const float*    ref_depth;    /* [n_refs] FeatureBA::depth */
+
+    int32_t  n_laser_points;      /* must be 0: laser factor is out of scope this round */
+} visfs_ba_window;
+
+typedef struct visfs_ba_result {
+    int32_t  status;              /* VISFS_BA_* */
+    int32_t  n_poses_out;         /* 0 on failure (the reference's empty map) */
+    uint64_t* pose_ids_out;       /* caller-allocated [n_poses] */
+    double*   pose_Twr_out;       /* caller-allocated [n_poses][12] */
+    int32_t  outlier_capacity;    /* size of the two arrays below (>= n_refs is always enough) */
+    int32_t  n_outliers;          /* appended pairs (featureId, poseId), reference order (Optimizer.cpp:284-302) */
+    uint64_t* outlier_feature;    /* caller-allocated */
+    uint64_t* outlier_pose;       /* caller-allocated */
+    int32_t  iterations_run[2];   /* outer LM iterations executed in phase 1 / phase 2 */
+    double   chi2_initial;        /* activeRobustChi2 before the first iteration */
+    double   chi2_phase1;         /* Optimizer.cpp:271 */
+    double   chi2_final;          /* Optimizer.cpp:315 */
+    int32_t  warn_mono_skipped;   /* observations that would take the reference's uninitialised mono branch (Optimizer.cpp:197-210): skipped */
+    int32_t  reserved;
+} visfs_ba_result;
+
+/* ---- GRAPH layer: the factor graph of Optimizer.cpp:100-223 as flat arrays ---- */
+/* Pose state is the reference's CameraPose (OptimizeTypeDefine.h:16-86):
+ * Tcw as [tx ty tz qx qy qz qw], w >= 0, unit norm.  Observations are sorted by
+ * (point, pose) — the insertion order of the reference's edges. */
+typedef struct visfs_ba_graph {
+    int32_t n_poses, n_points, n_obs, n_odo;
+    const double*  pose_tq;       /* [n_poses][7] */
+    const uint8_t* pose_fixed;    /* [n_poses] */
+    const double*  point_xyz;     /* [n_points][3] */
+    const uint8_t* point_fixed;   /* [n_points] */
+    const int32_t* obs_point;     /* [n_obs] non-decreasing */
+    const int32_t* obs_pose;      /* [n_obs] */
+    const double*  obs_uvr;       /* [n_obs][3] (u_l, v_l, u_r) as built at Optimizer.cpp:187-188 */
+    const int32_t* odo_from;      /* [n_odo] vertex(0) (Optimizer.cpp:136-139) */
+    const int32_t* odo_to;        /* [n_odo] vertex(1) */
+    const double*  odo_tq;        /* [n_odo][7] T_c1c2 = Trc^-1 T_r1r2 Trc as SE3Quat (Optimizer.cpp:131-140) */
+    double fx, fy, cx, cy, bf;    /* EdgeStereo intrinsics (Optimizer.cpp:191-195) */
+} visfs_ba_graph;
+
+/* Per-solve statistics of the two optimise phases (Optimizer.cpp:261-318). */
+#define VISFS_BA_MAX_TRACE 64
+typedef struct visfs_ba_stats {
+    int32_t status;
+    int32_t iterations_run[2];
+    int32_t trials_run[2];        /* damped solves incl. rejected ones */
+    int32_t pcg_iterations;       /* total over all solves (solver == 2) */
+    int32_t n_outliers;
+    double  chi2_initial, chi2_phase1, chi2_final;
+    int32_t n_trace;              /* entries used below (outer iterations, both phases) */
+    double  trace_lambda[VISFS_BA_MAX_TRACE];   /* lambda of the accepted (or last) trial */
+    double  trace_chi2[VISFS_BA_MAX_TRACE];     /* robust chi2 after the iteration */
+} visfs_ba_stats;
+
+typedef struct visfs_ba_handle visfs_ba_handle;
+
+/* Replaces `Optimizer::Optimizer(const ParametersMap&)` (Optimizer.cpp:37-56).
+ * device_index: HIP device ordinal.  Returns VISFS_BA_ERR_DEVICE when no gfx950
+ * device can be opened — there is NO CPU fallback behind this ABI. */
+int visfs_ba_create(const visfs_ba_params* params, int device_index, visfs_ba_handle** out);
+void visfs_ba_destroy(visfs_ba_handle* h);
+const char* visfs_ba_last_error(const visfs_ba_handle* h);
+int visfs_ba_abi_version(void);
+
+/* Replaces one call of `Optimizer::localOptimize` (Optimizer.cpp:58-364): pack
+ * (graph build :100-223), upload, both optimise phases on the GPU (:261-318),
+ * download, write-back (:320-358).  Host pointers in, host pointers out. */
+int visfs_ba_solve_window(visfs_ba_handle* h, const visfs_ba_window* w, visfs_ba_result* r);
+
+/* BASELINE config 5: n independent windows solved concurrently on this handle's
+ * device (one stream per in-flight window).  No reference counterpart — the
+ * reference solves one window per frame. */
+int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r);
+
+/* Host-only graph build, exported so that CPU tests can check it without a GPU
+ * (Optimizer.cpp:100-223: Twr→Tcw :104-109, link → T_c1c2 :131-140, float
+ * disparity :187-188).  Caller allocates: pose_tq[n_poses*7], pose_fixed[n_poses],
+ * point_used[n_points] (1 iff the point became a vertex, :158), obs_* sized n_refs,
+ * odo_* sized n_links.  On return *g points into those buffers. */
+int visfs_ba_pack_window(const visfs_ba_params* params, const visfs_ba_window* w,
+                         double* pose_tq, uint8_t* pose_fixed, uint8_t* point_used,
+                         int32_t* obs_point, int32_t* obs_pose, double* obs_uvr, int32_t* obs_ref,
+                         int32_t* odo_from, int32_t* odo_to, double* odo_tq,
+                         visfs_ba_graph* g, int32_t* n_mono_skipped);
+/* Host-only write-back (Optimizer.cpp:320-329): Twr = Tcw^-1 * Trc^-1. */
+void visfs_ba_unpack_pose(const double* tq, const double* Trc, double* Twr_out);
+
+/* Upload a graph and build the device-side index structures (the analogue of
+ * graph construction + g2o buildStructure).  The graph stays resident. */
+int visfs_ba_graph_upload(visfs_ba_handle* h, const visfs_ba_graph* g);
+/* Restore the uploaded initial estimates and re-activate all edges (device→device). */
+int visfs_ba_graph_reset(visfs_ba_handle* h);
+/* Both optimise phases + outlier marking on the resident graph
+ * (Optimizer.cpp:261-318).  Inputs are already in HBM: this is the timed region
+ * of bench.py. */
+int visfs_ba_optimize(visfs_ba_handle* h, visfs_ba_stats* stats);
+/* Any of the output pointers may be NULL.  obs_outlier[i] = 1 iff edge i was
+ * moved to level 1 (Optimizer.cpp:285-286); obs_chi2 = e^T Omega e at :270. */
+int visfs_ba_graph_download(visfs_ba_handle* h, double* pose_tq, double* point_xyz,
+                            uint8_t* obs_outlier, double* obs_chi2);
+
+/* ---- stage hooks (parity tests; each runs the production kernels) -------- */
+enum {
+    VISFS_BA_BUF_OBS_ERR = 0,     /* [n_obs][3]  e = z - pi(R Pw + t)          (OptimizeTypeDefine.h:121-126) */
+    VISFS_BA_BUF_OBS_CHI2 = 1,    /* [n_obs]     e^T Omega e                    */
+    VISFS_BA_BUF_OBS_WEIGHT = 2,  /* [n_obs]     Huber rho'(chi2), 0 if inactive */
+    VISFS_BA_BUF_HPL = 3,         /* [n_obs][18] J_pose^T (rho' Omega) J_point, 6x3 row-major; 0 if an end is fixed */
+    VISFS_BA_BUF_HLL = 4,         /* [n_points][6] xx xy xz yy yz zz            */
+    VISFS_BA_BUF_BL = 5,          /* [n_points][3]                              */
+    VISFS_BA_BUF_HPP = 6,         /* [6*npf][6*npf] dense row-major, free poses in index order (visual + odometry) */
+    VISFS_BA_BUF_BP = 7,          /* [6*npf]                                    */
+    VISFS_BA_BUF_S = 8,           /* [6*npf][6*npf] reduced camera matrix incl. lambda */
+    VISFS_BA_BUF_BS = 9,          /* [6*npf]                                    */
+    VISFS_BA_BUF_DX_POSE = 10,    /* [6*npf]                                    */
+    VISFS_BA_BUF_DX_POINT = 11,   /* [n_points][3], 0 for fixed points          */
+    VISFS_BA_BUF_POSE_TRIAL = 12, /* [n_poses][7]  state after the update       */
+    VISFS_BA_BUF_POINT_TRIAL = 13 /* [n_points][3]                              */
+};
+/* number of free (non-fixed) poses of the resident graph */
+int visfs_ba_graph_free_poses(visfs_ba_handle* h);
+/* Linearise at the current estimate (K1,K2,K3,K4): fills ERR/CHI2/WEIGHT/HPL/HLL/BL/HPP/BP.
+ * Returns the robust chi2 (activeRobustChi2) and the max |diag H| used for lambda init. */
+int visfs_ba_stage_linearize(visfs_ba_handle* h, double* robust_chi2, double* max_diag);
+/* One damped solve at the given lambda (K5,K6,K7,K8 + chi2 at the trial state).
+ * solver follows the handle's params.  Does not commit the trial state. */
+int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, double* scale,
+                         int32_t* pcg_iterations, int32_t* solver_ok);
+/* Copies a stage buffer to host memory as fp64 in the layout documented above. */
+int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISFS_BA_H */

@@ -1,0 +1,175 @@
+"""ctypes binding of the HIP backend (visfs_amd/lib/libvisfs_ba_hip.so) — plumbing only.
+
+The product is the C-ABI library; this module exists so that tests and bench.py can
+drive it.  It never falls back to a CPU path: a missing library raises ImportError-like
+RuntimeError, a missing GPU surfaces as VISFS_BA_ERR_DEVICE from `visfs_ba_create`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvisfs_ba_hip.so")
+
+_pd = C.POINTER(C.c_double)
+_pu8 = C.POINTER(C.c_uint8)
+
+EXPORTS = [
+    "visfs_ba_abi_version", "visfs_ba_default_params", "visfs_ba_create", "visfs_ba_destroy",
+    "visfs_ba_last_error", "visfs_ba_solve_window", "visfs_ba_solve_batch", "visfs_ba_pack_window",
+    "visfs_ba_unpack_pose", "visfs_ba_graph_upload", "visfs_ba_graph_reset", "visfs_ba_optimize",
+    "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
+    "visfs_ba_stage_trial", "visfs_ba_stage_fetch",
+]
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load the HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    lib.visfs_ba_abi_version.restype = C.c_int
+    lib.visfs_ba_default_params.argtypes = [C.POINTER(abi.Params)]
+    lib.visfs_ba_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(C.c_void_p)]
+    lib.visfs_ba_create.restype = C.c_int
+    lib.visfs_ba_destroy.argtypes = [C.c_void_p]
+    lib.visfs_ba_last_error.argtypes = [C.c_void_p]
+    lib.visfs_ba_last_error.restype = C.c_char_p
+    lib.visfs_ba_solve_window.argtypes = [C.c_void_p, C.POINTER(abi.Window), C.POINTER(abi.Result)]
+    lib.visfs_ba_solve_window.restype = C.c_int
+    lib.visfs_ba_solve_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.Window)), C.POINTER(C.POINTER(abi.Result))]
+    lib.visfs_ba_solve_batch.restype = C.c_int
+    lib.visfs_ba_pack_window.argtypes = abi.PACK_ARGTYPES
+    lib.visfs_ba_pack_window.restype = C.c_int
+    lib.visfs_ba_unpack_pose.argtypes = [_pd, _pd, _pd]
+    lib.visfs_ba_graph_upload.argtypes = [C.c_void_p, C.POINTER(abi.Graph)]
+    lib.visfs_ba_graph_upload.restype = C.c_int
+    lib.visfs_ba_graph_reset.argtypes = [C.c_void_p]
+    lib.visfs_ba_graph_reset.restype = C.c_int
+    lib.visfs_ba_optimize.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
+    lib.visfs_ba_optimize.restype = C.c_int
+    lib.visfs_ba_graph_download.argtypes = [C.c_void_p, _pd, _pd, _pu8, _pd]
+    lib.visfs_ba_graph_download.restype = C.c_int
+    lib.visfs_ba_graph_free_poses.argtypes = [C.c_void_p]
+    lib.visfs_ba_graph_free_poses.restype = C.c_int
+    lib.visfs_ba_stage_linearize.argtypes = [C.c_void_p, _pd, _pd]
+    lib.visfs_ba_stage_linearize.restype = C.c_int
+    lib.visfs_ba_stage_trial.argtypes = [C.c_void_p, C.c_double, _pd, _pd, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.visfs_ba_stage_trial.restype = C.c_int
+    lib.visfs_ba_stage_fetch.argtypes = [C.c_void_p, C.c_int32, _pd, C.c_size_t]
+    lib.visfs_ba_stage_fetch.restype = C.c_int
+    if lib.visfs_ba_abi_version() != abi.ABI_VERSION:
+        raise BackendError("ABI version mismatch between visfs_amd/abi.py and libvisfs_ba_hip.so")
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_pd)
+
+
+class Solver:
+    """One `visfs_ba_handle` (one GPU, one stream) — the analogue of a VISFS::Optimizer::Optimizer instance."""
+
+    def __init__(self, params=None, device=0):
+        self.lib = load_library()
+        self.params = params if params is not None else abi.default_params()
+        h = C.c_void_p()
+        rc = self.lib.visfs_ba_create(C.byref(self.params), device, C.byref(h))
+        if rc != abi.OK:
+            raise BackendError(f"visfs_ba_create failed with status {rc} (no MI355X / gfx950 device?)")
+        self.h = h
+        self.gb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.visfs_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what, allow=()):
+        if rc != abi.OK and rc not in allow:
+            raise BackendError(f"{what}: status {rc}: {self.lib.visfs_ba_last_error(self.h).decode()}")
+        return rc
+
+    # ---- graph layer
+    def upload(self, gb):
+        self.gb = gb
+        self._check(self.lib.visfs_ba_graph_upload(self.h, C.byref(gb.struct)), "graph_upload")
+        self.npf = self.lib.visfs_ba_graph_free_poses(self.h)
+
+    def reset(self):
+        self._check(self.lib.visfs_ba_graph_reset(self.h), "graph_reset")
+
+    def optimize(self):
+        st = abi.Stats()
+        rc = self.lib.visfs_ba_optimize(self.h, C.byref(st))
+        if rc in (abi.ERR_DEVICE, abi.ERR_NOT_LOADED, abi.ERR_BAD_ARGUMENT):
+            self._check(rc, "optimize")
+        return rc, st
+
+    def download(self):
+        g = self.gb
+        pose = np.zeros((g.n_poses, 7)); pt = np.zeros((max(g.n_points, 1), 3))
+        out = np.zeros(max(g.n_obs, 1), np.uint8); chi = np.zeros(max(g.n_obs, 1))
+        self._check(self.lib.visfs_ba_graph_download(self.h, _p(pose), _p(pt), out.ctypes.data_as(_pu8), _p(chi)), "graph_download")
+        return pose, pt[:g.n_points], out[:g.n_obs], chi[:g.n_obs]
+
+    # ---- stage hooks (parity tests)
+    def linearize(self):
+        chi, md = C.c_double(), C.c_double()
+        self._check(self.lib.visfs_ba_stage_linearize(self.h, C.byref(chi), C.byref(md)), "stage_linearize")
+        return chi.value, md.value
+
+    def trial(self, lam):
+        chi, sc, it, ok = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        self._check(self.lib.visfs_ba_stage_trial(self.h, lam, C.byref(chi), C.byref(sc), C.byref(it), C.byref(ok)), "stage_trial")
+        return chi.value, sc.value, it.value, ok.value
+
+    def fetch(self, which):
+        n6 = 6 * self.npf
+        g = self.gb
+        size = {abi.BUF_OBS_ERR: g.n_obs * 3, abi.BUF_OBS_CHI2: g.n_obs, abi.BUF_OBS_WEIGHT: g.n_obs,
+                abi.BUF_HPL: g.n_obs * 18, abi.BUF_HLL: g.n_points * 6, abi.BUF_BL: g.n_points * 3,
+                abi.BUF_HPP: n6 * n6, abi.BUF_BP: n6, abi.BUF_S: n6 * n6, abi.BUF_BS: n6,
+                abi.BUF_DX_POSE: n6, abi.BUF_DX_POINT: g.n_points * 3,
+                abi.BUF_POSE_TRIAL: g.n_poses * 7, abi.BUF_POINT_TRIAL: g.n_points * 3}[which]
+        out = np.zeros(max(size, 1))
+        self._check(self.lib.visfs_ba_stage_fetch(self.h, which, _p(out), size), "stage_fetch")
+        return out[:size]
+
+    # ---- window layer
+    def solve_window(self, wb, rb=None):
+        rb = rb if rb is not None else abi.ResultBuffers(wb.struct.n_poses, wb.struct.n_refs)
+        rc = self.lib.visfs_ba_solve_window(self.h, C.byref(wb.struct), C.byref(rb.struct))
+        if rc in (abi.ERR_DEVICE, abi.ERR_NOT_LOADED):
+            self._check(rc, "solve_window")
+        return rc, rb
+
+    def solve_batch(self, wbs):
+        n = len(wbs)
+        rbs = [abi.ResultBuffers(w.struct.n_poses, w.struct.n_refs) for w in wbs]
+        WP = C.POINTER(abi.Window) * n
+        RP = C.POINTER(abi.Result) * n
+        wa = WP(*[C.pointer(w.struct) for w in wbs])
+        ra = RP(*[C.pointer(r.struct) for r in rbs])
+        rc = self.lib.visfs_ba_solve_batch(self.h, n, wa, ra)
+        self._check(rc, "solve_batch")
+        return rbs

@@ -1,0 +1,857 @@
+// ba_api.cpp — host side of the C ABI (include/visfs_ba.h): graph build, index structures,
+// HBM residency, the enqueue loop of the device-side LM state machine, stage hooks.
+//
+// There is no CPU solve path in this library: every entry point that computes fails with
+// VISFS_BA_ERR_DEVICE when no HIP device is available.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/visfs_ba.h"
+#include "ba_kernels.hpp"
+
+using namespace visfs_ba;
+
+static_assert(MAX_TRACE == VISFS_BA_MAX_TRACE, "trace size mismatch");
+
+namespace {
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    template <typename T>
+    T* take(size_t n) {
+        used = (used + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + used);
+        used += n * sizeof(T);
+        return p;
+    }
+};
+
+// One resident window: device arena + host mirrors of what the host needs later.
+struct Workspace {
+    hipStream_t stream = nullptr;
+    char* d_base = nullptr;  size_t d_cap = 0;
+    char* h_base = nullptr;  size_t h_cap = 0;     // pinned staging, same layout as the static part
+    LmState* h_state = nullptr;                    // pinned
+    DeviceGraph g{};
+    bool loaded = false;
+    int hp = 0;                 // PCG launch parity counter
+    int pcg_slots = 24;         // k_pcg_iter launches enqueued per unit (adapts upwards)
+    // host mirrors for fetch / unpack
+    std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
+    int n6() const { return 6 * g.Npf; }
+};
+
+}  // namespace
+
+struct visfs_ba_handle {
+    visfs_ba_params prm;
+    int device = 0;
+    std::string err;
+    Workspace ws;
+    std::vector<Workspace*> batch;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            return VISFS_BA_ERR_DEVICE;                                                   \
+        }                                                                                 \
+    } while (0)
+
+int bad(visfs_ba_handle* h, const char* msg) { h->err = msg; return VISFS_BA_ERR_BAD_ARGUMENT; }
+
+void ws_release(Workspace& w) {
+    if (w.d_base) (void)hipFree(w.d_base);
+    if (w.h_base) (void)hipHostFree(w.h_base);
+    if (w.h_state) (void)hipHostFree(w.h_state);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
+    w = Workspace{};
+}
+
+int ws_init(visfs_ba_handle* h, Workspace& w) {
+    if (w.stream) return VISFS_BA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&w.h_state), sizeof(LmState), hipHostMallocDefault));
+    return VISFS_BA_OK;
+}
+
+// ------------------------------------------------------------------ graph → device structures
+int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
+    const visfs_ba_params& prm = h->prm;
+    const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = gr->n_odo;
+    if (Np < 1 || Nl < 0 || No < 0 || Ne < 0) return bad(h, "negative sizes");
+    if (Np > MAX_STAGED_POSES) { h->err = "more than 640 poses per window is not supported"; return VISFS_BA_ERR_UNSUPPORTED; }
+    for (int k = 0; k < No; ++k) {
+        const int p = gr->obs_point[k], c = gr->obs_pose[k];
+        if (p < 0 || p >= Nl || c < 0 || c >= Np) return bad(h, "observation index out of range");
+        if (k > 0 && (p < gr->obs_point[k - 1] || (p == gr->obs_point[k - 1] && c <= gr->obs_pose[k - 1])))
+            return bad(h, "observations must be sorted by (point, pose) and unique");
+    }
+    for (int e = 0; e < Ne; ++e)
+        if (gr->odo_from[e] < 0 || gr->odo_from[e] >= Np || gr->odo_to[e] < 0 || gr->odo_to[e] >= Np || gr->odo_from[e] == gr->odo_to[e])
+            return bad(h, "odometry edge index out of range");
+    int rc = ws_init(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+
+    // buildIndexMapping: free poses in index (= id) order
+    std::vector<int32_t> pose_free(Np), free_pose;
+    for (int i = 0; i < Np; ++i) { if (gr->pose_fixed[i]) pose_free[i] = -1; else { pose_free[i] = (int32_t)free_pose.size(); free_pose.push_back(i); } }
+    const int Npf = (int)free_pose.size();
+    std::vector<int32_t> lm_ptr(Nl + 1, 0);
+    for (int k = 0; k < No; ++k) lm_ptr[gr->obs_point[k] + 1]++;
+    for (int l = 0; l < Nl; ++l) lm_ptr[l + 1] += lm_ptr[l];
+    std::vector<uint8_t> obs_ok(std::max(No, 1));
+    for (int k = 0; k < No; ++k) obs_ok[k] = !(gr->pose_fixed[gr->obs_pose[k]] && gr->point_fixed[gr->obs_point[k]]);
+
+    // pose-major permutation of the observations of free poses, cut into chunks
+    std::vector<int32_t> cnt(Npf + 1, 0);
+    for (int k = 0; k < No; ++k) { const int a = pose_free[gr->obs_pose[k]]; if (a >= 0) cnt[a + 1]++; }
+    for (int a = 0; a < Npf; ++a) cnt[a + 1] += cnt[a];
+    std::vector<int32_t> pose_obs(std::max(cnt[Npf], 1)), fill(cnt.begin(), cnt.end() - 1);
+    for (int k = 0; k < No; ++k) { const int a = pose_free[gr->obs_pose[k]]; if (a >= 0) pose_obs[fill[a]++] = k; }
+    std::vector<int32_t> chunk_pose, chunk_ptr, pose_chunk_ptr(Npf + 1, 0);
+    for (int a = 0; a < Npf; ++a) {
+        pose_chunk_ptr[a] = (int32_t)chunk_pose.size();
+        for (int s = cnt[a]; s < cnt[a + 1]; s += LIN_CHUNK) { chunk_pose.push_back(a); chunk_ptr.push_back(s); }
+    }
+    pose_chunk_ptr[Npf] = (int32_t)chunk_pose.size();
+    const int n_chunks = (int)chunk_pose.size();
+    chunk_ptr.push_back(cnt[Npf]);
+    // chunk c of pose a ends where the next chunk starts, or at the end of the pose's range
+    std::vector<int32_t> chunk_end(n_chunks);
+    for (int c = 0; c < n_chunks; ++c) chunk_end[c] = std::min(chunk_ptr[c] + LIN_CHUNK, cnt[chunk_pose[c] + 1]);
+    // k_linearize reads [chunk_ptr[c], chunk_ptr[c+1]) — consecutive chunks are contiguous, so chunk_ptr[c+1] == chunk_end[c]
+    for (int c = 0; c + 1 < n_chunks; ++c) if (chunk_ptr[c + 1] != chunk_end[c]) return bad(h, "internal: chunk layout");
+
+    // odometry incidence
+    std::vector<int32_t> pose_odo_ptr(Npf + 1, 0), pose_odo;
+    {
+        std::vector<std::vector<int32_t>> inc(Npf);
+        for (int e = 0; e < Ne; ++e) {
+            const int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
+            if (a >= 0) inc[a].push_back(2 * e);
+            if (b >= 0) inc[b].push_back(2 * e + 1);
+        }
+        for (int a = 0; a < Npf; ++a) { pose_odo_ptr[a] = (int32_t)pose_odo.size(); pose_odo.insert(pose_odo.end(), inc[a].begin(), inc[a].end()); }
+        pose_odo_ptr[Npf] = (int32_t)pose_odo.size();
+    }
+
+    // S block structure (g2o buildStructure analogue): per block (i<=j) the co-observation pairs
+    std::vector<int64_t> pcount((size_t)Npf * Npf, 0);
+    std::vector<uint8_t> has_odo((size_t)Npf * Npf, 0);
+    for (int l = 0; l < Nl; ++l) {
+        if (gr->point_fixed[l]) continue;
+        for (int k1 = lm_ptr[l]; k1 < lm_ptr[l + 1]; ++k1) {
+            const int a = pose_free[gr->obs_pose[k1]];
+            if (a < 0) continue;
+            for (int k2 = k1; k2 < lm_ptr[l + 1]; ++k2) {
+                const int b = pose_free[gr->obs_pose[k2]];
+                if (b >= 0) pcount[(size_t)a * Npf + b]++;
+            }
+        }
+    }
+    for (int e = 0; e < Ne; ++e) {
+        int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
+        if (a < 0 || b < 0) continue;
+        if (a > b) std::swap(a, b);
+        has_odo[(size_t)a * Npf + b] = 1;
+    }
+    std::vector<int32_t> blk_i, blk_j, blk_ptr(1, 0), blk_of((size_t)Npf * Npf, -1);
+    int64_t npairs = 0;
+    for (int a = 0; a < Npf; ++a)
+        for (int b = a; b < Npf; ++b) {
+            const size_t key = (size_t)a * Npf + b;
+            if (a == b || pcount[key] > 0 || has_odo[key]) {
+                blk_of[key] = (int32_t)blk_i.size();
+                blk_i.push_back(a); blk_j.push_back(b);
+                npairs += pcount[key];
+                if (npairs > 0x7fffffff) { h->err = "window too large (pair list)"; return VISFS_BA_ERR_UNSUPPORTED; }
+                blk_ptr.push_back((int32_t)npairs);
+            }
+        }
+    const int n_blk = (int)blk_i.size();
+    std::vector<int2> pairs(std::max<int64_t>(npairs, 1));
+    {
+        std::vector<int32_t> pos(blk_ptr.begin(), blk_ptr.end() - 1);
+        for (int l = 0; l < Nl; ++l) {
+            if (gr->point_fixed[l]) continue;
+            for (int k1 = lm_ptr[l]; k1 < lm_ptr[l + 1]; ++k1) {
+                const int a = pose_free[gr->obs_pose[k1]];
+                if (a < 0) continue;
+                for (int k2 = k1; k2 < lm_ptr[l + 1]; ++k2) {
+                    const int b = pose_free[gr->obs_pose[k2]];
+                    if (b < 0) continue;
+                    pairs[pos[blk_of[(size_t)a * Npf + b]]++] = make_int2(k1, k2);
+                }
+            }
+        }
+    }
+    std::vector<int32_t> blk_odo_ptr(n_blk + 1, 0), blk_odo;
+    {
+        std::vector<std::vector<int32_t>> inc(n_blk);
+        for (int e = 0; e < Ne; ++e) {
+            const int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
+            if (a < 0 || b < 0) continue;
+            // Aij is (row = from, col = to): stored block is (min,max); transposed when from > to
+            if (a < b) inc[blk_of[(size_t)a * Npf + b]].push_back(2 * e);
+            else inc[blk_of[(size_t)b * Npf + a]].push_back(2 * e + 1);
+        }
+        for (int b = 0; b < n_blk; ++b) { blk_odo_ptr[b] = (int32_t)blk_odo.size(); blk_odo.insert(blk_odo.end(), inc[b].begin(), inc[b].end()); }
+        blk_odo_ptr[n_blk] = (int32_t)blk_odo.size();
+    }
+    // block-row adjacency of the symmetric S for the mat-vec
+    std::vector<int32_t> row_ptr(Npf + 1, 0), row_col, row_blk;
+    {
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> adj(Npf);
+        for (int b = 0; b < n_blk; ++b) {
+            adj[blk_i[b]].push_back({ blk_j[b], 2 * b });
+            if (blk_i[b] != blk_j[b]) adj[blk_j[b]].push_back({ blk_i[b], 2 * b + 1 });
+        }
+        for (int a = 0; a < Npf; ++a) {
+            std::sort(adj[a].begin(), adj[a].end());
+            row_ptr[a] = (int32_t)row_col.size();
+            for (auto& pr : adj[a]) { row_col.push_back(pr.first); row_blk.push_back(pr.second); }
+        }
+        row_ptr[Npf] = (int32_t)row_col.size();
+    }
+
+    // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
+    int group = 4;
+    const double mean_track = Nl > 0 ? (double)No / Nl : 1.0;
+    while (group < 64 && group < mean_track) group *= 2;
+    const int n_lin_a = std::max(1, (Nl + (256 / group) - 1) / (256 / group));
+    const int n_eval = (No + 255) / 256 + 1;
+    const int n_parts = std::max(n_lin_a + 1, n_eval);
+    const size_t n6 = (size_t)6 * Npf;
+
+    // ---- lay out the static section (host staging == device layout), then the mutable section
+    auto layout = [&](Arena& A, DeviceGraph& g, bool is_static_pass) {
+        (void)is_static_pass;
+        g.pose0 = A.take<double>((size_t)Np * POSE_STRIDE);
+        g.pt0 = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.pose_free = A.take<int32_t>(Np);
+        g.free_pose = A.take<int32_t>(std::max(Npf, 1));
+        g.pt_fixed = A.take<uint8_t>(std::max(Nl, 1));
+        g.obs_pose = A.take<int32_t>(std::max(No, 1));
+        g.obs_pt = A.take<int32_t>(std::max(No, 1));
+        g.obs_uvr = A.take<double>((size_t)std::max(No, 1) * 3);
+        g.obs_ok = A.take<uint8_t>(std::max(No, 1));
+        g.lm_ptr = A.take<int32_t>(Nl + 1);
+        g.chunk_pose = A.take<int32_t>(std::max(n_chunks, 1));
+        g.chunk_ptr = A.take<int32_t>(n_chunks + 1);
+        g.pose_obs = A.take<int32_t>(pose_obs.size());
+        g.pose_chunk_ptr = A.take<int32_t>(Npf + 1);
+        g.odo_i = A.take<int32_t>(std::max(Ne, 1));
+        g.odo_j = A.take<int32_t>(std::max(Ne, 1));
+        g.odo_tq = A.take<double>((size_t)std::max(Ne, 1) * 7);
+        g.pose_odo_ptr = A.take<int32_t>(Npf + 1);
+        g.pose_odo = A.take<int32_t>(std::max<size_t>(pose_odo.size(), 1));
+        g.blk_i = A.take<int32_t>(std::max(n_blk, 1));
+        g.blk_j = A.take<int32_t>(std::max(n_blk, 1));
+        g.blk_ptr = A.take<int32_t>(n_blk + 1);
+        g.blk_pairs = A.take<int2>(pairs.size());
+        g.blk_odo_ptr = A.take<int32_t>(n_blk + 1);
+        g.blk_odo = A.take<int32_t>(std::max<size_t>(blk_odo.size(), 1));
+        g.row_ptr = A.take<int32_t>(Npf + 1);
+        g.row_col = A.take<int32_t>(std::max<size_t>(row_col.size(), 1));
+        g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
+    };
+    DeviceGraph hg{};                 // pointers into the pinned staging arena
+    Arena sizing{ nullptr, 0, 0 };
+    layout(sizing, hg, true);
+    const size_t static_bytes = (sizing.used + 255) & ~size_t(255);
+
+    Arena dyn{ nullptr, 0, static_bytes };
+    DeviceGraph dg{};
+    auto layout_dyn = [&](Arena& A, DeviceGraph& g) {
+        g.pose[0] = A.take<double>((size_t)Np * POSE_STRIDE); g.pose[1] = A.take<double>((size_t)Np * POSE_STRIDE);
+        g.pt[0] = A.take<double>((size_t)std::max(Nl, 1) * 3); g.pt[1] = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.obs_level = A.take<uint8_t>(std::max(No, 1));
+        g.obs_outlier = A.take<uint8_t>(std::max(No, 1));
+        g.obs_chi2_out = A.take<double>(std::max(No, 1));
+        g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);
+        g.obs_chi2 = A.take<double>(std::max(No, 1));
+        g.obs_w = A.take<double>(std::max(No, 1));
+        g.W = A.take<double>((size_t)std::max(No, 1) * 18);
+        g.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
+        g.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
+        g.odo_blk = A.take<double>((size_t)std::max(Ne, 1) * 120);
+        g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
+        g.bp = A.take<double>(std::max<size_t>(n6, 1));
+        g.pose_pin = A.take<int32_t>(std::max(Npf, 1));
+        g.lin_part = A.take<double>((size_t)n_parts * 2);
+        g.S = A.take<double>((size_t)std::max(n_blk, 1) * 36);
+        g.bs = A.take<double>(std::max<size_t>(n6, 1));
+        g.Minv = A.take<double>((size_t)std::max(Npf, 1) * 36);
+        g.x = A.take<double>(std::max<size_t>(n6, 1));
+        for (int p = 0; p < 2; ++p) { g.pcg_r[p] = A.take<double>(std::max<size_t>(n6, 1)); g.pcg_d[p] = A.take<double>(std::max<size_t>(n6, 1)); g.pcg_q[p] = A.take<double>(std::max<size_t>(n6, 1)); }
+        g.pcg_ctl = A.take<PcgCtl>(2);
+        g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.trial_part = A.take<double>((size_t)n_parts * 2);
+        g.dense = A.take<double>(prm.solver == 2 ? 1 : std::max<size_t>(n6 * n6, 1));
+        g.st = A.take<LmState>(1);
+    };
+    layout_dyn(dyn, dg);
+    const size_t total_bytes = (dyn.used + 255) & ~size_t(255);
+
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (w.d_cap < total_bytes) {
+        if (w.d_base) (void)hipFree(w.d_base);
+        w.d_base = nullptr; w.d_cap = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&w.d_base), total_bytes));
+        w.d_cap = total_bytes;
+    }
+    if (w.h_cap < static_bytes) {
+        if (w.h_base) (void)hipHostFree(w.h_base);
+        w.h_base = nullptr; w.h_cap = 0;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&w.h_base), static_bytes, hipHostMallocDefault));
+        w.h_cap = static_bytes;
+    }
+    // fill the staging arena
+    Arena hs{ w.h_base, w.h_cap, 0 };
+    layout(hs, hg, true);
+    {
+        double* p0 = const_cast<double*>(hg.pose0);
+        for (int i = 0; i < Np; ++i) { for (int q = 0; q < 7; ++q) p0[POSE_STRIDE * i + q] = gr->pose_tq[7 * i + q]; p0[POSE_STRIDE * i + 7] = 0.0; }
+        if (Nl) std::memcpy(const_cast<double*>(hg.pt0), gr->point_xyz, (size_t)Nl * 24);
+        std::memcpy(const_cast<int32_t*>(hg.pose_free), pose_free.data(), (size_t)Np * 4);
+        if (Npf) std::memcpy(const_cast<int32_t*>(hg.free_pose), free_pose.data(), (size_t)Npf * 4);
+        if (Nl) std::memcpy(const_cast<uint8_t*>(hg.pt_fixed), gr->point_fixed, Nl);
+        if (No) {
+            std::memcpy(const_cast<int32_t*>(hg.obs_pose), gr->obs_pose, (size_t)No * 4);
+            std::memcpy(const_cast<int32_t*>(hg.obs_pt), gr->obs_point, (size_t)No * 4);
+            std::memcpy(const_cast<double*>(hg.obs_uvr), gr->obs_uvr, (size_t)No * 24);
+            std::memcpy(const_cast<uint8_t*>(hg.obs_ok), obs_ok.data(), No);
+        }
+        std::memcpy(const_cast<int32_t*>(hg.lm_ptr), lm_ptr.data(), (size_t)(Nl + 1) * 4);
+        if (n_chunks) std::memcpy(const_cast<int32_t*>(hg.chunk_pose), chunk_pose.data(), (size_t)n_chunks * 4);
+        std::memcpy(const_cast<int32_t*>(hg.chunk_ptr), chunk_ptr.data(), (size_t)(n_chunks + 1) * 4);
+        std::memcpy(const_cast<int32_t*>(hg.pose_obs), pose_obs.data(), pose_obs.size() * 4);
+        std::memcpy(const_cast<int32_t*>(hg.pose_chunk_ptr), pose_chunk_ptr.data(), (size_t)(Npf + 1) * 4);
+        if (Ne) {
+            std::memcpy(const_cast<int32_t*>(hg.odo_i), gr->odo_from, (size_t)Ne * 4);
+            std::memcpy(const_cast<int32_t*>(hg.odo_j), gr->odo_to, (size_t)Ne * 4);
+            std::memcpy(const_cast<double*>(hg.odo_tq), gr->odo_tq, (size_t)Ne * 56);
+        }
+        std::memcpy(const_cast<int32_t*>(hg.pose_odo_ptr), pose_odo_ptr.data(), (size_t)(Npf + 1) * 4);
+        if (!pose_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.pose_odo), pose_odo.data(), pose_odo.size() * 4);
+        if (n_blk) { std::memcpy(const_cast<int32_t*>(hg.blk_i), blk_i.data(), (size_t)n_blk * 4); std::memcpy(const_cast<int32_t*>(hg.blk_j), blk_j.data(), (size_t)n_blk * 4); }
+        std::memcpy(const_cast<int32_t*>(hg.blk_ptr), blk_ptr.data(), (size_t)(n_blk + 1) * 4);
+        std::memcpy(const_cast<int2*>(hg.blk_pairs), pairs.data(), pairs.size() * sizeof(int2));
+        std::memcpy(const_cast<int32_t*>(hg.blk_odo_ptr), blk_odo_ptr.data(), (size_t)(n_blk + 1) * 4);
+        if (!blk_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.blk_odo), blk_odo.data(), blk_odo.size() * 4);
+        std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
+        if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
+    }
+    // device pointers: same offsets
+    Arena ds{ w.d_base, w.d_cap, 0 };
+    layout(ds, dg, true);
+    Arena dd{ w.d_base, w.d_cap, static_bytes };
+    layout_dyn(dd, dg);
+    dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
+    dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group;
+    dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
+    dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
+    dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
+    dg.huber_delta = prm.robust_kernel_delta;             // Optimizer.cpp:212-216
+    dg.debug = 0;
+    w.g = dg;
+    w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
+    w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
+    HIP_TRY(h, hipMemcpyAsync(w.d_base, w.h_base, static_bytes, hipMemcpyHostToDevice, w.stream));
+    HIP_TRY(h, hipMemsetAsync(w.d_base + static_bytes, 0, total_bytes - static_bytes, w.stream));
+    if (configure_kernels(w.g) != 0) { h->err = "hipFuncSetAttribute failed"; return VISFS_BA_ERR_DEVICE; }
+    launch_reset(w.g, prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(w.stream));            // staging arena is reused by the next upload
+    w.loaded = true;
+    w.hp = 0;
+    return VISFS_BA_OK;
+}
+
+int ws_read_state(visfs_ba_handle* h, Workspace& w) {
+    HIP_TRY(h, hipMemcpyAsync(w.h_state, w.g.st, sizeof(LmState), hipMemcpyDeviceToHost, w.stream));
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
+    return VISFS_BA_OK;
+}
+
+// One unit of the LM state machine (gated on the device; see ba_kernels.hip header).
+void enqueue_unit(visfs_ba_handle* h, Workspace& w) {
+    launch_linearize(w.g, w.stream);
+    launch_schur(w.g, w.stream);
+    if (h->prm.solver == 2) {
+        launch_pcg_init(w.g, w.hp & 1, w.stream);
+        for (int s = 0; s < w.pcg_slots; ++s) { launch_pcg_iter(w.g, w.hp & 1, w.stream); w.hp++; }
+    } else {
+        launch_direct(w.g, w.stream);
+    }
+    launch_backsub(w.g, w.stream);
+    launch_decide(w.g, w.stream);
+}
+
+// optimizer.optimize(n) for the phase armed in LmState: enqueue units until the device reports `done`.
+int run_phase(visfs_ba_handle* h, Workspace& w, int max_iter) {
+    if (max_iter <= 0) return VISFS_BA_OK;
+    int guard = 0;
+    int remaining = max_iter;
+    while (true) {
+        for (int u = 0; u < remaining; ++u) enqueue_unit(h, w);
+        HIP_TRY(h, hipGetLastError());
+        int rc = ws_read_state(h, w);
+        if (rc != VISFS_BA_OK) return rc;
+        const LmState& st = *w.h_state;
+        if (st.done) break;
+        if (st.solve_state == 1 && w.pcg_slots < 6 * w.g.Npf + 2) w.pcg_slots = std::min(2 * w.pcg_slots, 6 * w.g.Npf + 2);   // PCG needed more launches than one unit holds
+        remaining = std::max(1, max_iter - st.phase_iter);
+        if (++guard > 64 * max_iter + 64) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
+    }
+    return VISFS_BA_OK;
+}
+
+void fill_stats(const LmState& st, visfs_ba_stats* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->status = st.status;
+    out->iterations_run[0] = st.iterations_run[0]; out->iterations_run[1] = st.iterations_run[1];
+    out->trials_run[0] = st.trials_run[0]; out->trials_run[1] = st.trials_run[1];
+    out->pcg_iterations = st.pcg_total;
+    out->n_outliers = st.n_outliers;
+    out->chi2_initial = st.chi2_initial; out->chi2_phase1 = st.chi2_phase1; out->chi2_final = st.chi2_final;
+    out->n_trace = st.n_trace;
+    for (int i = 0; i < st.n_trace && i < MAX_TRACE; ++i) { out->trace_lambda[i] = st.trace_lambda[i]; out->trace_chi2[i] = st.trace_chi2[i]; }
+}
+
+// Optimizer.cpp:261-318 on the resident graph.
+int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    const int half = h->prm.iterations / 2;
+    // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
+    launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream);
+    int rc = run_phase(h, w, half);                               // :265
+    if (rc != VISFS_BA_OK) return rc;
+    launch_phase_end(w.g, 0, 1, half, w.stream);                  // :270-303
+    rc = run_phase(h, w, (h->prm.robust_kernel_delta > 0.0) ? half : 0);   // :310-311 (gated off on abort)
+    if (rc != VISFS_BA_OK) return rc;
+    launch_phase_end(w.g, 1, 0, 0, w.stream);                     // :315-318
+    HIP_TRY(h, hipGetLastError());
+    rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    if (stats) fill_stats(*w.h_state, stats);
+    if (h->prm.solver == 2 && w.h_state->pcg_max > 0) w.pcg_slots = std::max(4, w.h_state->pcg_max + 2);   // right-size the next enqueue
+    return w.h_state->status;
+}
+
+int ws_download(visfs_ba_handle* h, Workspace& w, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2) {
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    int rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    const int sel = w.h_state->sel;
+    const DeviceGraph& g = w.g;
+    if (pose_tq) {
+        std::vector<double> tmp((size_t)g.Np * POSE_STRIDE);
+        HIP_TRY(h, hipMemcpyAsync(tmp.data(), g.pose[sel], tmp.size() * 8, hipMemcpyDeviceToHost, w.stream));
+        HIP_TRY(h, hipStreamSynchronize(w.stream));
+        for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) pose_tq[7 * i + q] = tmp[POSE_STRIDE * i + q];
+    }
+    if (point_xyz && g.Nl) HIP_TRY(h, hipMemcpyAsync(point_xyz, g.pt[sel], (size_t)g.Nl * 24, hipMemcpyDeviceToHost, w.stream));
+    if (obs_outlier && g.No) HIP_TRY(h, hipMemcpyAsync(obs_outlier, g.obs_outlier, g.No, hipMemcpyDeviceToHost, w.stream));
+    if (obs_chi2 && g.No) HIP_TRY(h, hipMemcpyAsync(obs_chi2, g.obs_chi2_out, (size_t)g.No * 8, hipMemcpyDeviceToHost, w.stream));
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
+    return VISFS_BA_OK;
+}
+
+// ------------------------------------------------------------------ window layer
+int find_id(const uint64_t* ids, int n, uint64_t id) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        if (ids[mid] == id) return mid;
+        if (ids[mid] < id) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+struct PackedWindow {
+    std::vector<double> pose_tq, obs_uvr, odo_tq;
+    std::vector<uint8_t> pose_fixed, point_used;
+    std::vector<int32_t> obs_point, obs_pose, obs_ref, odo_from, odo_to;
+    visfs_ba_graph g{};
+    int32_t mono = 0;
+};
+
+int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r) {
+    const visfs_ba_params& prm = h->prm;
+    r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
+    r->iterations_run[0] = r->iterations_run[1] = 0;
+    r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
+    if (prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return r->status = VISFS_BA_ERR_UNSUPPORTED; }
+    if (win->n_laser_points != 0) { h->err = "laser occupied-space factor is out of scope"; return r->status = VISFS_BA_ERR_UNSUPPORTED; }
+    if (win->n_poses < 0 || win->n_points < 0 || win->n_refs < 0 || win->n_links < 0) return r->status = bad(h, "negative sizes");
+    // guards of Optimizer.cpp:74 and :360-364
+    if (!(win->n_poses >= 2 && prm.iterations > 0 && win->pose_ids[0] > 0)) {
+        if (win->n_poses == 1 || prm.iterations <= 0) {
+            for (int i = 0; i < win->n_poses; ++i) { r->pose_ids_out[i] = win->pose_ids[i]; std::memcpy(r->pose_Twr_out + 12 * i, win->pose_Twr + 12 * i, 96); }
+            r->n_poses_out = win->n_poses;
+            return r->status = VISFS_BA_PASSTHROUGH;
+        }
+        return r->status = VISFS_BA_ERR_TOO_FEW_POSES;
+    }
+    for (int i = 1; i < win->n_poses; ++i) if (win->pose_ids[i] <= win->pose_ids[i - 1]) return r->status = bad(h, "pose ids must ascend (std::map order)");
+    for (int i = 1; i < win->n_points; ++i) if (win->point_ids[i] <= win->point_ids[i - 1]) return r->status = bad(h, "point ids must ascend (std::map order)");
+    PackedWindow pk;
+    const int Np = win->n_poses, Nl = win->n_points, Nr = win->n_refs, Nk = win->n_links;
+    pk.pose_tq.resize((size_t)Np * 7); pk.pose_fixed.resize(Np); pk.point_used.resize(std::max(Nl, 1));
+    pk.obs_point.resize(std::max(Nr, 1)); pk.obs_pose.resize(std::max(Nr, 1)); pk.obs_ref.resize(std::max(Nr, 1)); pk.obs_uvr.resize((size_t)std::max(Nr, 1) * 3);
+    pk.odo_from.resize(std::max(Nk, 1)); pk.odo_to.resize(std::max(Nk, 1)); pk.odo_tq.resize((size_t)std::max(Nk, 1) * 7);
+    int rc = visfs_ba_pack_window(&prm, win, pk.pose_tq.data(), pk.pose_fixed.data(), pk.point_used.data(), pk.obs_point.data(), pk.obs_pose.data(),
+                                  pk.obs_uvr.data(), pk.obs_ref.data(), pk.odo_from.data(), pk.odo_to.data(), pk.odo_tq.data(), &pk.g, &pk.mono);
+    if (rc != VISFS_BA_OK) return r->status = bad(h, "window references must be sorted by (feature, pose)");
+    r->warn_mono_skipped = pk.mono;
+    rc = ws_upload(h, w, &pk.g);
+    if (rc != VISFS_BA_OK) return r->status = rc;
+    visfs_ba_stats st;
+    rc = ws_optimize(h, w, &st);
+    if (rc == VISFS_BA_ERR_DEVICE || rc == VISFS_BA_ERR_NOT_LOADED) return r->status = rc;
+    r->status = rc;
+    r->iterations_run[0] = st.iterations_run[0]; r->iterations_run[1] = st.iterations_run[1];
+    r->chi2_initial = st.chi2_initial; r->chi2_phase1 = st.chi2_phase1; r->chi2_final = st.chi2_final;
+    if (rc != VISFS_BA_OK && rc != VISFS_BA_ERR_HUGE_CHI2_2) return rc;
+    std::vector<double> pose((size_t)Np * 7), pts((size_t)std::max(Nl, 1) * 3);
+    std::vector<uint8_t> outl(std::max(pk.g.n_obs, 1));
+    int rc2 = ws_download(h, w, pose.data(), pts.data(), outl.data(), nullptr);
+    if (rc2 != VISFS_BA_OK) return r->status = rc2;
+    // outliers are appended at Optimizer.cpp:296, before the phase-2 abort check
+    int n = 0;
+    for (int k = 0; k < pk.g.n_obs; ++k)
+        if (outl[k] && n < r->outlier_capacity) { r->outlier_feature[n] = win->ref_feature[pk.obs_ref[k]]; r->outlier_pose[n] = win->ref_pose[pk.obs_ref[k]]; ++n; }
+    r->n_outliers = n;
+    if (rc != VISFS_BA_OK) return rc;
+    for (int i = 0; i < Np; ++i) { r->pose_ids_out[i] = win->pose_ids[i]; visfs_ba_unpack_pose(pose.data() + 7 * i, win->Trc, r->pose_Twr_out + 12 * i); }   // :320-340
+    r->n_poses_out = Np;
+    for (int l = 0; l < Nl; ++l) {                                  // :343-358
+        double* p = win->point_xyz + 3 * l;
+        if (pk.point_used[l]) {
+            const double dx = p[0] - pts[3 * l], dy = p[1] - pts[3 * l + 1], dz = p[2] - pts[3 * l + 2];
+            if (std::sqrt(dx * dx + dy * dy + dz * dz) < 5.0) { p[0] = pts[3 * l]; p[1] = pts[3 * l + 1]; p[2] = pts[3 * l + 2]; }
+        } else { p[0] = p[1] = p[2] = std::nan(""); }
+    }
+    return VISFS_BA_OK;
+}
+
+}  // namespace
+
+// ====================================================================== exported C ABI
+extern "C" {
+
+int visfs_ba_abi_version(void) { return VISFS_BA_ABI_VERSION; }
+
+void visfs_ba_default_params(visfs_ba_params* p) {
+    // Parameters.h:184-191
+    p->framework = 0; p->solver = 0; p->trust_region = 0; p->iterations = 10;
+    p->pixel_variance = 1.5; p->odometry_covariance = 0.00005; p->laser_covariance = 0.1; p->robust_kernel_delta = 8.0;
+}
+
+int visfs_ba_create(const visfs_ba_params* params, int device_index, visfs_ba_handle** out) {
+    if (!out || !params) return VISFS_BA_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_index < 0 || device_index >= n) return VISFS_BA_ERR_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) return VISFS_BA_ERR_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VISFS_BA_ERR_DEVICE;     // kernels are built for gfx950 only
+    visfs_ba_handle* h = new visfs_ba_handle();
+    h->prm = *params;
+    h->device = device_index;
+    if (ws_init(h, h->ws) != VISFS_BA_OK) { delete h; return VISFS_BA_ERR_DEVICE; }
+    *out = h;
+    return VISFS_BA_OK;
+}
+
+void visfs_ba_destroy(visfs_ba_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    ws_release(h->ws);
+    for (Workspace* w : h->batch) { ws_release(*w); delete w; }
+    delete h;
+}
+
+const char* visfs_ba_last_error(const visfs_ba_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int visfs_ba_pack_window(const visfs_ba_params* params, const visfs_ba_window* w,
+                         double* pose_tq, uint8_t* pose_fixed, uint8_t* point_used,
+                         int32_t* obs_point, int32_t* obs_pose, double* obs_uvr, int32_t* obs_ref,
+                         int32_t* odo_from, int32_t* odo_to, double* odo_tq,
+                         visfs_ba_graph* g, int32_t* n_mono_skipped) {
+    (void)params;
+    std::memset(g, 0, sizeof(*g));
+    // poses: Twc = Twr * Trc ; Tcw = Twc^-1 as CameraPose(R,t) ; fixed iff id == rootId   (Optimizer.cpp:100-114)
+    for (int i = 0; i < w->n_poses; ++i) {
+        double Twc[12], Tcw[12];
+        iso_mul(w->pose_Twr + 12 * i, w->Trc, Twc);
+        iso_inv(Twc, Tcw);
+        iso_to_tq(Tcw, pose_tq + 7 * i);
+        pose_fixed[i] = (w->pose_ids[i] == w->root_id);
+    }
+    // links: T_c1c2 = Trc^-1 * T_r1r2 * Trc as SE3Quat   (Optimizer.cpp:123-150)
+    int ne = 0;
+    double Tcr[12];
+    iso_inv(w->Trc, Tcr);
+    for (int k = 0; k < w->n_links; ++k) {
+        const uint64_t from = w->link_from[k], to = w->link_to[k];
+        if (from == 0 || to == 0) continue;
+        const int a = find_id(w->pose_ids, w->n_poses, from), b = find_id(w->pose_ids, w->n_poses, to);
+        if (a < 0 || b < 0 || from == to) continue;
+        double T1[12], T2[12];
+        iso_mul(Tcr, w->link_T + 12 * k, T1);
+        iso_mul(T1, w->Trc, T2);
+        iso_to_tq(T2, odo_tq + 7 * ne);
+        odo_from[ne] = a; odo_to[ne] = b;
+        ++ne;
+    }
+    // landmarks + stereo edges   (Optimizer.cpp:153-223)
+    std::memset(point_used, 0, (size_t)w->n_points);
+    int no = 0, mono = 0, last_p = -1, last_c = -1;
+    for (int k = 0; k < w->n_refs; ++k) {
+        const int p = find_id(w->point_ids, w->n_points, w->ref_feature[k]);
+        if (p < 0) continue;                                                    // :158
+        point_used[p] = 1;
+        const int c = find_id(w->pose_ids, w->n_poses, w->ref_pose[k]);
+        if (c < 0 || w->ref_pose[k] == 0) continue;                             // :172
+        const double depth = (double)w->ref_depth[k];                           // :174
+        double baseLine = 0.0;
+        if (w->n_cameras > 1) baseLine = (double)w->baseline;                   // :181-183
+        if (std::isfinite(depth) && depth > 0.0 && baseLine > 0.0) {
+            if (p < last_p || (p == last_p && c <= last_c)) return VISFS_BA_ERR_BAD_ARGUMENT;   // nested std::map order
+            last_p = p; last_c = c;
+            const float disparity = static_cast<float>(baseLine * w->fx / depth);               // :187
+            obs_uvr[3 * no + 0] = (double)w->ref_u[k];
+            obs_uvr[3 * no + 1] = (double)w->ref_v[k];
+            obs_uvr[3 * no + 2] = (double)(w->ref_u[k] - disparity);                            // float - float, :188
+            obs_point[no] = p; obs_pose[no] = c;
+            if (obs_ref) obs_ref[no] = k;
+            ++no;
+        } else {
+            ++mono;   // the reference dereferences an uninitialised edge pointer here (:179, :197-210); we skip the observation
+        }
+    }
+    if (n_mono_skipped) *n_mono_skipped = mono;
+    g->n_poses = w->n_poses; g->n_points = w->n_points; g->n_obs = no; g->n_odo = ne;
+    g->pose_tq = pose_tq; g->pose_fixed = pose_fixed;
+    g->point_xyz = w->point_xyz; g->point_fixed = w->point_fixed;
+    g->obs_point = obs_point; g->obs_pose = obs_pose; g->obs_uvr = obs_uvr;
+    g->odo_from = odo_from; g->odo_to = odo_to; g->odo_tq = odo_tq;
+    g->fx = w->fx; g->fy = w->fy; g->cx = w->cx; g->cy = w->cy;
+    g->bf = ((w->n_cameras > 1) ? (double)w->baseline : 0.0) * w->fx;          // :195
+    return VISFS_BA_OK;
+}
+
+void visfs_ba_unpack_pose(const double* tq, const double* Trc, double* Twr_out) {
+    // Twr = Tcw^-1 * Trc^-1   (Optimizer.cpp:324-329)
+    const Rt T = pose_to_Rt(tq);
+    const double Tcw[12] = { T.R.m00, T.R.m01, T.R.m02, T.t.x, T.R.m10, T.R.m11, T.R.m12, T.t.y, T.R.m20, T.R.m21, T.R.m22, T.t.z };
+    double Twc[12], Tcr[12];
+    iso_inv(Tcw, Twc);
+    iso_inv(Trc, Tcr);
+    iso_mul(Twc, Tcr, Twr_out);
+}
+
+int visfs_ba_graph_upload(visfs_ba_handle* h, const visfs_ba_graph* g) {
+    if (!h || !g) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (h->prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return VISFS_BA_ERR_UNSUPPORTED; }
+    return ws_upload(h, h->ws, g);
+}
+
+int visfs_ba_graph_reset(visfs_ba_handle* h) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (!h->ws.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    launch_reset(h->ws.g, h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
+    HIP_TRY(h, hipGetLastError());
+    return VISFS_BA_OK;
+}
+
+int visfs_ba_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    return ws_optimize(h, h->ws, stats);
+}
+
+int visfs_ba_graph_download(visfs_ba_handle* h, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    return ws_download(h, h->ws, pose_tq, point_xyz, obs_outlier, obs_chi2);
+}
+
+int visfs_ba_solve_window(visfs_ba_handle* h, const visfs_ba_window* w, visfs_ba_result* r) {
+    if (!h || !w || !r) return VISFS_BA_ERR_BAD_ARGUMENT;
+    return solve_window_on(h, h->ws, w, r);
+}
+
+int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r) {
+    if (!h || n < 0 || (n > 0 && (!w || !r))) return VISFS_BA_ERR_BAD_ARGUMENT;
+    // independent windows: one workspace + stream + host thread per in-flight window
+    const int lanes = std::min<int>(n, 8);
+    while ((int)h->batch.size() < lanes) h->batch.push_back(new Workspace());
+    std::vector<int> rcs(n, VISFS_BA_OK);
+    std::vector<std::string> errs(lanes);
+    std::vector<std::thread> th;
+    for (int t = 0; t < lanes; ++t) {
+        th.emplace_back([&, t]() {
+            (void)hipSetDevice(h->device);
+            visfs_ba_handle local;            // per-thread error string; shares params / device
+            local.prm = h->prm; local.device = h->device;
+            for (int i = t; i < n; i += lanes) rcs[i] = solve_window_on(&local, *h->batch[t], w[i], r[i]);
+            errs[t] = local.err;
+        });
+    }
+    for (auto& x : th) x.join();
+    int worst = VISFS_BA_OK;
+    for (int i = 0; i < n; ++i) if (rcs[i] == VISFS_BA_ERR_DEVICE) worst = VISFS_BA_ERR_DEVICE;
+    for (int t = 0; t < lanes; ++t) if (!errs[t].empty()) h->err = errs[t];
+    return worst;
+}
+
+// ---------------------------------------------------------------- stage hooks
+int visfs_ba_graph_free_poses(visfs_ba_handle* h) { return (h && h->ws.loaded) ? h->ws.g.Npf : -1; }
+
+int visfs_ba_stage_linearize(visfs_ba_handle* h, double* robust_chi2, double* max_diag) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    DeviceGraph g = w.g;
+    g.debug = 1;
+    launch_stage_arm(g, 0.0, 1, w.stream);
+    launch_linearize(g, w.stream);
+    HIP_TRY(h, hipGetLastError());
+    int rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    if (robust_chi2) *robust_chi2 = w.h_state->current_chi;
+    if (max_diag) *max_diag = w.h_state->max_diag;
+    return VISFS_BA_OK;
+}
+
+int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, double* scale, int32_t* pcg_iterations, int32_t* solver_ok) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    int rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    const int sel0 = w.h_state->sel;
+    const double chi0 = w.h_state->current_chi;
+    launch_stage_arm(w.g, lambda, 0, w.stream);
+    launch_schur(w.g, w.stream);
+    if (h->prm.solver == 2) {
+        launch_pcg_init(w.g, w.hp & 1, w.stream);
+        for (int guard = 0; guard < 6 * w.g.Npf + 8; guard += 16) {
+            for (int s = 0; s < 16; ++s) { launch_pcg_iter(w.g, w.hp & 1, w.stream); w.hp++; }
+            rc = ws_read_state(h, w);
+            if (rc != VISFS_BA_OK) return rc;
+            if (w.h_state->solve_state != 1) break;
+        }
+    } else {
+        launch_direct(w.g, w.stream);
+    }
+    launch_backsub(w.g, w.stream);
+    HIP_TRY(h, hipGetLastError());
+    rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    const int ok = (w.h_state->solve_state == 2);
+    if (pcg_iterations) *pcg_iterations = w.h_state->pcg_iter;
+    if (solver_ok) *solver_ok = ok;
+    launch_decide(w.g, w.stream);                    // production K9 computes tempChi / scale ...
+    HIP_TRY(h, hipGetLastError());
+    rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    if (trial_chi2) *trial_chi2 = w.h_state->temp_chi;
+    if (scale) *scale = w.h_state->scale - 1e-3;     // report computeScale() without the +1e-3 guard
+    // ... and the hook then undoes the commit so the resident estimate is unchanged
+    LmState st = *w.h_state;
+    st.sel = sel0; st.current_chi = chi0; st.solve_state = 0; st.done = 0;
+    *w.h_state = st;
+    HIP_TRY(h, hipMemcpyAsync(w.g.st, w.h_state, sizeof(LmState), hipMemcpyHostToDevice, w.stream));
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
+    return VISFS_BA_OK;
+}
+
+int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {
+    if (!h || !dst) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    const DeviceGraph& g = w.g;
+    const size_t n6 = (size_t)w.n6();
+    int rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    const int sel = w.h_state->sel;
+    const double* src = nullptr; size_t m = 0;
+    switch (which) {
+        case VISFS_BA_BUF_OBS_ERR: src = g.obs_err; m = (size_t)g.No * 3; break;
+        case VISFS_BA_BUF_OBS_CHI2: src = g.obs_chi2; m = g.No; break;
+        case VISFS_BA_BUF_OBS_WEIGHT: src = g.obs_w; m = g.No; break;
+        case VISFS_BA_BUF_HPL: src = g.W; m = (size_t)g.No * 18; break;
+        case VISFS_BA_BUF_HLL: src = g.Hll; m = (size_t)g.Nl * 6; break;
+        case VISFS_BA_BUF_BL: src = g.bl; m = (size_t)g.Nl * 3; break;
+        case VISFS_BA_BUF_BP: src = g.bp; m = n6; break;
+        case VISFS_BA_BUF_BS: src = g.bs; m = n6; break;
+        case VISFS_BA_BUF_DX_POSE: src = g.x; m = n6; break;
+        case VISFS_BA_BUF_DX_POINT: src = g.dxl; m = (size_t)g.Nl * 3; break;
+        case VISFS_BA_BUF_POINT_TRIAL: src = g.pt[sel ^ 1]; m = (size_t)g.Nl * 3; break;
+        case VISFS_BA_BUF_HPP: case VISFS_BA_BUF_S: m = n6 * n6; break;
+        case VISFS_BA_BUF_POSE_TRIAL: m = (size_t)g.Np * 7; break;
+        default: return bad(h, "unknown buffer id");
+    }
+    if (n_doubles < m) return bad(h, "destination too small");
+    if (src) {
+        if (m) HIP_TRY(h, hipMemcpyAsync(dst, src, m * 8, hipMemcpyDeviceToHost, w.stream));
+        HIP_TRY(h, hipStreamSynchronize(w.stream));
+        return VISFS_BA_OK;
+    }
+    if (which == VISFS_BA_BUF_POSE_TRIAL) {
+        std::vector<double> tmp((size_t)g.Np * POSE_STRIDE);
+        HIP_TRY(h, hipMemcpyAsync(tmp.data(), g.pose[sel ^ 1], tmp.size() * 8, hipMemcpyDeviceToHost, w.stream));
+        HIP_TRY(h, hipStreamSynchronize(w.stream));
+        for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) dst[7 * i + q] = tmp[POSE_STRIDE * i + q];
+        return VISFS_BA_OK;
+    }
+    std::memset(dst, 0, m * 8);
+    if (which == VISFS_BA_BUF_S) {
+        std::vector<double> blk((size_t)g.n_blk * 36);
+        HIP_TRY(h, hipMemcpyAsync(blk.data(), g.S, blk.size() * 8, hipMemcpyDeviceToHost, w.stream));
+        HIP_TRY(h, hipStreamSynchronize(w.stream));
+        for (int b = 0; b < g.n_blk; ++b)
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+                const double v = blk[36 * (size_t)b + 6 * r + c];
+                dst[(size_t)(6 * w.blk_i[b] + r) * n6 + 6 * w.blk_j[b] + c] = v;
+                dst[(size_t)(6 * w.blk_j[b] + c) * n6 + 6 * w.blk_i[b] + r] = v;
+            }
+        return VISFS_BA_OK;
+    }
+    // HPP: diagonal blocks + odometry off-diagonal blocks
+    std::vector<double> diag((size_t)std::max(g.Npf, 1) * 36), odo((size_t)std::max(g.Ne, 1) * 120);
+    HIP_TRY(h, hipMemcpyAsync(diag.data(), g.Hpp, (size_t)g.Npf * 36 * 8, hipMemcpyDeviceToHost, w.stream));
+    if (g.Ne) HIP_TRY(h, hipMemcpyAsync(odo.data(), g.odo_blk, (size_t)g.Ne * 120 * 8, hipMemcpyDeviceToHost, w.stream));
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
+    for (int a = 0; a < g.Npf; ++a)
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) dst[(size_t)(6 * a + r) * n6 + 6 * a + c] = diag[36 * (size_t)a + 6 * r + c];
+    for (int e = 0; e < g.Ne; ++e) {
+        const int a = w.pose_free[w.odo_i[e]], b = w.pose_free[w.odo_j[e]];
+        if (a < 0 || b < 0) continue;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+            const double v = odo[120 * (size_t)e + 72 + 6 * r + c];
+            dst[(size_t)(6 * a + r) * n6 + 6 * b + c] += v;
+            dst[(size_t)(6 * b + c) * n6 + 6 * a + r] += v;
+        }
+    }
+    return VISFS_BA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// ba_device.hpp — HBM layout of one resident window and the device-side LM state.
+//
+// Layout rules:
+//   * observations are LANDMARK-MAJOR (sorted by point, then pose) — the reference's edge
+//     insertion order (Optimizer.cpp:156-221) — so a landmark's tiles are contiguous;
+//   * a second POSE-MAJOR permutation (pose_obs) cut into chunks of <= LIN_CHUNK
+//     observations feeds the Hpp/b_p reduction without atomics;
+//   * per S block (i<=j) a list of (obs_a, obs_b) pairs sharing a landmark — g2o's
+//     buildStructure analogue — feeds the Schur complement as a gather, no atomics;
+//   * every accumulation is a fixed-order tree or serial sum: results are bitwise
+//     reproducible run to run.
+#pragma once
+
+#include <stdint.h>
+
+namespace visfs_ba {
+
+constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
+constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
+constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
+constexpr int MAX_STAGED_POSES = 640; // 12 doubles each in LDS (60 KiB)
+
+// LM / phase state machine, resident in HBM; every kernel of a "unit" reads its gate from here.
+struct LmState {
+    double lambda, ni, current_chi, temp_chi, rho, scale, max_diag;
+    double pcg_dn, pcg_d0, pcg_residual;
+    double chi2_initial, chi2_phase1, chi2_final;
+    double trace_lambda[MAX_TRACE], trace_chi2[MAX_TRACE];
+    int32_t sel;            // index of the committed estimate buffer (0/1)
+    int32_t phase;          // 0 / 1
+    int32_t max_iter;       // outer iterations allowed in this phase
+    int32_t phase_iter;     // outer iterations completed in this phase
+    int32_t trial_q;        // damped solves tried in the current outer iteration
+    int32_t need_lin;       // next LIN slot must linearise
+    int32_t done;           // phase finished (max_iter reached or Terminate)
+    int32_t solve_state;    // 0: no solve in flight, 1: PCG running, 2: solution ready, 3: solver failed
+    int32_t pcg_iter;       // iterations done in the current solve
+    int32_t pcg_total;      // over all solves
+    int32_t gauss_newton;   // trust_region == 1
+    int32_t status;         // VISFS_BA_* (abort reasons)
+    int32_t n_outliers;
+    int32_t n_trace;
+    int32_t iterations_run[2], trials_run[2];
+    int32_t pcg_max;        // most PCG iterations any solve of this call needed (sizes the next enqueue)
+    int32_t pad_;
+};
+
+// PCG control word, double-buffered on the launch parity (see k_pcg_iter).
+struct PcgCtl { int32_t go, has_q, iter, pad; double dn; };
+
+struct DeviceGraph {
+    int32_t Np, Nl, No, Ne, Npf;
+    int32_t n_chunks;       // pose-major chunks
+    int32_t n_blk;          // stored S blocks (i <= j)
+    int32_t n_lin_a;        // workgroups of the landmark-major role
+    int32_t group;          // lanes per landmark (4/8/16/32/64)
+    double fx, fy, cx, cy, bf;
+    double inv_pixel_var, inv_odo_cov, huber_delta;
+
+    // ---- static graph ----
+    const double* pose0;        // [Np][8]  initial Tcw (tx ty tz qx qy qz qw pad)
+    const double* pt0;          // [Nl][3]
+    const int32_t* pose_free;   // [Np]  free index or -1
+    const int32_t* free_pose;   // [Npf] pose index
+    const uint8_t* pt_fixed;    // [Nl]
+    const int32_t* obs_pose;    // [No]
+    const int32_t* obs_pt;      // [No]
+    const double* obs_uvr;      // [No][3]
+    const uint8_t* obs_ok;      // [No] !(pose fixed && point fixed)
+    const int32_t* lm_ptr;      // [Nl+1]
+    const int32_t* chunk_pose;  // [n_chunks] free pose index
+    const int32_t* chunk_ptr;   // [n_chunks+1] into pose_obs
+    const int32_t* pose_obs;    // [sum] observation ids, pose-major (free poses only)
+    const int32_t* pose_chunk_ptr; // [Npf+1] chunks of each free pose
+    const int32_t* odo_i;       // [Ne] pose index of vertex 0
+    const int32_t* odo_j;       // [Ne]
+    const double* odo_tq;       // [Ne][7]
+    const int32_t* pose_odo_ptr;// [Npf+1]
+    const int32_t* pose_odo;    // [..] edge*2 + role (0: vertex 0 → Aii, 1: vertex 1 → Ajj)
+    const int32_t* blk_i;       // [n_blk] free pose index (row)
+    const int32_t* blk_j;       // [n_blk] (col), j >= i
+    const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
+    const int2* blk_pairs;      // (obs of pose i, obs of pose j) sharing a landmark
+    const int32_t* blk_odo_ptr; // [n_blk+1]
+    const int32_t* blk_odo;     // [..] edge*2 + transposed
+    const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)
+    const int32_t* row_col;     // [..] column block
+    const int32_t* row_blk;     // [..] stored block id * 2 + transposed
+
+    // ---- estimates ----
+    double* pose[2];            // [Np][8]
+    double* pt[2];              // [Nl][3]
+    uint8_t* obs_level;         // [No] 0 active, 1 outlier (level 1)
+    uint8_t* obs_outlier;       // [No] 1 iff moved to level 1 at Optimizer.cpp:285-286
+    double* obs_chi2_out;       // [No] e^T Omega e at Optimizer.cpp:270
+
+    // ---- linearisation products ----
+    double* obs_err;            // [No][3]   (written only when debug != 0)
+    double* obs_chi2;           // [No]
+    double* obs_w;              // [No]      rho' (0: inactive)
+    double* W;                  // [No][18]  Hpl tiles, 6x3 row-major
+    double* Hll;                // [Nl][6]
+    double* bl;                 // [Nl][3]
+    double* hpp_part;           // [n_chunks][27] 21 upper + 6 b
+    double* odo_blk;            // [Ne][120] Aii(36) Ajj(36) Aij(36) bi(6) bj(6)
+    double* Hpp;                // [Npf][36]
+    double* bp;                 // [Npf][6]
+    int32_t* pose_pin;          // [Npf] 1: pose has no active edge (outside g2o's active set)
+    double* lin_part;           // [n_lin_a + 1][2]  (robust chi2, max |Hll diag|) per workgroup; last = odometry
+
+    // ---- per trial ----
+    double* S;                  // [n_blk][36]
+    double* bs;                 // [Npf][6]
+    double* Minv;               // [Npf][36]
+    double* x;                  // [Npf][6]   pose increment
+    double* pcg_r[2];           // [Npf][6]
+    double* pcg_d[2];
+    double* pcg_q[2];           // [Npf][6]
+    PcgCtl* pcg_ctl;            // [2]
+    double* dxl;                // [Nl][3]    landmark increment
+    double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
+    double* dense;              // [6Npf][6Npf] scratch for the direct solver
+
+    LmState* st;
+    int32_t debug;
+};
+
+}  // namespace visfs_ba

@@ -1,0 +1,315 @@
+// ba_math.hpp — fp64 pose / edge arithmetic shared by the HIP kernels and the host packer.
+//
+// Every function restates VISFS's own vertex/edge arithmetic and cites the reference
+// (paths relative to the reference repo root).  Written for gfx950: scalar-per-lane fp64,
+// everything in registers, no local arrays indexed at run time.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define BA_HD __host__ __device__ __forceinline__
+
+namespace visfs_ba {
+
+struct Quat { double x, y, z, w; };
+struct Vec3 { double x, y, z; };
+struct Mat3 { double m00, m01, m02, m10, m11, m12, m20, m21, m22; };
+// Rigid transform kept as rotation matrix + translation (the form the edges consume).
+struct Rt { Mat3 R; Vec3 t; };
+
+// Eigen::Quaternion::toRotationMatrix() as used by CameraPose::map (OptimizeTypeDefine.h:45-47).
+BA_HD Mat3 quat_to_R(const Quat& q) {
+    const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    Mat3 R;
+    R.m00 = 1.0 - (tyy + tzz); R.m01 = txy - twz;         R.m02 = txz + twy;
+    R.m10 = txy + twz;         R.m11 = 1.0 - (txx + tzz); R.m12 = tyz - twx;
+    R.m20 = txz - twy;         R.m21 = tyz + twx;         R.m22 = 1.0 - (txx + tyy);
+    return R;
+}
+
+// Eigen::Quaterniond(Matrix3d) — the conversion behind CameraPose(R,t) (OptimizeTypeDefine.h:30-34).
+BA_HD Quat R_to_quat(const Mat3& m) {
+    Quat q;
+    double t = m.m00 + m.m11 + m.m22;
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m.m21 - m.m12) * t;
+        q.y = (m.m02 - m.m20) * t;
+        q.z = (m.m10 - m.m01) * t;
+    } else if (m.m00 >= m.m11 && m.m00 >= m.m22) {          // i = 0, j = 1, k = 2
+        t = sqrt(m.m00 - m.m11 - m.m22 + 1.0);
+        q.x = 0.5 * t; t = 0.5 / t;
+        q.w = (m.m21 - m.m12) * t; q.y = (m.m10 + m.m01) * t; q.z = (m.m20 + m.m02) * t;
+    } else if (m.m11 > m.m00 && m.m11 >= m.m22) {           // i = 1, j = 2, k = 0
+        t = sqrt(m.m11 - m.m22 - m.m00 + 1.0);
+        q.y = 0.5 * t; t = 0.5 / t;
+        q.w = (m.m02 - m.m20) * t; q.z = (m.m21 + m.m12) * t; q.x = (m.m01 + m.m10) * t;
+    } else {                                                 // i = 2, j = 0, k = 1
+        t = sqrt(m.m22 - m.m00 - m.m11 + 1.0);
+        q.z = 0.5 * t; t = 0.5 / t;
+        q.w = (m.m10 - m.m01) * t; q.x = (m.m02 + m.m20) * t; q.y = (m.m12 + m.m21) * t;
+    }
+    return q;
+}
+
+BA_HD Quat quat_mul(const Quat& a, const Quat& b) {
+    Quat o;
+    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    o.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    o.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return o;
+}
+
+BA_HD Quat quat_normalized(const Quat& q) {
+    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return Quat{ q.x / n, q.y / n, q.z / n, q.w / n };
+}
+
+// CameraPose::normalizeRotation (OptimizeTypeDefine.h:36-41) == QuaternionPositify (Math.h:308-317).
+BA_HD Quat quat_positify(Quat q) {
+    if (q.w < 0.0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    return quat_normalized(q);
+}
+
+// Eigen::Quaternion::inverse(): conjugate / squaredNorm.
+BA_HD Quat quat_inv(const Quat& q) {
+    const double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    return Quat{ -q.x / n2, -q.y / n2, -q.z / n2, q.w / n2 };
+}
+
+// Eigen::Quaternion * Vector3 (_transformVector).
+BA_HD Vec3 quat_rot(const Quat& q, const Vec3& v) {
+    double ux = q.y * v.z - q.z * v.y, uy = q.z * v.x - q.x * v.z, uz = q.x * v.y - q.y * v.x;
+    ux += ux; uy += uy; uz += uz;
+    return Vec3{ v.x + q.w * ux + (q.y * uz - q.z * uy),
+                 v.y + q.w * uy + (q.z * ux - q.x * uz),
+                 v.z + q.w * uz + (q.x * uy - q.y * ux) };
+}
+
+BA_HD Vec3 mat_vec(const Mat3& A, const Vec3& v) {
+    return Vec3{ A.m00 * v.x + A.m01 * v.y + A.m02 * v.z,
+                 A.m10 * v.x + A.m11 * v.y + A.m12 * v.z,
+                 A.m20 * v.x + A.m21 * v.y + A.m22 * v.z };
+}
+
+BA_HD Mat3 mat_mul(const Mat3& A, const Mat3& B) {
+    Mat3 C;
+    C.m00 = A.m00 * B.m00 + A.m01 * B.m10 + A.m02 * B.m20;
+    C.m01 = A.m00 * B.m01 + A.m01 * B.m11 + A.m02 * B.m21;
+    C.m02 = A.m00 * B.m02 + A.m01 * B.m12 + A.m02 * B.m22;
+    C.m10 = A.m10 * B.m00 + A.m11 * B.m10 + A.m12 * B.m20;
+    C.m11 = A.m10 * B.m01 + A.m11 * B.m11 + A.m12 * B.m21;
+    C.m12 = A.m10 * B.m02 + A.m11 * B.m12 + A.m12 * B.m22;
+    C.m20 = A.m20 * B.m00 + A.m21 * B.m10 + A.m22 * B.m20;
+    C.m21 = A.m20 * B.m01 + A.m21 * B.m11 + A.m22 * B.m21;
+    C.m22 = A.m20 * B.m02 + A.m21 * B.m12 + A.m22 * B.m22;
+    return C;
+}
+
+BA_HD Mat3 mat_T(const Mat3& A) {
+    return Mat3{ A.m00, A.m10, A.m20, A.m01, A.m11, A.m21, A.m02, A.m12, A.m22 };
+}
+
+// skewSymmetric (Math.h:294-301)
+BA_HD Mat3 skew(const Vec3& v) {
+    return Mat3{ 0.0, -v.z, v.y, v.z, 0.0, -v.x, -v.y, v.x, 0.0 };
+}
+
+// ---- pose state: [tx ty tz qx qy qz qw] (CameraPose::toVector, OptimizeTypeDefine.h:57-67) ----
+BA_HD Rt pose_to_Rt(const double* tq) {
+    Rt p;
+    p.R = quat_to_R(Quat{ tq[3], tq[4], tq[5], tq[6] });
+    p.t = Vec3{ tq[0], tq[1], tq[2] };
+    return p;
+}
+
+// CameraPose::update (OptimizeTypeDefine.cpp:7-14) with deltaQ (Math.h:277-287):
+// t += dt; q = normalize((1, dtheta/2) * q) — first order, left-multiplied, not re-positified.
+BA_HD void pose_oplus(const double* tq, const double* d, double* out) {
+    out[0] = tq[0] + d[0]; out[1] = tq[1] + d[1]; out[2] = tq[2] + d[2];
+    const Quat dq{ d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0 };
+    const Quat q = quat_normalized(quat_mul(dq, Quat{ tq[3], tq[4], tq[5], tq[6] }));
+    out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+
+struct Intrinsics { double fx, fy, cx, cy, bf; };
+
+// EdgeStereo::computeError (OptimizeTypeDefine.h:121-126) + project (:180-187).
+// Returns Pc = R Pw + t through pc (needed by the Jacobians).
+BA_HD Vec3 stereo_error(const Rt& T, const Vec3& pw, double u, double v, double ur, const Intrinsics& K, Vec3& pc) {
+    pc = mat_vec(T.R, pw);
+    pc.x += T.t.x; pc.y += T.t.y; pc.z += T.t.z;
+    const double invZ = 1.0 / pc.z;
+    const double r0 = pc.x * invZ * K.fx + K.cx;
+    const double r1 = pc.y * invZ * K.fy + K.cy;
+    const double r2 = r0 - K.bf * invZ;
+    return Vec3{ u - r0, v - r1, ur - r2 };
+}
+
+// EdgeStereo::linearizeOplus (OptimizeTypeDefine.h:134-178).
+// Jp: d e / d point, 3x3 row-major (":145-155").  Jx: d e / d pose (dt | dtheta), 3x6 row-major (":157-176"),
+// including the reference's SE(3)-style -[Pc]x rotation block (SURVEY §8a a6 quirk — reproduced as written).
+BA_HD void stereo_jacobians(const Rt& T, const Vec3& pc, const Intrinsics& K, double Jp[9], double Jx[18]) {
+    const double x = pc.x, y = pc.y, z = pc.z, z_2 = z * z;
+    const Mat3& R = T.R;
+    Jp[0] = -K.fx * R.m00 / z + K.fx * x * R.m20 / z_2;
+    Jp[1] = -K.fx * R.m01 / z + K.fx * x * R.m21 / z_2;
+    Jp[2] = -K.fx * R.m02 / z + K.fx * x * R.m22 / z_2;
+    Jp[3] = -K.fy * R.m10 / z + K.fy * y * R.m20 / z_2;
+    Jp[4] = -K.fy * R.m11 / z + K.fy * y * R.m21 / z_2;
+    Jp[5] = -K.fy * R.m12 / z + K.fy * y * R.m22 / z_2;
+    Jp[6] = Jp[0] - K.bf * R.m20 / z_2;
+    Jp[7] = Jp[1] - K.bf * R.m21 / z_2;
+    Jp[8] = Jp[2] - K.bf * R.m22 / z_2;
+    Jx[0] = -1. / z * K.fx;
+    Jx[1] = 0.;
+    Jx[2] = x / z_2 * K.fx;
+    Jx[3] = x * y / z_2 * K.fx;
+    Jx[4] = -(1. + (x * x / z_2)) * K.fx;
+    Jx[5] = y / z * K.fx;
+    Jx[6] = 0.;
+    Jx[7] = -1. / z * K.fy;
+    Jx[8] = y / z_2 * K.fy;
+    Jx[9] = (1. + y * y / z_2) * K.fy;
+    Jx[10] = -x * y / z_2 * K.fy;
+    Jx[11] = -x / z * K.fy;
+    Jx[12] = Jx[0];
+    Jx[13] = 0.;
+    Jx[14] = Jx[2] - K.bf / z_2;
+    Jx[15] = Jx[3] - K.bf * y / z_2;
+    Jx[16] = Jx[4] + K.bf * x / z_2;
+    Jx[17] = Jx[5];
+}
+
+// Only the pose Jacobian (pose-major pass).
+BA_HD void stereo_jacobian_pose(const Vec3& pc, const Intrinsics& K, double Jx[18]) {
+    const double x = pc.x, y = pc.y, z = pc.z, z_2 = z * z;
+    Jx[0] = -1. / z * K.fx;
+    Jx[1] = 0.;
+    Jx[2] = x / z_2 * K.fx;
+    Jx[3] = x * y / z_2 * K.fx;
+    Jx[4] = -(1. + (x * x / z_2)) * K.fx;
+    Jx[5] = y / z * K.fx;
+    Jx[6] = 0.;
+    Jx[7] = -1. / z * K.fy;
+    Jx[8] = y / z_2 * K.fy;
+    Jx[9] = (1. + y * y / z_2) * K.fy;
+    Jx[10] = -x * y / z_2 * K.fy;
+    Jx[11] = -x / z * K.fy;
+    Jx[12] = Jx[0];
+    Jx[13] = 0.;
+    Jx[14] = Jx[2] - K.bf / z_2;
+    Jx[15] = Jx[3] - K.bf * y / z_2;
+    Jx[16] = Jx[4] + K.bf * x / z_2;
+    Jx[17] = Jx[5];
+}
+
+// [g2o-upstream] RobustKernelHuber::robustify on chi2 = e^T Omega e (delta compared SQUARED).
+BA_HD void huber(double e2, double delta, double& rho0, double& rho1) {
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
+    else { const double s = sqrt(e2); rho0 = 2.0 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+// Inverse of a symmetric 3x3 given as (xx xy xz yy yz zz), cofactor form (Eigen's fixed-size 3x3 inverse).
+BA_HD void sym3_inverse(const double h[6], double o[6]) {
+    const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double id = 1.0 / (a * c00 + b * c01 + c * c02);
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
+}
+
+// ---- wheel-odometry edge: EdgePoseConstraint (OptimizeTypeDefine.cpp:35-88) ----
+// Bottom-right 3x3 of QuaternionLeft(a) * QuaternionRight(b) (Math.h:324-345; both positify their argument).
+BA_HD Mat3 quat_LR_br(const Quat& a_in, const Quat& b_in) {
+    const Quat a = quat_positify(a_in), b = quat_positify(b_in);
+    // L = [aw, -av^T; av, aw I + [av]x], R = [bw, -bv^T; bv, bw I - [bv]x]
+    // (L R)[1:,1:] = av (-bv^T) + (aw I + [av]x)(bw I - [bv]x)
+    const Mat3 A{ a.w, -a.z, a.y, a.z, a.w, -a.x, -a.y, a.x, a.w };
+    const Mat3 B{ b.w, b.z, -b.y, -b.z, b.w, b.x, b.y, -b.x, b.w };
+    Mat3 M = mat_mul(A, B);
+    M.m00 -= a.x * b.x; M.m01 -= a.x * b.y; M.m02 -= a.x * b.z;
+    M.m10 -= a.y * b.x; M.m11 -= a.y * b.y; M.m12 -= a.y * b.z;
+    M.m20 -= a.z * b.x; M.m21 -= a.z * b.y; M.m22 -= a.z * b.z;
+    return M;
+}
+
+// Bottom-right 3x3 of QuaternionLeft(a): aw I + [av]x on the positified a.
+BA_HD Mat3 quat_L_br(const Quat& a_in) {
+    const Quat a = quat_positify(a_in);
+    return Mat3{ a.w, -a.z, a.y, a.z, a.w, -a.x, -a.y, a.x, a.w };
+}
+
+// e (6) only.
+BA_HD void odo_error(const double* tq1, const double* tq2, const double* m, double e[6]) {
+    const Quat Q1{ tq1[3], tq1[4], tq1[5], tq1[6] }, Q2{ tq2[3], tq2[4], tq2[5], tq2[6] }, mQ{ m[3], m[4], m[5], m[6] };
+    const Quat Q2i = quat_inv(Q2);
+    const Quat Q12 = quat_mul(Q1, Q2i);
+    const Vec3 r = quat_rot(Q12, Vec3{ -tq2[0], -tq2[1], -tq2[2] });
+    e[0] = r.x + tq1[0] - m[0]; e[1] = r.y + tq1[1] - m[1]; e[2] = r.z + tq1[2] - m[2];
+    const Quat t2 = quat_mul(quat_mul(quat_inv(mQ), Q1), Q2i);
+    e[3] = 2 * t2.x; e[4] = 2 * t2.y; e[5] = 2 * t2.z;
+}
+
+// e plus the "Left update" Jacobians (OptimizeTypeDefine.cpp:64-73); Ji, Jj 6x6 row-major.
+BA_HD void odo_linearize(const double* tq1, const double* tq2, const double* m, double e[6], double Ji[36], double Jj[36]) {
+    const Quat Q1{ tq1[3], tq1[4], tq1[5], tq1[6] }, Q2{ tq2[3], tq2[4], tq2[5], tq2[6] }, mQ{ m[3], m[4], m[5], m[6] };
+    const Vec3 nP2{ -tq2[0], -tq2[1], -tq2[2] };
+    const Quat Q2i = quat_inv(Q2);
+    const Quat Q12 = quat_mul(Q1, Q2i);
+    const Vec3 r = quat_rot(Q12, nP2);
+    e[0] = r.x + tq1[0] - m[0]; e[1] = r.y + tq1[1] - m[1]; e[2] = r.z + tq1[2] - m[2];
+    const Quat t2 = quat_mul(quat_mul(quat_inv(mQ), Q1), Q2i);
+    e[3] = 2 * t2.x; e[4] = 2 * t2.y; e[5] = 2 * t2.z;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { Ji[i] = 0.0; Jj[i] = 0.0; }
+    Ji[0] = Ji[7] = Ji[14] = 1.0;
+    const Vec3 b = quat_rot(Q1, quat_rot(Q2i, nP2));
+    const Mat3 S = skew(b);
+    Ji[3] = -S.m00; Ji[4] = -S.m01; Ji[5] = -S.m02;
+    Ji[9] = -S.m10; Ji[10] = -S.m11; Ji[11] = -S.m12;
+    Ji[15] = -S.m20; Ji[16] = -S.m21; Ji[17] = -S.m22;
+    const Mat3 LR = quat_LR_br(quat_mul(Q2, quat_inv(Q1)), mQ);
+    Ji[21] = LR.m00; Ji[22] = LR.m01; Ji[23] = LR.m02;
+    Ji[27] = LR.m10; Ji[28] = LR.m11; Ji[29] = LR.m12;
+    Ji[33] = LR.m20; Ji[34] = LR.m21; Ji[35] = LR.m22;
+    const Mat3 R12 = quat_to_R(Q12);
+    Jj[0] = -R12.m00; Jj[1] = -R12.m01; Jj[2] = -R12.m02;
+    Jj[6] = -R12.m10; Jj[7] = -R12.m11; Jj[8] = -R12.m12;
+    Jj[12] = -R12.m20; Jj[13] = -R12.m21; Jj[14] = -R12.m22;
+    const Mat3 U = mat_mul(mat_mul(quat_to_R(Q1), quat_to_R(Q2i)), skew(nP2));
+    Jj[3] = U.m00; Jj[4] = U.m01; Jj[5] = U.m02;
+    Jj[9] = U.m10; Jj[10] = U.m11; Jj[11] = U.m12;
+    Jj[15] = U.m20; Jj[16] = U.m21; Jj[17] = U.m22;
+    const Mat3 L = quat_L_br(t2);
+    Jj[21] = -L.m00; Jj[22] = -L.m01; Jj[23] = -L.m02;
+    Jj[27] = -L.m10; Jj[28] = -L.m11; Jj[29] = -L.m12;
+    Jj[33] = -L.m20; Jj[34] = -L.m21; Jj[35] = -L.m22;
+}
+
+// ---- 3x4 row-major isometries (host packer: Optimizer.cpp:104-109, 131-140, 324-329) ----
+BA_HD void iso_mul(const double* A, const double* B, double* C) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) C[r * 4 + c] = A[r * 4] * B[c] + A[r * 4 + 1] * B[4 + c] + A[r * 4 + 2] * B[8 + c];
+        C[r * 4 + 3] = A[r * 4] * B[3] + A[r * 4 + 1] * B[7] + A[r * 4 + 2] * B[11] + A[r * 4 + 3];
+    }
+}
+BA_HD void iso_inv(const double* A, double* C) {   // Eigen Transform::inverse(Isometry): R^T, -R^T t
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C[r * 4 + c] = A[c * 4 + r];
+    for (int r = 0; r < 3; ++r) C[r * 4 + 3] = -(C[r * 4] * A[3] + C[r * 4 + 1] * A[7] + C[r * 4 + 2] * A[11]);
+}
+BA_HD void iso_to_tq(const double* T, double* tq) {   // CameraPose(R,t) / g2o::SE3Quat(R,t)
+    const Quat q = quat_positify(R_to_quat(Mat3{ T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] }));
+    tq[0] = T[3]; tq[1] = T[7]; tq[2] = T[11];
+    tq[3] = q.x; tq[4] = q.y; tq[5] = q.z; tq[6] = q.w;
+}
+
+}  // namespace visfs_ba
