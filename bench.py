@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — BA iterations/sec of the MI355X sliding-window bundle-adjustment backend.
+
+Contract (one JSON line on rank 0):
+  metric  = BASELINE.json's "BA iterations/sec (50 KF, 5k pts, 50k obs) @1 GPU"
+  step    = one full two-phase optimise (Optimizer.cpp:261-318) of every window resident on this rank,
+            graph already in HBM when the timed region starts (reset of the estimates included);
+  value   = outer LM iterations executed by ALL ranks / max-over-ranks wall time  (weak scaling: each
+            rank owns `--windows-per-gpu` independent windows, no data-path collective).
+Also reported: `roofline` of the dominant kernel (HIP-event durations measured in the timed region on
+the library's own stream) and `cpu_baseline` = the CPU oracle timed on this box (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def algorithmic_bytes(kernel, d):
+    """SURVEY.md §8(d) per-unit bytes x units of one launch."""
+    No, Nl, Np, npairs, nblk = d["n_obs"], d["n_points"], d["n_poses"], d["n_pairs"], d["n_blk"]
+    if kernel == "k_linearize":      # stage A of §8d: 256 B/obs + 96 B/landmark + 336 B/pose
+        return 256 * No + 96 * Nl + 336 * Np
+    if kernel == "k_schur":          # stage B: 144 B/obs (Hpl) + 96 B/landmark + 288 B/stored block + 48 B/pose
+        return 144 * No + 96 * Nl + 288 * nblk + 48 * Np
+    if kernel == "k_backsub":        # stages D+E: 144 + 112 + 8 B/obs, (72+24+24)+48 B/landmark, 112 B/pose
+        return 264 * No + 168 * Nl + 112 * Np
+    if kernel == "k_pcg_iter":       # stage C, one iteration: 288 B/block + 4*48 B/pose
+        return 288 * nblk + 192 * Np
+    raise KeyError(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2", help="C1..C5 / PROD (BASELINE.json configs); C2 is the headline")
+    ap.add_argument("--windows-per-gpu", type=int, default=1)
+    ap.add_argument("--solver", type=int, default=2, help="Optimizer/Solver: 2 = PCG (headline), 0 = direct Cholesky")
+    ap.add_argument("--iterations", type=int, default=20, help="Optimizer/Iterations (10+10, as the shipped launch files)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from visfs_amd import abi, synth, backend, dist as vdist
+    import torch
+
+    rank, local_rank, world = vdist.env_rank()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    if world > 1:
+        vdist.init_process_group("nccl", rank, world)
+
+    prm = abi.default_params(iterations=args.iterations, solver=args.solver)
+    lib = backend.load_library()
+    B = args.windows_per_gpu
+    solvers, descs = [], []
+    for b in range(B):
+        w = synth.make_window(args.config, window_index=rank * B + b)
+        wb = abi.WindowBuffers(w)
+        gb, used, oref, mono = abi.pack_window_with(lib.visfs_ba_pack_window, prm, wb)    # host graph build (product code)
+        s = backend.Solver(prm, device=dev)
+        s.upload(gb)                                                                      # inputs resident in HBM
+        solvers.append(s)
+        descs.append(s.describe())
+
+    def step():
+        its = 0
+        if B == 1:
+            solvers[0].reset()
+            rc, st = solvers[0].optimize()
+            assert rc == abi.OK, rc
+            return st.iterations_run[0] + st.iterations_run[1], st
+        st = None
+        for s in solvers:
+            s.reset()
+        for s in solvers:          # windows are independent: each has its own stream
+            rc, st = s.optimize()
+            assert rc == abi.OK, rc
+            its += st.iterations_run[0] + st.iterations_run[1]
+        return its, st
+
+    for _ in range(args.warmup):
+        step()
+    # untimed calibration pass: HIP-event pairs around every kernel class → per-kernel breakdown + the dominant kernel
+    data_kernels = ("k_linearize", "k_schur", "k_backsub", "k_pcg_iter")
+    solvers[0].profile_enable(True)
+    for _ in range(3):
+        step()
+    calib = solvers[0].profile_read()
+    cand = [k for k in data_kernels if calib.get(k, {}).get("active_launches", 0) > 0]
+    dom = max(cand, key=lambda k: calib[k]["active_ms"]) if cand else None
+    # timed region: events only around the dominant kernel's launches (on the library's own stream)
+    solvers[0].profile_enable([dom] if dom else False)
+    vdist.barrier(world, dev if world > 1 else None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 0
+    last = None
+    for _ in range(args.steps):
+        n, last = step()
+        iters += n
+    torch.cuda.synchronize()
+    vdist.barrier(world, dev if world > 1 else None)
+    t1 = time.perf_counter()
+    elapsed = vdist.reduce_max(t1 - t0, world, f"cuda:{dev}" if world > 1 else "cpu")
+    total_iters = vdist.reduce_sum(iters, world, f"cuda:{dev}" if world > 1 else "cpu")
+
+    if rank != 0:
+        return
+    prof = solvers[0].profile_read()
+    d = descs[0]
+    roofline = None
+    if dom and dom in prof:
+        p = prof[dom]
+        avg_s = p["active_ms"] * 1e-3 / p["active_launches"]
+        byts = algorithmic_bytes(dom, d)
+        achieved = byts / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "bytes_per_launch": byts, "avg_launch_us": round(avg_s * 1e6, 3), "launches": p["active_launches"]}
+    out = {
+        "metric": "BA iterations/sec (50 KF, 5k pts, 50k obs) @1 GPU; max-pose-err vs g2o",
+        "value": round(total_iters / elapsed, 2), "unit": "BA iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {d['n_poses']} KF / {d['n_points']} landmarks / {d['n_obs']} stereo observations"
+                               f" / {d['n_odo']} odometry edges, Schur + {'PCG' if args.solver == 2 else 'direct Cholesky'}, "
+                               f"Iterations={args.iterations} ({args.iterations // 2}+{args.iterations // 2}), {B} window(s) per GPU",
+                   "windows_per_gpu": B, "solver": args.solver, "iterations_per_solve": int(total_iters / (args.steps * world * B)),
+                   "pcg_iterations_per_solve": int(last.pcg_iterations) if last is not None else 0,
+                   "parallelism": f"{world} rank(s) x {B} independent window(s), no data-path collective"},
+        "roofline": roofline,
+        "kernel_us_per_step_calibration": {k: round(1e3 * v["total_ms"] / 3, 2) for k, v in calib.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, prm)
+        # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
+        out["max_pose_err_vs_oracle"] = parity_vs_oracle(args, prm, solvers[0])
+    print(json.dumps(out))
+
+
+def cpu_baseline(args, prm):
+    """The CPU oracle ('port' of the g2o algorithm) timed on this box's host cores: bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from visfs_amd import abi, synth
+    import oracle_lib
+    olib = oracle_lib.load()
+    w = synth.make_window(args.config, window_index=0)
+    wb = abi.WindowBuffers(w)
+    gb, *_ = abi.pack_window_with(olib.oracle_pack_window, prm, wb)
+    s = oracle_lib.OracleSystem(olib, prm, gb, 1)
+    secs, its = [], 0
+    t_budget = time.perf_counter() + 15.0
+    runs = 0
+    while runs < 3 or (time.perf_counter() < t_budget and runs < 25):
+        s.reset()
+        rc, st, sec = s.optimize()
+        secs.append(sec); its = st.iterations_run[0] + st.iterations_run[1]; runs += 1
+    s.close()
+    med = float(np.median(secs))
+    return {"value": round(its / med, 2), "unit": "BA iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{runs} full solves of the same {args.config} window ({its} outer iterations each), median; "
+                      f"g2o-algorithm restatement in C (oracle/), single thread, gcc -O3 x86-64-v3"}
+
+
+def parity_vs_oracle(args, prm, solver):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from visfs_amd import abi, synth
+    import oracle_lib
+    from helpers import twr_of
+    olib = oracle_lib.load()
+    w = synth.make_window(args.config, window_index=0)
+    gb, *_ = abi.pack_window_with(olib.oracle_pack_window, prm, abi.WindowBuffers(w))
+    o = oracle_lib.OracleSystem(olib, prm, gb, 1)
+    o.optimize()
+    po, pto, outo, _ = o.download(); o.close()
+    solver.reset(); solver.optimize()
+    pg, ptg, outg, _ = solver.download()
+    et, er = synth.pose_errors(twr_of(olib.oracle_unpack_pose, pg, w["Trc"]), twr_of(olib.oracle_unpack_pose, po, w["Trc"]))
+    return {"translation_rel": et, "rotation_rad": er, "landmark_abs_max": float(np.abs(ptg - pto).max()),
+            "outlier_set_equal": bool(np.array_equal(outo, outg))}
+
+
+if __name__ == "__main__":
+    main()

@@ -224,6 +224,34 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
 /* Copies a stage buffer to host memory as fp64 in the layout documented above. */
 int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles);
 
+/* ---- measurement hooks (bench.py) ------------------------------------------ */
+/* Sizes of the resident graph and of the index structures built at upload. */
+typedef struct visfs_ba_graph_info {
+    int32_t n_poses, n_free_poses, n_points, n_obs, n_odo;
+    int32_t n_blk;                /* stored 6x6 blocks of the reduced camera matrix (upper triangle incl. diagonal) */
+    int64_t n_pairs;              /* co-observation pairs feeding the Schur gather */
+    int32_t lanes_per_landmark;   /* wavefront sub-group size of the landmark-major kernels */
+    int32_t pcg_slots;            /* k_pcg_iter launches enqueued per damped solve */
+    int64_t device_bytes;         /* HBM footprint of the window */
+} visfs_ba_graph_info;
+int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out);
+
+enum {
+    VISFS_BA_K_LINEARIZE = 0, VISFS_BA_K_LIN_FINALIZE = 1, VISFS_BA_K_SCHUR = 2, VISFS_BA_K_PCG_INIT = 3,
+    VISFS_BA_K_PCG_ITER = 4, VISFS_BA_K_DIRECT = 5, VISFS_BA_K_BACKSUB = 6, VISFS_BA_K_DECIDE = 7,
+    VISFS_BA_K_PHASE_END = 8, VISFS_BA_K_RESET = 9, VISFS_BA_K_COUNT = 10
+};
+typedef struct visfs_ba_profile {
+    double  total_ms[VISFS_BA_K_COUNT];        /* sum of hipEventElapsedTime over all launches of the class */
+    int64_t launches[VISFS_BA_K_COUNT];
+    double  active_ms[VISFS_BA_K_COUNT];       /* the `active_launches` longest launches (gated-off launches return at once) */
+    int64_t active_launches[VISFS_BA_K_COUNT]; /* launches that did work, counted on the device */
+} visfs_ba_profile;
+/* mask: bit k enables hipEvent pairs around every launch of kernel class k on the handle's own stream. */
+int visfs_ba_profile_enable(visfs_ba_handle* h, uint32_t mask);
+/* Returns and clears the accumulated profile. */
+int visfs_ba_profile_read(visfs_ba_handle* h, visfs_ba_profile* out);
+
 #ifdef __cplusplus
 }
 #endif

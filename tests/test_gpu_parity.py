@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (fp64 everywhere): the device sums in a different (fixed) order than the oracle and the
+compiler contracts multiply-adds into FMAs, so stage outputs agree to ~1e-13 relative; bounds are
+set to 1e-9 for linearisation products, 1e-7 for solved increments (conditioning of S) and 1e-6
+relative on final poses (north_star demands 1e-4).  Outlier sets (a discrete output) must be identical.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from helpers import drop_refs, graph_of, hard_window, ragged_window, rel_err, twr_of
+from visfs_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+LIN_BUFS = [("err", abi.BUF_OBS_ERR), ("chi2", abi.BUF_OBS_CHI2), ("weight", abi.BUF_OBS_WEIGHT), ("Hpl", abi.BUF_HPL),
+            ("Hll", abi.BUF_HLL), ("bl", abi.BUF_BL), ("Hpp", abi.BUF_HPP), ("bp", abi.BUF_BP)]
+TRIAL_BUFS = [("S", abi.BUF_S, 1e-9), ("bs", abi.BUF_BS, 1e-9), ("dx_pose", abi.BUF_DX_POSE, 1e-7), ("dx_point", abi.BUF_DX_POINT, 1e-7),
+              ("pose_trial", abi.BUF_POSE_TRIAL, 1e-10), ("point_trial", abi.BUF_POINT_TRIAL, 1e-10)]
+
+
+def make_pair(olib, w, **prm_kw):
+    from visfs_amd import backend
+    prm = abi.default_params(**prm_kw)
+    wb, gb, used, oref, mono = graph_of(olib.oracle_pack_window, prm, w)
+    o = oracle_lib.OracleSystem(olib, prm, gb)
+    s = backend.Solver(prm)
+    s.upload(gb)
+    return o, s, gb
+
+
+def check_stages(o, s, lambdas=(None, 1.0)):
+    oc, omd = o.linearize(); gc, gmd = s.linearize()
+    assert abs(oc - gc) <= 1e-10 * abs(oc) and abs(omd - gmd) <= 1e-10 * abs(omd)
+    for name, b in LIN_BUFS:
+        assert rel_err(s.fetch(b), o.fetch(b)) < 1e-9, name
+    for lam in lambdas:
+        lam = 1e-5 * omd if lam is None else lam * omd
+        ot, gt = o.trial(lam), s.trial(lam)
+        assert ot[3] == gt[3] == 1
+        assert ot[2] == gt[2], "PCG iteration counts differ"
+        assert abs(ot[0] - gt[0]) <= 1e-8 * abs(ot[0]) and abs(ot[1] - gt[1]) <= 1e-7 * abs(ot[1])
+        for name, b, tol in TRIAL_BUFS:
+            assert rel_err(s.fetch(b), o.fetch(b)) < tol, (name, lam)
+
+
+def check_optimize(o, s, pose_tol=1e-6):
+    o.reset(); s.reset()
+    rc_o, st_o, _ = o.optimize()
+    rc_g, st_g = s.optimize()
+    assert rc_o == rc_g
+    assert list(st_o.iterations_run) == list(st_g.iterations_run) and list(st_o.trials_run) == list(st_g.trials_run)
+    assert st_o.n_outliers == st_g.n_outliers and st_o.n_trace == st_g.n_trace
+    for a, b in ((st_o.chi2_initial, st_g.chi2_initial), (st_o.chi2_phase1, st_g.chi2_phase1), (st_o.chi2_final, st_g.chi2_final)):
+        assert abs(a - b) <= 1e-7 * max(abs(a), 1e-12)
+    lam_o = np.array([st_o.trace_lambda[i] for i in range(st_o.n_trace)]); lam_g = np.array([st_g.trace_lambda[i] for i in range(st_g.n_trace)])
+    assert rel_err(lam_g, lam_o) < 1e-6                         # identical LM trajectory
+    po, pto, outo, chio = o.download(); pg, ptg, outg, chig = s.download()
+    assert np.array_equal(outo, outg), "outlier sets differ"
+    assert rel_err(pg, po) < pose_tol and rel_err(ptg, pto) < pose_tol
+    assert rel_err(chig, chio) < 1e-6
+    return st_g
+
+
+# ---------------------------------------------------------------- stage parity
+@pytest.mark.parametrize("solver", [2, 0])
+def test_stage_parity_c1(olib, solver):
+    o, s, gb = make_pair(olib, synth.make_window("C1"), iterations=20, solver=solver)
+    check_stages(o, s)
+    s.close(); o.close()
+
+
+def test_stage_parity_ragged_with_odometry(olib):
+    """Ragged tracks (0, 1, many observations per landmark), wheel-odometry edges, 12 poses."""
+    o, s, gb = make_pair(olib, ragged_window(seed=7), iterations=20, solver=2)
+    assert gb.struct.n_odo == 11
+    check_stages(o, s, lambdas=(None, 1e-2, 10.0))
+    s.close(); o.close()
+
+
+def test_stage_parity_long_tracks_exceed_group(olib):
+    """Track length 40 > lanes per landmark: the landmark-major kernels loop over their tiles."""
+    w = synth.make_window("custom", n_kf=40, n_lm=60, n_obs=2400, seed=3)
+    keep = np.ones(2400, bool); keep[::7] = False            # mean track ≈ 34 → group 64; make it ragged too
+    o, s, gb = make_pair(olib, drop_refs(w, keep), iterations=10, solver=2)
+    check_stages(o, s)
+    s.close(); o.close()
+
+
+def test_stage_parity_production_window(olib):
+    """6 poses x 300 features, the production shape (Parameters.h:161,148), short tracks → 4/8 lanes per landmark."""
+    o, s, gb = make_pair(olib, synth.make_window("PROD"), iterations=10, solver=2)
+    check_stages(o, s)
+    s.close(); o.close()
+
+
+# ---------------------------------------------------------------- full optimise parity
+@pytest.mark.parametrize("cfg,solver", [("C1", 2), ("C1", 0), ("PROD", 2), ("C3", 2), ("C2", 2), ("C2", 0)])
+def test_optimize_parity(olib, cfg, solver):
+    o, s, gb = make_pair(olib, synth.make_window(cfg), iterations=20, solver=solver)
+    st = check_optimize(o, s)
+    assert st.chi2_final < 0.02 * st.chi2_initial
+    s.close(); o.close()
+
+
+def test_optimize_parity_default_iterations(olib):
+    """Reference defaults: Iterations=10 → 5+5 (Parameters.h:187)."""
+    o, s, gb = make_pair(olib, synth.make_window("C1"))
+    st = check_optimize(o, s)
+    assert list(st.iterations_run) == [5, 5]
+    s.close(); o.close()
+
+
+def test_optimize_parity_with_rejected_steps(olib):
+    """The lambda *= ni / pop path of the LM loop: trials > iterations, identical trajectory on both sides."""
+    o, s, gb = make_pair(olib, hard_window(), iterations=20, solver=2)
+    st = check_optimize(o, s, pose_tol=1e-5)
+    assert st.trials_run[0] > st.iterations_run[0]
+    s.close(); o.close()
+
+
+def test_optimize_parity_ragged_odometry_direct(olib):
+    o, s, gb = make_pair(olib, ragged_window(seed=21), iterations=20, solver=0)
+    check_optimize(o, s)
+    s.close(); o.close()
+
+
+def test_optimize_parity_gauss_newton(olib):
+    w = synth.make_window("C1", pose_noise_t=0.01, pose_noise_r=0.002, point_noise=0.01)
+    o, s, gb = make_pair(olib, w, iterations=10, trust_region=1, solver=2)
+    check_optimize(o, s)
+    s.close(); o.close()
+
+
+def test_optimize_parity_no_robust_kernel(olib):
+    """RobustKernelDelta <= 0: no Huber, no second phase (Optimizer.cpp:212,283)."""
+    o, s, gb = make_pair(olib, synth.make_window("C1", outlier_frac=0.0), iterations=10, robust_kernel_delta=0.0, solver=2)
+    st = check_optimize(o, s)
+    assert list(st.iterations_run) == [5, 0] and st.n_outliers == 0
+    s.close(); o.close()
+
+
+def test_no_fixed_pose_and_all_landmarks_fixed(olib):
+    """rootId outside the window → no fixed pose; gauge held by LM damping and fixed landmarks."""
+    w = synth.make_window("C1")
+    w["root_id"] = 10 ** 6
+    o, s, gb = make_pair(olib, w, iterations=10, solver=2)
+    assert gb.pose_fixed.sum() == 0
+    check_stages(o, s)
+    check_optimize(o, s, pose_tol=1e-5)
+    s.close(); o.close()
+    w2 = synth.make_window("C1", fixed_frac=1.1)                 # every landmark STABLE → pose-only problem, empty Schur lists
+    o, s, gb = make_pair(olib, w2, iterations=10, solver=2)
+    assert gb.point_fixed.all()
+    check_stages(o, s)
+    check_optimize(o, s)
+    s.close(); o.close()
+
+
+def test_two_pose_window(olib):
+    w = synth.make_window("custom", n_kf=2, n_lm=40, n_obs=80, seed=4)
+    o, s, gb = make_pair(olib, w, iterations=10, solver=2)
+    check_stages(o, s)
+    check_optimize(o, s)
+    s.close(); o.close()
+
+
+def test_zero_noise_fixed_point_at_c2(olib):
+    """Full-size property test: at the true state chi2 ~ 0, no outliers, nothing moves."""
+    from visfs_amd import backend
+    w = synth.make_window("C2", noise_px=0.0, outlier_frac=0.0, pose_noise_t=0.0, pose_noise_r=0.0, point_noise=0.0)
+    prm = abi.default_params(iterations=10, solver=2)
+    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+    s = backend.Solver(prm); s.upload(gb)
+    rc, st = s.optimize()
+    pose, pt, out, chi = s.download()
+    assert rc == abi.OK and st.n_outliers == 0 and st.chi2_initial < 0.05 and st.chi2_final <= st.chi2_initial
+    assert np.abs(pose - gb.pose_tq).max() < 1e-6 and np.abs(pt - gb.point_xyz).max() < 1e-4
+    s.close()
+
+
+def test_c4_parity_and_determinism(olib):
+    """200 KF / 30k landmarks / 300k observations: parity with the oracle and bitwise run-to-run reproducibility
+    (every device reduction has a fixed order; no floating-point atomics)."""
+    o, s, gb = make_pair(olib, synth.make_window("C4"), iterations=10, solver=2)
+    check_optimize(o, s, pose_tol=1e-5)
+    a = s.download()
+    s.reset(); s.optimize()
+    b = s.download()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    s.close(); o.close()
+
+
+# ---------------------------------------------------------------- window layer (localOptimize contract)
+def solve_both(olib, w, **prm_kw):
+    from visfs_amd import backend
+    prm = abi.default_params(**prm_kw)
+    wb_o, wb_g = abi.WindowBuffers(w), abi.WindowBuffers(w)
+    rb_o = abi.ResultBuffers(wb_o.struct.n_poses, wb_o.struct.n_refs)
+    rc_o = olib.oracle_solve_window(C.byref(prm), C.byref(wb_o.struct), C.byref(rb_o.struct), 1)
+    s = backend.Solver(prm)
+    rc_g, rb_g = s.solve_window(wb_g)
+    s.close()
+    return rc_o, wb_o, rb_o, rc_g, wb_g, rb_g
+
+
+def test_solve_window_matches_oracle(olib):
+    w = synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400)
+    w["point_ids"] = np.r_[np.asarray(w["point_ids"]), np.uint64(77777)]       # a point without references → NaN on return
+    w["point_xyz"] = np.vstack([w["point_xyz"], [[1.0, 2.0, 3.0]]]); w["point_fixed"] = np.r_[w["point_fixed"], np.uint8(0)]
+    rc_o, wb_o, rb_o, rc_g, wb_g, rb_g = solve_both(olib, w, iterations=20, solver=2)
+    assert rc_o == rc_g == abi.OK
+    assert rb_g.struct.n_poses_out == rb_o.struct.n_poses_out == 12
+    assert np.array_equal(rb_g.pose_ids_out[:12], rb_o.pose_ids_out[:12])
+    et, er = synth.pose_errors(rb_g.pose_Twr_out[:12], rb_o.pose_Twr_out[:12])
+    assert et < 1e-6 and er < 1e-6                                             # north_star: <= 1e-4
+    assert rb_g.outliers() == rb_o.outliers()                                  # same pairs, same (reference) order
+    assert np.isnan(wb_g.point_xyz[-1]).all() and np.isnan(wb_o.point_xyz[-1]).all()
+    assert rel_err(wb_g.point_xyz[:-1], wb_o.point_xyz[:-1]) < 1e-6
+    assert list(rb_g.struct.iterations_run) == list(rb_o.struct.iterations_run)
+
+
+def test_solve_window_error_convention(olib):
+    from visfs_amd import backend
+    w = synth.make_window("C1")
+    s = backend.Solver(abi.default_params(iterations=10))
+    # single pose → passthrough (Optimizer.cpp:360-361)
+    w1 = dict(w); w1["pose_ids"] = w["pose_ids"][:1]; w1["pose_Twr"] = w["pose_Twr"][:1]
+    rc, rb = s.solve_window(abi.WindowBuffers(w1))
+    assert rc == abi.PASSTHROUGH and rb.struct.n_poses_out == 1 and np.array_equal(rb.pose_Twr_out[0], np.asarray(w["pose_Twr"])[0])
+    # first id == 0 → error, empty map (Optimizer.cpp:74, 362-364)
+    w0 = dict(w); w0["pose_ids"] = np.arange(0, 10, dtype=np.uint64)
+    rc, rb = s.solve_window(abi.WindowBuffers(w0))
+    assert rc == abi.ERR_TOO_FEW_POSES and rb.struct.n_poses_out == 0
+    # NaN pose → "Optimization generated NANs" → empty map (Optimizer.cpp:272-275)
+    wn = dict(w); T = np.asarray(w["pose_Twr"]).copy(); T[3, 3] = np.nan; wn["pose_Twr"] = T
+    rc, rb = s.solve_window(abi.WindowBuffers(wn))
+    assert rc == abi.ERR_NAN_CHI2 and rb.struct.n_poses_out == 0 and rb.struct.n_outliers == 0
+    # laser points are out of scope → explicit UNSUPPORTED, never a silent skip
+    wl = dict(w); wl["n_laser_points"] = 5
+    rc, rb = s.solve_window(abi.WindowBuffers(wl))
+    assert rc == abi.ERR_UNSUPPORTED
+    # iterations <= 0 → passthrough
+    s0 = backend.Solver(abi.default_params(iterations=0))
+    rc, rb = s0.solve_window(abi.WindowBuffers(w))
+    assert rc == abi.PASSTHROUGH and rb.struct.n_poses_out == 10
+    s.close(); s0.close()
+
+
+def test_solve_batch_equals_individual_solves(olib):
+    """BASELINE config 5 in miniature: independent windows solved concurrently give the single-window results bit for bit."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("C1", window_index=i) for i in range(5)]
+    s = backend.Solver(prm)
+    singles = []
+    for w in ws:
+        rc, rb = s.solve_window(abi.WindowBuffers(w))
+        assert rc == abi.OK
+        singles.append(rb)
+    wbs = [abi.WindowBuffers(w) for w in ws]
+    rbs = s.solve_batch(wbs)
+    for a, b in zip(singles, rbs):
+        assert b.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+    s.close()
+
+
+def test_handle_reuse_across_shapes(olib):
+    """One handle, windows of different sizes back to back (the per-frame usage pattern of Estimator::process)."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    s = backend.Solver(prm)
+    for cfg in ("PROD", "C1", "PROD"):
+        w = synth.make_window(cfg)
+        rc, rb = s.solve_window(abi.WindowBuffers(w))
+        wb_o = abi.WindowBuffers(w); rb_o = abi.ResultBuffers(wb_o.struct.n_poses, wb_o.struct.n_refs)
+        assert olib.oracle_solve_window(C.byref(prm), C.byref(wb_o.struct), C.byref(rb_o.struct), 1) == abi.OK == rc
+        n = rb.struct.n_poses_out
+        et, er = synth.pose_errors(rb.pose_Twr_out[:n], rb_o.pose_Twr_out[:n])
+        assert et < 1e-6 and er < 1e-6 and rb.outliers() == rb_o.outliers()
+    s.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

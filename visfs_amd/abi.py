@@ -1,9 +1,8 @@
 """ctypes mirror of include/visfs_ba.h (the C ABI of the BA backend).
 
 Only struct layouts and helpers to fill them from numpy arrays live here; no
-arithmetic.  Both the product binding (visfs_amd.backend) and the test-side oracle
-binding (tests/oracle_lib.py) use these definitions so that they are fed identical
-bytes.
+arithmetic.  The product binding (visfs_amd.backend) and the test-side checker binding
+under tests/ both use these definitions so that they are fed identical bytes.
 """
 import ctypes as C
 
@@ -69,6 +68,22 @@ class Graph(C.Structure):
                 ("obs_point", _pi32), ("obs_pose", _pi32), ("obs_uvr", _pd),
                 ("odo_from", _pi32), ("odo_to", _pi32), ("odo_tq", _pd),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
+
+
+K_NAMES = ["k_linearize", "k_lin_finalize", "k_schur", "k_pcg_init", "k_pcg_iter", "k_direct", "k_backsub",
+           "k_decide", "k_phase_end", "k_reset"]
+K_COUNT = len(K_NAMES)
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_free_poses", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
+                ("n_odo", C.c_int32), ("n_blk", C.c_int32), ("n_pairs", C.c_int64), ("lanes_per_landmark", C.c_int32),
+                ("pcg_slots", C.c_int32), ("device_bytes", C.c_int64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("total_ms", C.c_double * K_COUNT), ("launches", C.c_int64 * K_COUNT),
+                ("active_ms", C.c_double * K_COUNT), ("active_launches", C.c_int64 * K_COUNT)]
 
 
 class Stats(C.Structure):
@@ -189,7 +204,7 @@ class GraphBuffers:
 
 
 def pack_window_with(lib_pack, params, wb):
-    """Run a `*_pack_window` entry point (product or oracle) and return (GraphBuffers, point_used, obs_ref, n_mono)."""
+    """Run a `*_pack_window` entry point and return (GraphBuffers, point_used, obs_ref, n_mono)."""
     w = wb.struct
     Np, Nl, Nr, Nk = w.n_poses, w.n_points, w.n_refs, w.n_links
     pose_tq = np.zeros((Np, 7)); pose_fixed = np.zeros(Np, np.uint8); used = np.zeros(max(Nl, 1), np.uint8)

@@ -22,7 +22,8 @@ EXPORTS = [
     "visfs_ba_last_error", "visfs_ba_solve_window", "visfs_ba_solve_batch", "visfs_ba_pack_window",
     "visfs_ba_unpack_pose", "visfs_ba_graph_upload", "visfs_ba_graph_reset", "visfs_ba_optimize",
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
-    "visfs_ba_stage_trial", "visfs_ba_stage_fetch",
+    "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
+    "visfs_ba_profile_read",
 ]
 
 _lib = None
@@ -70,6 +71,12 @@ def load_library():
     lib.visfs_ba_stage_trial.restype = C.c_int
     lib.visfs_ba_stage_fetch.argtypes = [C.c_void_p, C.c_int32, _pd, C.c_size_t]
     lib.visfs_ba_stage_fetch.restype = C.c_int
+    lib.visfs_ba_graph_describe.argtypes = [C.c_void_p, C.POINTER(abi.GraphInfo)]
+    lib.visfs_ba_graph_describe.restype = C.c_int
+    lib.visfs_ba_profile_enable.argtypes = [C.c_void_p, C.c_uint32]
+    lib.visfs_ba_profile_enable.restype = C.c_int
+    lib.visfs_ba_profile_read.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
+    lib.visfs_ba_profile_read.restype = C.c_int
     if lib.visfs_ba_abi_version() != abi.ABI_VERSION:
         raise BackendError("ABI version mismatch between visfs_amd/abi.py and libvisfs_ba_hip.so")
     _lib = lib
@@ -131,6 +138,28 @@ class Solver:
         out = np.zeros(max(g.n_obs, 1), np.uint8); chi = np.zeros(max(g.n_obs, 1))
         self._check(self.lib.visfs_ba_graph_download(self.h, _p(pose), _p(pt), out.ctypes.data_as(_pu8), _p(chi)), "graph_download")
         return pose, pt[:g.n_points], out[:g.n_obs], chi[:g.n_obs]
+
+    # ---- measurement hooks
+    def describe(self):
+        info = abi.GraphInfo()
+        self._check(self.lib.visfs_ba_graph_describe(self.h, C.byref(info)), "graph_describe")
+        return {k: getattr(info, k) for k, _ in abi.GraphInfo._fields_}
+
+    def profile_enable(self, which=True):
+        """which: True (all kernel classes), False (none) or an iterable of kernel names (abi.K_NAMES)."""
+        if which is True:
+            mask = (1 << abi.K_COUNT) - 1
+        elif not which:
+            mask = 0
+        else:
+            mask = sum(1 << abi.K_NAMES.index(k) for k in which)
+        self._check(self.lib.visfs_ba_profile_enable(self.h, mask), "profile_enable")
+
+    def profile_read(self):
+        p = abi.Profile()
+        self._check(self.lib.visfs_ba_profile_read(self.h, C.byref(p)), "profile_read")
+        return {abi.K_NAMES[k]: dict(total_ms=p.total_ms[k], launches=p.launches[k], active_ms=p.active_ms[k],
+                                     active_launches=p.active_launches[k]) for k in range(abi.K_COUNT) if p.launches[k]}
 
     # ---- stage hooks (parity tests)
     def linearize(self):

@@ -46,8 +46,44 @@ struct Workspace {
     int pcg_slots = 24;         // k_pcg_iter launches enqueued per unit (adapts upwards)
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
+    int64_t n_pairs = 0;
+    size_t device_bytes = 0;
+    // measurement: hipEvent pairs around the launches of the enabled kernel classes
+    uint32_t prof_mask = 0;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct ProfRec { int k; hipEvent_t a, b; };
+    std::vector<ProfRec> recs;
+    std::vector<float> durs[VISFS_BA_K_COUNT];
+    int64_t active[VISFS_BA_K_COUNT] = { 0 };
     int n6() const { return 6 * g.Npf; }
 };
+
+// RAII: records an event pair on the workspace stream around the launches of one kernel class.
+struct ProfScope {
+    Workspace& w; int k; bool on; hipEvent_t a{};
+    static hipEvent_t take(Workspace& w) {
+        if (w.ev_used == w.ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; w.ev_pool.push_back(e); }
+        return w.ev_pool[w.ev_used++];
+    }
+    ProfScope(Workspace& w_, int k_) : w(w_), k(k_), on((w_.prof_mask >> k_) & 1u) {
+        if (on) { a = take(w); if (a) (void)hipEventRecord(a, w.stream); else on = false; }
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEvent_t b = take(w);
+        if (!b) return;
+        (void)hipEventRecord(b, w.stream);
+        w.recs.push_back({ k, a, b });
+    }
+};
+
+// after a stream synchronisation: turn the recorded pairs into durations and recycle the events
+static void prof_harvest(Workspace& w) {
+    for (auto& r : w.recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) w.durs[r.k].push_back(ms); }
+    w.recs.clear();
+    w.ev_used = 0;
+}
 
 }  // namespace
 
@@ -76,6 +112,7 @@ void ws_release(Workspace& w) {
     if (w.d_base) (void)hipFree(w.d_base);
     if (w.h_base) (void)hipHostFree(w.h_base);
     if (w.h_state) (void)hipHostFree(w.h_state);
+    for (hipEvent_t e : w.ev_pool) (void)hipEventDestroy(e);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     w = Workspace{};
 }
@@ -370,6 +407,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.huber_delta = prm.robust_kernel_delta;             // Optimizer.cpp:212-216
     dg.debug = 0;
     w.g = dg;
+    w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
     HIP_TRY(h, hipMemcpyAsync(w.d_base, w.h_base, static_bytes, hipMemcpyHostToDevice, w.stream));
@@ -386,21 +424,23 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
 int ws_read_state(visfs_ba_handle* h, Workspace& w) {
     HIP_TRY(h, hipMemcpyAsync(w.h_state, w.g.st, sizeof(LmState), hipMemcpyDeviceToHost, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));
+    if (!w.recs.empty()) prof_harvest(w);
     return VISFS_BA_OK;
 }
 
 // One unit of the LM state machine (gated on the device; see ba_kernels.hip header).
 void enqueue_unit(visfs_ba_handle* h, Workspace& w) {
-    launch_linearize(w.g, w.stream);
-    launch_schur(w.g, w.stream);
+    { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE); launch_lin_finalize(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_SCHUR); launch_schur(w.g, w.stream); }
     if (h->prm.solver == 2) {
-        launch_pcg_init(w.g, w.hp & 1, w.stream);
-        for (int s = 0; s < w.pcg_slots; ++s) { launch_pcg_iter(w.g, w.hp & 1, w.stream); w.hp++; }
+        { ProfScope p(w, VISFS_BA_K_PCG_INIT); launch_pcg_init(w.g, w.hp & 1, w.stream); }
+        for (int s = 0; s < w.pcg_slots; ++s) { ProfScope p(w, VISFS_BA_K_PCG_ITER); launch_pcg_iter(w.g, w.hp & 1, w.stream); w.hp++; }
     } else {
-        launch_direct(w.g, w.stream);
+        ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream);
     }
-    launch_backsub(w.g, w.stream);
-    launch_decide(w.g, w.stream);
+    { ProfScope p(w, VISFS_BA_K_BACKSUB); launch_backsub(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_DECIDE); launch_decide(w.g, w.stream); }
 }
 
 // optimizer.optimize(n) for the phase armed in LmState: enqueue units until the device reports `done`.
@@ -439,17 +479,25 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     const int half = h->prm.iterations / 2;
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
-    launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream);
+    { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     int rc = run_phase(h, w, half);                               // :265
     if (rc != VISFS_BA_OK) return rc;
-    launch_phase_end(w.g, 0, 1, half, w.stream);                  // :270-303
+    { ProfScope p(w, VISFS_BA_K_PHASE_END); launch_phase_end(w.g, 0, 1, half, w.stream); }   // :270-303
     rc = run_phase(h, w, (h->prm.robust_kernel_delta > 0.0) ? half : 0);   // :310-311 (gated off on abort)
     if (rc != VISFS_BA_OK) return rc;
-    launch_phase_end(w.g, 1, 0, 0, w.stream);                     // :315-318
+    { ProfScope p(w, VISFS_BA_K_PHASE_END); launch_phase_end(w.g, 1, 0, 0, w.stream); }      // :315-318
     HIP_TRY(h, hipGetLastError());
     rc = ws_read_state(h, w);
     if (rc != VISFS_BA_OK) return rc;
     if (stats) fill_stats(*w.h_state, stats);
+    if (w.prof_mask) {
+        const LmState& st = *w.h_state;
+        w.active[VISFS_BA_K_LINEARIZE] += st.n_active[0]; w.active[VISFS_BA_K_LIN_FINALIZE] += st.n_active[0];
+        w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
+        w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG_INIT : VISFS_BA_K_DIRECT] += st.n_active[1];
+        w.active[VISFS_BA_K_PCG_ITER] += st.n_active[2]; w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
+        w.active[VISFS_BA_K_PHASE_END] += 2; w.active[VISFS_BA_K_RESET] += 1;
+    }
     if (h->prm.solver == 2 && w.h_state->pcg_max > 0) w.pcg_slots = std::max(4, w.h_state->pcg_max + 2);   // right-size the next enqueue
     return w.h_state->status;
 }
@@ -721,6 +769,40 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
     return worst;
 }
 
+int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
+    if (!h || !out) return VISFS_BA_ERR_BAD_ARGUMENT;
+    const Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    out->n_poses = w.g.Np; out->n_free_poses = w.g.Npf; out->n_points = w.g.Nl; out->n_obs = w.g.No; out->n_odo = w.g.Ne;
+    out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->pcg_slots = w.pcg_slots;
+    out->device_bytes = (int64_t)w.device_bytes;
+    return VISFS_BA_OK;
+}
+
+int visfs_ba_profile_enable(visfs_ba_handle* h, uint32_t mask) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    h->ws.prof_mask = mask;
+    return VISFS_BA_OK;
+}
+
+int visfs_ba_profile_read(visfs_ba_handle* h, visfs_ba_profile* out) {
+    if (!h || !out) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (w.stream) { HIP_TRY(h, hipStreamSynchronize(w.stream)); prof_harvest(w); }
+    std::memset(out, 0, sizeof(*out));
+    for (int k = 0; k < VISFS_BA_K_COUNT; ++k) {
+        std::vector<float>& d = w.durs[k];
+        std::sort(d.begin(), d.end(), [](float a, float b) { return a > b; });
+        out->launches[k] = (int64_t)d.size();
+        const int64_t na = std::min<int64_t>(w.active[k], (int64_t)d.size());
+        out->active_launches[k] = na;
+        for (size_t i = 0; i < d.size(); ++i) { out->total_ms[k] += d[i]; if ((int64_t)i < na) out->active_ms[k] += d[i]; }
+        d.clear();
+        w.active[k] = 0;
+    }
+    return VISFS_BA_OK;
+}
+
 // ---------------------------------------------------------------- stage hooks
 int visfs_ba_graph_free_poses(visfs_ba_handle* h) { return (h && h->ws.loaded) ? h->ws.g.Npf : -1; }
 
@@ -732,6 +814,7 @@ int visfs_ba_stage_linearize(visfs_ba_handle* h, double* robust_chi2, double* ma
     g.debug = 1;
     launch_stage_arm(g, 0.0, 1, w.stream);
     launch_linearize(g, w.stream);
+    launch_lin_finalize(g, w.stream);
     HIP_TRY(h, hipGetLastError());
     int rc = ws_read_state(h, w);
     if (rc != VISFS_BA_OK) return rc;

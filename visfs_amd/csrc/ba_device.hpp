@@ -43,6 +43,7 @@ struct LmState {
     int32_t iterations_run[2], trials_run[2];
     int32_t pcg_max;        // most PCG iterations any solve of this call needed (sizes the next enqueue)
     int32_t pad_;
+    int32_t n_active[4];    // launches that did work: 0 linearise, 1 schur, 2 pcg_iter, 3 backsub
 };
 
 // PCG control word, double-buffered on the launch parity (see k_pcg_iter).

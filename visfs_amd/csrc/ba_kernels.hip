@@ -325,6 +325,7 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g) {
         }
         st->need_lin = 0;
         st->trial_q = 0;
+        st->n_active[0] += 1;
     }
 }
 
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(64) void k_pcg_iter(const DeviceGraph g, const int 
     PcgCtl* nxt = g.pcg_ctl + (hp ^ 1);
     const int lane = threadIdx.x, i = blockIdx.x;
     if (!ctl.go) { if (i == 0 && lane == 0) nxt->go = 0; return; }
+    if (i == 0 && lane == 0) g.st->n_active[2] += 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n6 = 6 * g.Npf;
     double* sd = smem;                 // d (new)
@@ -749,6 +751,8 @@ __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
     const int ph = st->phase;
     st->trials_run[ph] += 1;
     st->solve_state = 0;
+    st->n_active[1] += 1;
+    if (ok) st->n_active[3] += 1;
     if (st->gauss_newton) {
         // OptimizationAlgorithmGaussNewton: always take the step; Fail ends the phase
         if (ok) st->sel ^= 1;
@@ -887,6 +891,7 @@ __global__ __launch_bounds__(256) void k_reset(const DeviceGraph g, const int ma
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
         if (restore) st->sel = 0;
         st->pcg_max = 0; st->pad_ = 0;
+        st->n_active[0] = st->n_active[1] = st->n_active[2] = st->n_active[3] = 0;
         st->phase = 0; st->max_iter = max_iter; st->phase_iter = 0; st->trial_q = 0;
         st->need_lin = 1; st->done = (max_iter <= 0) ? 1 : 0; st->solve_state = 0;
         st->pcg_iter = 0; st->pcg_total = 0; st->gauss_newton = gauss_newton; st->status = 0;
@@ -924,6 +929,9 @@ void launch_linearize(const DeviceGraph& g, hipStream_t s) {
         case 32: launch_lin_t<32>(g, s); break;
         default: launch_lin_t<64>(g, s); break;
     }
+}
+
+void launch_lin_finalize(const DeviceGraph& g, hipStream_t s) {
     hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(1024), 0, s, g);
 }
 

@@ -10,7 +10,8 @@ namespace visfs_ba {
 
 int configure_kernels(const DeviceGraph& g);
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s);
-void launch_linearize(const DeviceGraph& g, hipStream_t s);          // k_linearize + k_lin_finalize
+void launch_linearize(const DeviceGraph& g, hipStream_t s);
+void launch_lin_finalize(const DeviceGraph& g, hipStream_t s);
 void launch_schur(const DeviceGraph& g, hipStream_t s);
 void launch_pcg_init(const DeviceGraph& g, int hp_write, hipStream_t s);
 void launch_pcg_iter(const DeviceGraph& g, int hp, hipStream_t s);

@@ -225,5 +225,7 @@ def pose_errors(Twr_a, Twr_b):
     B = np.asarray(Twr_b).reshape(-1, 3, 4)
     dt = np.linalg.norm(A[:, :, 3] - B[:, :, 3], axis=1) / np.maximum(1.0, np.linalg.norm(B[:, :, 3], axis=1))
     Rrel = np.swapaxes(A[:, :, :3], 1, 2) @ B[:, :, :3]
-    c = np.clip((np.trace(Rrel, axis1=1, axis2=2) - 1.0) * 0.5, -1.0, 1.0)
-    return float(dt.max()), float(np.arccos(c).max())
+    # geodesic angle from the chord ||R - I||_F = 2 sqrt(2) sin(theta/2): accurate near zero, unlike acos(trace)
+    chord = np.linalg.norm(Rrel - np.eye(3), axis=(1, 2))
+    ang = 2.0 * np.arcsin(np.clip(chord / (2.0 * np.sqrt(2.0)), 0.0, 1.0))
+    return float(dt.max()), float(ang.max())
