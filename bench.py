@@ -28,12 +28,12 @@ def algorithmic_bytes(kernel, d):
     No, Nl, Np, npairs, nblk = d["n_obs"], d["n_points"], d["n_poses"], d["n_pairs"], d["n_blk"]
     if kernel == "k_linearize":      # stage A of §8d: 256 B/obs + 96 B/landmark + 336 B/pose
         return 256 * No + 96 * Nl + 336 * Np
-    if kernel == "k_schur":          # stage B: 144 B/obs (Hpl) + 96 B/landmark + 288 B/stored block + 48 B/pose
+    if kernel == "k_schur_partial":  # stage B: 144 B/obs (Hpl) + 96 B/landmark + 288 B/stored block + 48 B/pose
         return 144 * No + 96 * Nl + 288 * nblk + 48 * Np
     if kernel == "k_backsub":        # stages D+E: 144 + 112 + 8 B/obs, (72+24+24)+48 B/landmark, 112 B/pose
         return 264 * No + 168 * Nl + 112 * Np
-    if kernel == "k_pcg_iter":       # stage C, one iteration: 288 B/block + 4*48 B/pose
-        return 288 * nblk + 192 * Np
+    if kernel == "k_pcg":            # stage C, k iterations in one launch: k * (288 B/block + 4*48 B/pose)
+        return d["pcg_iters_per_launch"] * (288 * nblk + 192 * Np)
     raise KeyError(kernel)
 
 
@@ -92,21 +92,24 @@ def main():
     for _ in range(args.warmup):
         step()
     # untimed calibration pass: HIP-event pairs around every kernel class → per-kernel breakdown + the dominant kernel
-    data_kernels = ("k_linearize", "k_schur", "k_backsub", "k_pcg_iter")
+    data_kernels = ("k_linearize", "k_schur_partial", "k_backsub", "k_pcg")
     solvers[0].profile_enable(True)
     for _ in range(3):
         step()
     calib = solvers[0].profile_read()
     cand = [k for k in data_kernels if calib.get(k, {}).get("active_launches", 0) > 0]
     dom = max(cand, key=lambda k: calib[k]["active_ms"]) if cand else None
-    # timed region: events only around the dominant kernel's launches (on the library's own stream)
-    solvers[0].profile_enable([dom] if dom else False)
+    # timed region: events only around the dominant kernel's launches (on the library's own stream), every 8th step
+    solvers[0].profile_enable(False)
     vdist.barrier(world, dev if world > 1 else None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     iters = 0
     last = None
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        # HIP-event pairs cost ~5 us per record on the stream: instrument every 8th step of the timed region only
+        if dom:
+            solvers[0].profile_enable([dom] if k % 8 == 0 else False)
         n, last = step()
         iters += n
     torch.cuda.synchronize()
@@ -123,6 +126,7 @@ def main():
     if dom and dom in prof:
         p = prof[dom]
         avg_s = p["active_ms"] * 1e-3 / p["active_launches"]
+        d["pcg_iters_per_launch"] = (last.pcg_iterations / max(1, last.trials_run[0] + last.trials_run[1])) if last is not None else 0
         byts = algorithmic_bytes(dom, d)
         achieved = byts / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",

@@ -70,7 +70,7 @@ class Graph(C.Structure):
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
 
 
-K_NAMES = ["k_linearize", "k_lin_finalize", "k_schur", "k_pcg_init", "k_pcg_iter", "k_direct", "k_backsub",
+K_NAMES = ["k_linearize", "k_lin_finalize", "k_schur_partial", "k_schur_finalize", "k_pcg", "k_direct", "k_backsub",
            "k_decide", "k_phase_end", "k_reset"]
 K_COUNT = len(K_NAMES)
 
@@ -78,7 +78,7 @@ K_COUNT = len(K_NAMES)
 class GraphInfo(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_free_poses", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
                 ("n_odo", C.c_int32), ("n_blk", C.c_int32), ("n_pairs", C.c_int64), ("lanes_per_landmark", C.c_int32),
-                ("pcg_slots", C.c_int32), ("device_bytes", C.c_int64)]
+                ("n_schur_chunks", C.c_int32), ("device_bytes", C.c_int64)]
 
 
 class Profile(C.Structure):

@@ -42,8 +42,6 @@ struct Workspace {
     LmState* h_state = nullptr;                    // pinned
     DeviceGraph g{};
     bool loaded = false;
-    int hp = 0;                 // PCG launch parity counter
-    int pcg_slots = 24;         // k_pcg_iter launches enqueued per unit (adapts upwards)
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
     int64_t n_pairs = 0;
@@ -220,7 +218,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
             }
         }
     const int n_blk = (int)blk_i.size();
-    std::vector<int2> pairs(std::max<int64_t>(npairs, 1));
+    std::vector<int4> pairs(std::max<int64_t>(npairs, 1), make_int4(0, 0, 0, 0));
     {
         std::vector<int32_t> pos(blk_ptr.begin(), blk_ptr.end() - 1);
         for (int l = 0; l < Nl; ++l) {
@@ -231,7 +229,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
                 for (int k2 = k1; k2 < lm_ptr[l + 1]; ++k2) {
                     const int b = pose_free[gr->obs_pose[k2]];
                     if (b < 0) continue;
-                    pairs[pos[blk_of[(size_t)a * Npf + b]]++] = make_int2(k1, k2);
+                    pairs[pos[blk_of[(size_t)a * Npf + b]]++] = make_int4(k1, k2, l, 0);
                 }
             }
         }
@@ -264,6 +262,24 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         }
         row_ptr[Npf] = (int32_t)row_col.size();
     }
+
+    // Schur chunks: <= SCH_CHUNK co-observation pairs of one block per wavefront
+    std::vector<int32_t> blk_chunk_ptr(n_blk + 1, 0), sch_blk, sch_ptr;
+    for (int b = 0; b < n_blk; ++b) {
+        blk_chunk_ptr[b] = (int32_t)sch_blk.size();
+        for (int e = blk_ptr[b]; e < blk_ptr[b + 1]; e += SCH_CHUNK) { sch_blk.push_back(b); sch_ptr.push_back(e); }
+    }
+    blk_chunk_ptr[n_blk] = (int32_t)sch_blk.size();
+    const int n_sch = (int)sch_blk.size();
+    // persistent PCG: LDS plan (4 vectors always; all Minv blocks and the own block row of S when they fit in 60 KiB)
+    if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 341 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
+    int max_row = 0;
+    for (int a = 0; a < Npf; ++a) max_row = std::max(max_row, row_ptr[a + 1] - row_ptr[a]);
+    size_t pcg_lds = (size_t)4 * 6 * Npf * 8 + 40 * 8;
+    int lds_minv = 0, lds_srow = 0;
+    if (pcg_lds + (size_t)288 * Npf <= 60 * 1024) { lds_minv = 1; pcg_lds += (size_t)288 * Npf; }
+    if (pcg_lds + (size_t)288 * max_row <= 60 * 1024) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
+    pcg_lds += (size_t)8 * max_row + 16;      // column / block-code tables of the row
 
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -299,7 +315,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.blk_i = A.take<int32_t>(std::max(n_blk, 1));
         g.blk_j = A.take<int32_t>(std::max(n_blk, 1));
         g.blk_ptr = A.take<int32_t>(n_blk + 1);
-        g.blk_pairs = A.take<int2>(pairs.size());
+        g.blk_pairs = A.take<int4>(pairs.size());
+        g.blk_chunk_ptr = A.take<int32_t>(n_blk + 1);
+        g.sch_blk = A.take<int32_t>(std::max(n_sch, 1));
+        g.sch_ptr = A.take<int32_t>(std::max(n_sch, 1));
         g.blk_odo_ptr = A.take<int32_t>(n_blk + 1);
         g.blk_odo = A.take<int32_t>(std::max<size_t>(blk_odo.size(), 1));
         g.row_ptr = A.take<int32_t>(Npf + 1);
@@ -329,14 +348,13 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.odo_blk = A.take<double>((size_t)std::max(Ne, 1) * 120);
         g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.bp = A.take<double>(std::max<size_t>(n6, 1));
-        g.pose_pin = A.take<int32_t>(std::max(Npf, 1));
         g.lin_part = A.take<double>((size_t)n_parts * 2);
         g.S = A.take<double>((size_t)std::max(n_blk, 1) * 36);
         g.bs = A.take<double>(std::max<size_t>(n6, 1));
         g.Minv = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.x = A.take<double>(std::max<size_t>(n6, 1));
-        for (int p = 0; p < 2; ++p) { g.pcg_r[p] = A.take<double>(std::max<size_t>(n6, 1)); g.pcg_d[p] = A.take<double>(std::max<size_t>(n6, 1)); g.pcg_q[p] = A.take<double>(std::max<size_t>(n6, 1)); }
-        g.pcg_ctl = A.take<PcgCtl>(2);
+        g.sch_part = A.take<double>((size_t)std::max(n_sch, 1) * 42);
+        g.granules = A.take<unsigned long long>(std::max<size_t>(4 * n6, 1));
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.dense = A.take<double>(prm.solver == 2 ? 1 : std::max<size_t>(n6 * n6, 1));
@@ -388,7 +406,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (!pose_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.pose_odo), pose_odo.data(), pose_odo.size() * 4);
         if (n_blk) { std::memcpy(const_cast<int32_t*>(hg.blk_i), blk_i.data(), (size_t)n_blk * 4); std::memcpy(const_cast<int32_t*>(hg.blk_j), blk_j.data(), (size_t)n_blk * 4); }
         std::memcpy(const_cast<int32_t*>(hg.blk_ptr), blk_ptr.data(), (size_t)(n_blk + 1) * 4);
-        std::memcpy(const_cast<int2*>(hg.blk_pairs), pairs.data(), pairs.size() * sizeof(int2));
+        std::memcpy(const_cast<int4*>(hg.blk_pairs), pairs.data(), pairs.size() * sizeof(int4));
+        std::memcpy(const_cast<int32_t*>(hg.blk_chunk_ptr), blk_chunk_ptr.data(), (size_t)(n_blk + 1) * 4);
+        if (n_sch) { std::memcpy(const_cast<int32_t*>(hg.sch_blk), sch_blk.data(), (size_t)n_sch * 4); std::memcpy(const_cast<int32_t*>(hg.sch_ptr), sch_ptr.data(), (size_t)n_sch * 4); }
         std::memcpy(const_cast<int32_t*>(hg.blk_odo_ptr), blk_odo_ptr.data(), (size_t)(n_blk + 1) * 4);
         if (!blk_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.blk_odo), blk_odo.data(), blk_odo.size() * 4);
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
@@ -401,6 +421,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     layout_dyn(dd, dg);
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group;
+    dg.n_sch = n_sch; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
@@ -417,7 +438,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(w.stream));            // staging arena is reused by the next upload
     w.loaded = true;
-    w.hp = 0;
     return VISFS_BA_OK;
 }
 
@@ -428,17 +448,15 @@ int ws_read_state(visfs_ba_handle* h, Workspace& w) {
     return VISFS_BA_OK;
 }
 
-// One unit of the LM state machine (gated on the device; see ba_kernels.hip header).
-void enqueue_unit(visfs_ba_handle* h, Workspace& w) {
+// One unit of the LM state machine (gated on the device; see ba_kernels.hip header).  `first` = first unit of a
+// phase: only there lambda has to be initialised from max|diag H| (k_lin_finalize).
+void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize(w.g, w.stream); }
-    { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE); launch_lin_finalize(w.g, w.stream); }
-    { ProfScope p(w, VISFS_BA_K_SCHUR); launch_schur(w.g, w.stream); }
-    if (h->prm.solver == 2) {
-        { ProfScope p(w, VISFS_BA_K_PCG_INIT); launch_pcg_init(w.g, w.hp & 1, w.stream); }
-        for (int s = 0; s < w.pcg_slots; ++s) { ProfScope p(w, VISFS_BA_K_PCG_ITER); launch_pcg_iter(w.g, w.hp & 1, w.stream); w.hp++; }
-    } else {
-        ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream);
-    }
+    if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE); launch_lin_finalize(w.g, 0, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_SCHUR); launch_schur_partial(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE); launch_schur_finalize(w.g, w.stream); }
+    if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG); launch_pcg(w.g, w.stream); }
+    else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     { ProfScope p(w, VISFS_BA_K_BACKSUB); launch_backsub(w.g, w.stream); }
     { ProfScope p(w, VISFS_BA_K_DECIDE); launch_decide(w.g, w.stream); }
 }
@@ -448,16 +466,17 @@ int run_phase(visfs_ba_handle* h, Workspace& w, int max_iter) {
     if (max_iter <= 0) return VISFS_BA_OK;
     int guard = 0;
     int remaining = max_iter;
+    bool first = true;
     while (true) {
-        for (int u = 0; u < remaining; ++u) enqueue_unit(h, w);
+        for (int u = 0; u < remaining; ++u) { enqueue_unit(h, w, first); first = false; }
         HIP_TRY(h, hipGetLastError());
         int rc = ws_read_state(h, w);
         if (rc != VISFS_BA_OK) return rc;
         const LmState& st = *w.h_state;
+        if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
         if (st.done) break;
-        if (st.solve_state == 1 && w.pcg_slots < 6 * w.g.Npf + 2) w.pcg_slots = std::min(2 * w.pcg_slots, 6 * w.g.Npf + 2);   // PCG needed more launches than one unit holds
-        remaining = std::max(1, max_iter - st.phase_iter);
-        if (++guard > 64 * max_iter + 64) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
+        remaining = std::max(1, max_iter - st.phase_iter);       // rejected trials consumed units without finishing an iteration
+        if (++guard > 16 * max_iter + 16) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
     }
     return VISFS_BA_OK;
 }
@@ -492,13 +511,14 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     if (stats) fill_stats(*w.h_state, stats);
     if (w.prof_mask) {
         const LmState& st = *w.h_state;
-        w.active[VISFS_BA_K_LINEARIZE] += st.n_active[0]; w.active[VISFS_BA_K_LIN_FINALIZE] += st.n_active[0];
-        w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
-        w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG_INIT : VISFS_BA_K_DIRECT] += st.n_active[1];
-        w.active[VISFS_BA_K_PCG_ITER] += st.n_active[2]; w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
+        w.active[VISFS_BA_K_LINEARIZE] += st.n_active[0];
+        w.active[VISFS_BA_K_LIN_FINALIZE] += (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0);
+        w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_SCHUR_FINALIZE] += st.n_active[1];
+        w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
+        w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT] += st.n_active[1];
+        w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
         w.active[VISFS_BA_K_PHASE_END] += 2; w.active[VISFS_BA_K_RESET] += 1;
     }
-    if (h->prm.solver == 2 && w.h_state->pcg_max > 0) w.pcg_slots = std::max(4, w.h_state->pcg_max + 2);   // right-size the next enqueue
     return w.h_state->status;
 }
 
@@ -774,7 +794,7 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     const Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     out->n_poses = w.g.Np; out->n_free_poses = w.g.Npf; out->n_points = w.g.Nl; out->n_obs = w.g.No; out->n_odo = w.g.Ne;
-    out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->pcg_slots = w.pcg_slots;
+    out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->n_schur_chunks = w.g.n_sch;
     out->device_bytes = (int64_t)w.device_bytes;
     return VISFS_BA_OK;
 }
@@ -812,9 +832,9 @@ int visfs_ba_stage_linearize(visfs_ba_handle* h, double* robust_chi2, double* ma
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     DeviceGraph g = w.g;
     g.debug = 1;
-    launch_stage_arm(g, 0.0, 1, w.stream);
+    launch_stage_arm(g, 0.0, MODE_LIN, w.stream);
     launch_linearize(g, w.stream);
-    launch_lin_finalize(g, w.stream);
+    launch_lin_finalize(g, 1, w.stream);
     HIP_TRY(h, hipGetLastError());
     int rc = ws_read_state(h, w);
     if (rc != VISFS_BA_OK) return rc;
@@ -831,25 +851,16 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
     if (rc != VISFS_BA_OK) return rc;
     const int sel0 = w.h_state->sel;
     const double chi0 = w.h_state->current_chi;
-    launch_stage_arm(w.g, lambda, 0, w.stream);
-    launch_schur(w.g, w.stream);
-    if (h->prm.solver == 2) {
-        launch_pcg_init(w.g, w.hp & 1, w.stream);
-        for (int guard = 0; guard < 6 * w.g.Npf + 8; guard += 16) {
-            for (int s = 0; s < 16; ++s) { launch_pcg_iter(w.g, w.hp & 1, w.stream); w.hp++; }
-            rc = ws_read_state(h, w);
-            if (rc != VISFS_BA_OK) return rc;
-            if (w.h_state->solve_state != 1) break;
-        }
-    } else {
-        launch_direct(w.g, w.stream);
-    }
+    launch_stage_arm(w.g, lambda, MODE_TRIAL, w.stream);
+    launch_schur_partial(w.g, w.stream);
+    launch_schur_finalize(w.g, w.stream);
+    if (h->prm.solver == 2) launch_pcg(w.g, w.stream); else launch_direct(w.g, w.stream);
     launch_backsub(w.g, w.stream);
     HIP_TRY(h, hipGetLastError());
     rc = ws_read_state(h, w);
     if (rc != VISFS_BA_OK) return rc;
-    const int ok = (w.h_state->solve_state == 2);
-    if (pcg_iterations) *pcg_iterations = w.h_state->pcg_iter;
+    const int ok = !w.h_state->solver_failed && !w.h_state->pcg_timeout;
+    if (pcg_iterations) *pcg_iterations = (h->prm.solver == 2) ? w.h_state->pcg_iter : 0;
     if (solver_ok) *solver_ok = ok;
     launch_decide(w.g, w.stream);                    // production K9 computes tempChi / scale ...
     HIP_TRY(h, hipGetLastError());
@@ -859,7 +870,7 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
     if (scale) *scale = w.h_state->scale - 1e-3;     // report computeScale() without the +1e-3 guard
     // ... and the hook then undoes the commit so the resident estimate is unchanged
     LmState st = *w.h_state;
-    st.sel = sel0; st.current_chi = chi0; st.solve_state = 0; st.done = 0;
+    st.sel = sel0; st.current_chi = chi0; st.done = 0; st.mode = 0;
     *w.h_state = st;
     HIP_TRY(h, hipMemcpyAsync(w.g.st, w.h_state, sizeof(LmState), hipMemcpyHostToDevice, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));

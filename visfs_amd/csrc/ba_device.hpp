@@ -19,11 +19,19 @@ constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
 constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
 constexpr int MAX_STAGED_POSES = 640; // 12 doubles each in LDS (60 KiB)
+constexpr int MAX_PCG_FREE_POSES = 341; // persistent PCG keeps 4 vectors of 6*Npf doubles in <= 64 KiB of LDS
+constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront
 
 // LM / phase state machine, resident in HBM; every kernel of a "unit" reads its gate from here.
+// Unit gate bits (LmState::mode).  Written ONLY by single-workgroup kernels (k_reset, k_decide, k_phase_end,
+// k_stage_arm), so no multi-workgroup launch ever reads a gate that the same launch modifies.
+constexpr int MODE_LIN = 1;     // this unit linearises (first unit of a phase, or the previous trial was accepted)
+constexpr int MODE_TRIAL = 2;   // this unit runs one damped solve
+
 struct LmState {
     double lambda, ni, current_chi, temp_chi, rho, scale, max_diag;
-    double pcg_dn, pcg_d0, pcg_residual;
+    double pcg_res_in;      // LinearSolverPCG::_residual as seen by the solve of this unit
+    double pcg_residual;    // ... as left by the last solve (copied to pcg_res_in by k_schur_finalize)
     double chi2_initial, chi2_phase1, chi2_final;
     double trace_lambda[MAX_TRACE], trace_chi2[MAX_TRACE];
     int32_t sel;            // index of the committed estimate buffer (0/1)
@@ -31,28 +39,30 @@ struct LmState {
     int32_t max_iter;       // outer iterations allowed in this phase
     int32_t phase_iter;     // outer iterations completed in this phase
     int32_t trial_q;        // damped solves tried in the current outer iteration
-    int32_t need_lin;       // next LIN slot must linearise
+    int32_t mode;           // MODE_* of the next unit; 0 = phase finished
     int32_t done;           // phase finished (max_iter reached or Terminate)
-    int32_t solve_state;    // 0: no solve in flight, 1: PCG running, 2: solution ready, 3: solver failed
-    int32_t pcg_iter;       // iterations done in the current solve
+    int32_t solver_failed;  // direct solver: Cholesky hit a non-positive pivot in this unit
+    int32_t pcg_iter;       // iterations of the last solve
     int32_t pcg_total;      // over all solves
     int32_t gauss_newton;   // trust_region == 1
     int32_t status;         // VISFS_BA_* (abort reasons)
     int32_t n_outliers;
     int32_t n_trace;
     int32_t iterations_run[2], trials_run[2];
-    int32_t pcg_max;        // most PCG iterations any solve of this call needed (sizes the next enqueue)
-    int32_t pad_;
-    int32_t n_active[4];    // launches that did work: 0 linearise, 1 schur, 2 pcg_iter, 3 backsub
+    int32_t pcg_max;        // most PCG iterations any solve of this call needed
+    int32_t pcg_timeout;    // a persistent-PCG workgroup gave up waiting (never expected; surfaces as ERR_DEVICE)
+    int32_t n_active[4];    // units that did work: 0 linearise, 1 trial, 2 (unused), 3 back-substitution
 };
-
-// PCG control word, double-buffered on the launch parity (see k_pcg_iter).
-struct PcgCtl { int32_t go, has_q, iter, pad; double dn; };
 
 struct DeviceGraph {
     int32_t Np, Nl, No, Ne, Npf;
     int32_t n_chunks;       // pose-major chunks
     int32_t n_blk;          // stored S blocks (i <= j)
+    int32_t n_sch;          // Schur chunks (<= 64 co-observation pairs of one block each)
+    int32_t pcg_lds_minv;   // persistent PCG keeps all Minv blocks in LDS
+    int32_t pcg_lds_srow;   // ... and its own block row of S
+    int32_t pcg_max_row;    // longest block row of S (blocks)
+    int32_t pcg_lds_bytes;
     int32_t n_lin_a;        // workgroups of the landmark-major role
     int32_t group;          // lanes per landmark (4/8/16/32/64)
     double fx, fy, cx, cy, bf;
@@ -81,7 +91,10 @@ struct DeviceGraph {
     const int32_t* blk_i;       // [n_blk] free pose index (row)
     const int32_t* blk_j;       // [n_blk] (col), j >= i
     const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
-    const int2* blk_pairs;      // (obs of pose i, obs of pose j) sharing a landmark
+    const int4* blk_pairs;      // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark
+    const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block
+    const int32_t* sch_blk;     // [n_sch] block of the chunk
+    const int32_t* sch_ptr;     // [n_sch] first pair of the chunk (it ends at min(+64, end of block))
     const int32_t* blk_odo_ptr; // [n_blk+1]
     const int32_t* blk_odo;     // [..] edge*2 + transposed
     const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)
@@ -114,10 +127,8 @@ struct DeviceGraph {
     double* bs;                 // [Npf][6]
     double* Minv;               // [Npf][36]
     double* x;                  // [Npf][6]   pose increment
-    double* pcg_r[2];           // [Npf][6]
-    double* pcg_d[2];
-    double* pcg_q[2];           // [Npf][6]
-    PcgCtl* pcg_ctl;            // [2]
+    double* sch_part;           // [n_sch][42] per-chunk partial sums (36 block entries + 6 of b_s)
+    unsigned long long* granules; // [2][2*6Npf] {epoch:32 | half of a double:32} hand-off words of the persistent PCG
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
     double* dense;              // [6Npf][6Npf] scratch for the direct solver

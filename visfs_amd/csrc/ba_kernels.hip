@@ -1,22 +1,24 @@
 // ba_kernels.hip — hand-written gfx950 kernels of the sliding-window BA hot path.
 //
 // One "unit" of the device-side LM state machine is the launch sequence
-//   k_linearize → k_lin_finalize → k_schur → k_pcg_init → k_pcg_iter × P → k_backsub → k_decide
-// Each kernel reads its gate from LmState in HBM and returns immediately when it has nothing
-// to do, so a whole phase is enqueued without any host round trip.
+//   k_linearize [k_odo_linearize] [k_lin_finalize]  →  k_schur_partial → k_schur_finalize
+//   → k_pcg (persistent, one launch per damped solve) | k_dense_assemble + k_cholesky → k_backsub → k_decide
+// Every kernel reads its gate (LmState::mode) from HBM and returns at once when it has nothing to do, so a
+// whole optimise phase is enqueued without a host round trip.  `mode` is written only by single-workgroup
+// kernels, so no multi-workgroup launch reads a gate that the same launch modifies.
 //
 // Mapping to the reference / g2o:
-//   K1,K2  EdgeStereo::computeError / linearizeOplus          → k_linearize (role A, B), k_backsub, k_eval
-//   K3     EdgePoseConstraint                                 → k_linearize (role C), k_backsub (odometry role)
-//   K4     constructQuadraticForm + RobustKernelHuber          → k_linearize + k_lin_finalize
-//   K5     BlockSolver Schur complement                        → k_schur (gather over per-block pair lists)
-//   K6     LinearSolverPCG / direct Cholesky                   → k_pcg_init + k_pcg_iter / k_dense_assemble + k_cholesky
-//   K7,K8  back-substitution, oplus                            → k_backsub (+ pose update in the solver epilogue)
-//   K9     OptimizationAlgorithmLevenberg control              → k_lin_finalize + k_decide
+//   K1,K2  EdgeStereo::computeError / linearizeOplus          → k_linearize (role A landmark-major, role B pose-major), k_backsub, k_eval
+//   K3     EdgePoseConstraint                                 → k_odo_linearize, k_backsub / k_eval (odometry role)
+//   K4     constructQuadraticForm + RobustKernelHuber          → k_linearize + k_schur_finalize (Hpp/b_p sums)
+//   K5     BlockSolver Schur complement                        → k_schur_partial (gather over co-observation pairs) + k_schur_finalize
+//   K6     LinearSolverPCG / sparse Cholesky                   → k_pcg (persistent) / k_dense_assemble + k_cholesky
+//   K7,K8  back-substitution, oplus                            → k_backsub (+ pose oplus in the solver epilogue)
+//   K9     OptimizationAlgorithmLevenberg control              → k_lin_finalize (lambda init) + k_decide
 //   K10    outlier marking (Optimizer.cpp:283-303)             → k_eval + k_phase_end
 //
-// All reductions are fixed-order (wave butterflies + serial tails): no floating-point atomics,
-// bitwise reproducible results.  Wavefront = 64 everywhere.
+// All reductions are fixed-order (halving butterflies + serial tails): no floating-point atomics, results are
+// bitwise reproducible.  Wavefront = 64 everywhere.
 #include "ba_kernels.hpp"
 
 #include <float.h>
@@ -47,7 +49,35 @@ __device__ __forceinline__ double group_max(double v) {
     return v;
 }
 
-// Sum (or max) one value per thread over a 256-thread workgroup; result valid in thread 0.
+// Halving reduce-scatter: sums N per-lane values across an aligned group of W lanes with sum_k ceil(N/2^k)
+// shuffles instead of N*log2(W).  At stage M a lane with bit M clear keeps the low half of its array and
+// receives its partner's low half; a lane with the bit set does the same with the high halves.  On return
+// a[j] holds the group sum of original element off + j for j < len (other slots are padding).
+template <int N, int M>
+struct ReduceScatter {
+    static __device__ __forceinline__ void run(double* a, int lane, int& off, int& len) {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (lane & M) != 0;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const double lo = a[j];
+            const double hi = (j + H < N) ? a[j + H] : 0.0;
+            const double send = up ? lo : hi;
+            const double keep = up ? hi : lo;
+            a[j] = keep + __shfl_xor(send, M, 64);
+        }
+        if (up) { off += H; len = len > H ? len - H : 0; } else { len = len < H ? len : H; }
+        ReduceScatter<H, M / 2>::run(a, lane, off, len);
+    }
+};
+template <int N>
+struct ReduceScatter<N, 0> {
+    static __device__ __forceinline__ void run(double*, int, int&, int&) {}
+};
+// number of array slots a lane still holds after reducing N values over W lanes
+constexpr int rs_slots(int N, int W) { return W <= 1 ? N : rs_slots((N + 1) / 2, W / 2); }
+
+// Sum (or max) one value per thread over a 256-thread workgroup; every thread gets the result.
 // red: LDS scratch of >= 4 doubles.  Fixed order: wave butterfly, then waves 0..3 serially.
 __device__ __forceinline__ double block_sum_256(double v, double* red) {
     v = wave_sum(v);
@@ -88,11 +118,37 @@ __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Int
 // chi2() = e . (Omega e), Omega = I3 / pixelVariance (Optimizer.cpp:153)
 __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x * (iv * e.x) + e.y * (iv * e.y) + e.z * (iv * e.z); }
 
-// ================================================================= K1/K2/K3/K4: linearise
+// Upper-triangle index of (r,c), r <= c, in the 21-entry packing used by role B.
+__device__ __forceinline__ int upper_idx(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+// Entry q (< 36: Hpp(r,c); 36..41: b_p) of free pose a: fixed-order sum of the pose-major chunk partials and
+// of the odometry edges incident to the pose.
+__device__ __forceinline__ double hpp_entry(const DeviceGraph& g, int a, int q) {
+    double v = 0.0;
+    if (q < 36) {
+        const int r = q / 6, c = q % 6;
+        const int u = r <= c ? upper_idx(r, c) : upper_idx(c, r);
+        for (int ch = g.pose_chunk_ptr[a]; ch < g.pose_chunk_ptr[a + 1]; ++ch) v += g.hpp_part[27 * (size_t)ch + u];
+        for (int n = g.pose_odo_ptr[a]; n < g.pose_odo_ptr[a + 1]; ++n) {
+            const int code = g.pose_odo[n];
+            v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 36 : 0) + q];
+        }
+    } else {
+        const int r = q - 36;
+        for (int ch = g.pose_chunk_ptr[a]; ch < g.pose_chunk_ptr[a + 1]; ++ch) v += g.hpp_part[27 * (size_t)ch + 21 + r];
+        for (int n = g.pose_odo_ptr[a]; n < g.pose_odo_ptr[a + 1]; ++n) {
+            const int code = g.pose_odo[n];
+            v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 114 : 108) + r];
+        }
+    }
+    return v;
+}
+
+// ================================================================= K1/K2/K4: linearise the stereo edges
 template <int G>
 __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
     const LmState* st = g.st;
-    if (st->done || !st->need_lin) return;
+    if (!(st->mode & MODE_LIN)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;                       // [Np][12]
     double* red = smem + 12 * g.Np;           // [4 * 27]
@@ -118,7 +174,10 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
             pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
             lfree = !g.pt_fixed[l];
         }
-        double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, b0 = 0, b1 = 0, b2 = 0, chi_acc = 0;
+        double hb[9];                          // Hll (xx xy xz yy yz zz) then b_l
+#pragma unroll
+        for (int q = 0; q < 9; ++q) hb[q] = 0.0;
+        double chi_acc = 0.0;
         for (int k = k0 + sub; k < k1; k += G) {
             const int ip = g.obs_pose[k];
             const Rt T = load_Rt(sRt, ip);
@@ -140,15 +199,15 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
                 double Jp[9], Jx[18];
                 stereo_jacobians(T, pc, K, Jp, Jx);
                 if (lfree) {
-                    h0 += Jp[0] * wo * Jp[0] + Jp[3] * wo * Jp[3] + Jp[6] * wo * Jp[6];
-                    h1 += Jp[0] * wo * Jp[1] + Jp[3] * wo * Jp[4] + Jp[6] * wo * Jp[7];
-                    h2 += Jp[0] * wo * Jp[2] + Jp[3] * wo * Jp[5] + Jp[6] * wo * Jp[8];
-                    h3 += Jp[1] * wo * Jp[1] + Jp[4] * wo * Jp[4] + Jp[7] * wo * Jp[7];
-                    h4 += Jp[1] * wo * Jp[2] + Jp[4] * wo * Jp[5] + Jp[7] * wo * Jp[8];
-                    h5 += Jp[2] * wo * Jp[2] + Jp[5] * wo * Jp[5] + Jp[8] * wo * Jp[8];
-                    b0 -= Jp[0] * wo * e.x + Jp[3] * wo * e.y + Jp[6] * wo * e.z;
-                    b1 -= Jp[1] * wo * e.x + Jp[4] * wo * e.y + Jp[7] * wo * e.z;
-                    b2 -= Jp[2] * wo * e.x + Jp[5] * wo * e.y + Jp[8] * wo * e.z;
+                    hb[0] += Jp[0] * wo * Jp[0] + Jp[3] * wo * Jp[3] + Jp[6] * wo * Jp[6];
+                    hb[1] += Jp[0] * wo * Jp[1] + Jp[3] * wo * Jp[4] + Jp[6] * wo * Jp[7];
+                    hb[2] += Jp[0] * wo * Jp[2] + Jp[3] * wo * Jp[5] + Jp[6] * wo * Jp[8];
+                    hb[3] += Jp[1] * wo * Jp[1] + Jp[4] * wo * Jp[4] + Jp[7] * wo * Jp[7];
+                    hb[4] += Jp[1] * wo * Jp[2] + Jp[4] * wo * Jp[5] + Jp[7] * wo * Jp[8];
+                    hb[5] += Jp[2] * wo * Jp[2] + Jp[5] * wo * Jp[5] + Jp[8] * wo * Jp[8];
+                    hb[6] -= Jp[0] * wo * e.x + Jp[3] * wo * e.y + Jp[6] * wo * e.z;
+                    hb[7] -= Jp[1] * wo * e.x + Jp[4] * wo * e.y + Jp[7] * wo * e.z;
+                    hb[8] -= Jp[2] * wo * e.x + Jp[5] * wo * e.y + Jp[8] * wo * e.z;
                 }
                 if (pfree && lfree) {
                     double Wv[18];
@@ -168,21 +227,29 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
                 for (int q = 0; q < 9; ++q) Wk[q] = make_double2(0.0, 0.0);
             }
         }
-        h0 = group_sum<G>(h0); h1 = group_sum<G>(h1); h2 = group_sum<G>(h2);
-        h3 = group_sum<G>(h3); h4 = group_sum<G>(h4); h5 = group_sum<G>(h5);
-        b0 = group_sum<G>(b0); b1 = group_sum<G>(b1); b2 = group_sum<G>(b2);
+        // 9 sums over the G lanes of the landmark; each lane ends up owning rs_slots(9,G) of them
+        int off = 0, len = 9;
+        ReduceScatter<9, G / 2>::run(hb, sub, off, len);
+        constexpr int SL = rs_slots(9, G);
         double md = 0.0;
-        if (lvalid && sub == 0) {
-            double* H = g.Hll + 6 * (size_t)l;
-            H[0] = h0; H[1] = h1; H[2] = h2; H[3] = h3; H[4] = h4; H[5] = h5;
-            double* B = g.bl + 3 * (size_t)l;
-            B[0] = b0; B[1] = b1; B[2] = b2;
-            if (lfree) md = fmax(fabs(h0), fmax(fabs(h3), fabs(h5)));
+        if (lvalid) {
+#pragma unroll
+            for (int j = 0; j < SL; ++j) {
+                const int idx = off + j;
+                if (j < len) {
+                    if (idx < 6) {
+                        g.Hll[6 * (size_t)l + idx] = hb[j];
+                        if (lfree && (idx == 0 || idx == 3 || idx == 5)) md = fmax(md, fabs(hb[j]));
+                    } else {
+                        g.bl[3 * (size_t)l + (idx - 6)] = hb[j];
+                    }
+                }
+            }
         }
         const double chi_tot = block_sum_256(chi_acc, red);
         const double md_tot = block_max_256(md, red);
         if (tid == 0) { g.lin_part[2 * bid] = chi_tot; g.lin_part[2 * bid + 1] = md_tot; }
-    } else if (bid < g.n_lin_a + g.n_chunks) {
+    } else {
         // ---- role B: pose-major chunk: upper triangle of Jx^T (rho' Omega) Jx and -Jx^T (rho' Omega) e
         const int c = bid - g.n_lin_a;
         const int a = g.chunk_pose[c];
@@ -217,86 +284,73 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
             }
         }
         const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int q = 0; q < 27; ++q) {
-            const double s = wave_sum(acc[q]);
-            if (lane == 0) red[wave * 27 + q] = s;
-        }
+        int off = 0, len = 27;
+        ReduceScatter<27, 32>::run(acc, lane, off, len);
+        if (len >= 1) red[wave * 27 + off] = acc[0];
         __syncthreads();
         if (tid < 27) g.hpp_part[27 * (size_t)c + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
-    } else {
-        // ---- role C: wheel-odometry edges (EdgePoseConstraint, Omega = I6 / odometryCovariance, no kernel)
-        const double ic = g.inv_odo_cov;
-        double chi_acc = 0.0;
-        for (int e_ = tid; e_ < g.Ne; e_ += 256) {
-            const int i = g.odo_i[e_], j = g.odo_j[e_];
-            const bool fi = g.pose_free[i] >= 0, fj = g.pose_free[j] >= 0;
-            double* o = g.odo_blk + 120 * (size_t)e_;
-            if (!fi && !fj) { for (int q = 0; q < 120; ++q) o[q] = 0.0; continue; }     // allVerticesFixed
-            double e[6], Ji[36], Jj[36];
-            odo_linearize(pose + POSE_STRIDE * i, pose + POSE_STRIDE * j, g.odo_tq + 7 * e_, e, Ji, Jj);
-            double c2 = 0.0;
-#pragma unroll
-            for (int d = 0; d < 6; ++d) c2 += e[d] * (ic * e[d]);
-            chi_acc += c2;
-            for (int r = 0; r < 6; ++r) {
-                for (int cc = 0; cc < 6; ++cc) {
-                    double aii = 0, ajj = 0, aij = 0;
-                    for (int d = 0; d < 6; ++d) {
-                        aii += Ji[d * 6 + r] * ic * Ji[d * 6 + cc];
-                        ajj += Jj[d * 6 + r] * ic * Jj[d * 6 + cc];
-                        aij += Ji[d * 6 + r] * ic * Jj[d * 6 + cc];
-                    }
-                    o[r * 6 + cc] = fi ? aii : 0.0;
-                    o[36 + r * 6 + cc] = fj ? ajj : 0.0;
-                    o[72 + r * 6 + cc] = (fi && fj) ? aij : 0.0;
-                }
-                double bi = 0, bj = 0;
-                for (int d = 0; d < 6; ++d) { bi += Ji[d * 6 + r] * ic * e[d]; bj += Jj[d * 6 + r] * ic * e[d]; }
-                o[108 + r] = fi ? -bi : 0.0;
-                o[114 + r] = fj ? -bj : 0.0;
-            }
-        }
-        const double chi_tot = block_sum_256(chi_acc, red);
-        if (tid == 0) { g.lin_part[2 * g.n_lin_a] = chi_tot; g.lin_part[2 * g.n_lin_a + 1] = 0.0; }
     }
 }
 
-// Upper-triangle index of (r,c), r <= c, in the 21-entry packing used by role B.
-__device__ __forceinline__ int upper_idx(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+// ================================================================= K3: wheel-odometry edges
+// EdgePoseConstraint, Omega = I6 / odometryCovariance (Optimizer.cpp:117-121), no robust kernel.  One workgroup.
+__global__ __launch_bounds__(256) void k_odo_linearize(const DeviceGraph g) {
+    const LmState* st = g.st;
+    if (!(st->mode & MODE_LIN)) return;
+    __shared__ double red[4];
+    const double* __restrict__ pose = g.pose[st->sel];
+    const double ic = g.inv_odo_cov;
+    const int tid = threadIdx.x;
+    double chi_acc = 0.0;
+    for (int e_ = tid; e_ < g.Ne; e_ += 256) {
+        const int i = g.odo_i[e_], j = g.odo_j[e_];
+        const bool fi = g.pose_free[i] >= 0, fj = g.pose_free[j] >= 0;
+        double* o = g.odo_blk + 120 * (size_t)e_;
+        if (!fi && !fj) { for (int q = 0; q < 120; ++q) o[q] = 0.0; continue; }     // allVerticesFixed
+        double e[6], Ji[36], Jj[36];
+        odo_linearize(pose + POSE_STRIDE * i, pose + POSE_STRIDE * j, g.odo_tq + 7 * e_, e, Ji, Jj);
+        double c2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) c2 += e[d] * (ic * e[d]);
+        chi_acc += c2;
+        for (int r = 0; r < 6; ++r) {
+            for (int cc = 0; cc < 6; ++cc) {
+                double aii = 0, ajj = 0, aij = 0;
+                for (int d = 0; d < 6; ++d) {
+                    aii += Ji[d * 6 + r] * ic * Ji[d * 6 + cc];
+                    ajj += Jj[d * 6 + r] * ic * Jj[d * 6 + cc];
+                    aij += Ji[d * 6 + r] * ic * Jj[d * 6 + cc];
+                }
+                o[r * 6 + cc] = fi ? aii : 0.0;
+                o[36 + r * 6 + cc] = fj ? ajj : 0.0;
+                o[72 + r * 6 + cc] = (fi && fj) ? aij : 0.0;
+            }
+            double bi = 0, bj = 0;
+            for (int d = 0; d < 6; ++d) { bi += Ji[d * 6 + r] * ic * e[d]; bj += Jj[d * 6 + r] * ic * e[d]; }
+            o[108 + r] = fi ? -bi : 0.0;
+            o[114 + r] = fj ? -bj : 0.0;
+        }
+    }
+    const double chi_tot = block_sum_256(chi_acc, red);
+    if (tid == 0) { g.lin_part[2 * g.n_lin_a] = chi_tot; g.lin_part[2 * g.n_lin_a + 1] = 0.0; }
+}
 
-// Single workgroup: finish K4 (sum chunk partials + odometry into Hpp/b_p), reduce chi2 and max|diag|,
-// computeLambdaInit on the first iteration of a phase ([g2o-upstream] tau = 1e-5).
-__global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g) {
+// Single workgroup, launched in the FIRST unit of a phase (and by the stage hook): sums Hpp/b_p, reduces the
+// robust chi2 and max|diag H| of the linearisation and does computeLambdaInit ([g2o-upstream] tau = 1e-5).
+// Later units take current_chi from the accepted trial and lambda from k_decide.
+__global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g, const int force) {
     LmState* st = g.st;
-    if (st->done || !st->need_lin) return;
+    if (!(st->mode & MODE_LIN)) return;
+    if (!force && st->phase_iter != 0) return;
     __shared__ double red[1024];
     const int tid = threadIdx.x;
     double md = 0.0;
     for (int t = tid; t < g.Npf * 42; t += 1024) {
         const int a = t / 42, q = t % 42;
-        double v = 0.0;
-        if (q < 36) {
-            const int r = q / 6, c = q % 6;
-            const int u = r <= c ? upper_idx(r, c) : upper_idx(c, r);
-            for (int ch = g.pose_chunk_ptr[a]; ch < g.pose_chunk_ptr[a + 1]; ++ch) v += g.hpp_part[27 * (size_t)ch + u];
-            for (int n = g.pose_odo_ptr[a]; n < g.pose_odo_ptr[a + 1]; ++n) {
-                const int code = g.pose_odo[n];
-                v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 36 : 0) + q];
-            }
-            g.Hpp[36 * (size_t)a + q] = v;
-            if (r == c) md = fmax(md, fabs(v));
-        } else {
-            const int r = q - 36;
-            for (int ch = g.pose_chunk_ptr[a]; ch < g.pose_chunk_ptr[a + 1]; ++ch) v += g.hpp_part[27 * (size_t)ch + 21 + r];
-            for (int n = g.pose_odo_ptr[a]; n < g.pose_odo_ptr[a + 1]; ++n) {
-                const int code = g.pose_odo[n];
-                v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 114 : 108) + r];
-            }
-            g.bp[6 * (size_t)a + r] = v;
-        }
+        const double v = hpp_entry(g, a, q);
+        if (q < 36) { g.Hpp[36 * (size_t)a + q] = v; if (q % 7 == 0) md = fmax(md, fabs(v)); }
+        else g.bp[6 * (size_t)a + (q - 36)] = v;
     }
-    // chi2 / max-diag partials of the workgroups of k_linearize
     double chi = 0.0;
     const int nparts = g.n_lin_a + 1;
     for (int w = tid; w < nparts; w += 1024) { chi += g.lin_part[2 * w]; md = fmax(md, g.lin_part[2 * w + 1]); }
@@ -309,12 +363,6 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g) {
     __syncthreads();
     for (int s = 512; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
     const double md_total = red[0];
-    // poses without any active edge are outside g2o's active set: pin their block (dx = 0)
-    for (int a = tid; a < g.Npf; a += 1024) {
-        bool any = false;
-        for (int r = 0; r < 6; ++r) any |= (g.Hpp[36 * (size_t)a + 7 * r] != 0.0);
-        g.pose_pin[a] = any ? 0 : 1;
-    }
     if (tid == 0) {
         st->current_chi = chi_total;
         st->max_diag = md_total;
@@ -323,201 +371,326 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g) {
             st->lambda = st->gauss_newton ? 0.0 : 1e-5 * md_total;
             st->ni = 2.0;
         }
-        st->need_lin = 0;
-        st->trial_q = 0;
-        st->n_active[0] += 1;
     }
 }
 
 // ================================================================= K5: Schur complement (gather form)
-// One wavefront per stored block (i <= j) of the reduced camera matrix:
-//   S_ij = Hpp_ij (+lambda I on the diagonal) - sum_l Hpl_il (Hll_l + lambda I)^-1 Hpl_jl^T
-//   b_s_i = b_p_i - sum_l Hpl_il (Hll_l + lambda I)^-1 b_l            (diagonal waves)
-//   Minv_i = S_ii^-1  (block-Jacobi preconditioner of LinearSolverPCG) (diagonal waves)
-__global__ __launch_bounds__(256) void k_schur(const DeviceGraph g) {
+// k_schur_partial: one wavefront per chunk of <= 64 co-observation pairs of ONE block (i <= j) of the reduced
+// camera matrix, one pair per lane:  Hpl_il (Hll_l + lambda I)^-1 Hpl_jl^T  (+ the b_s term on diagonal blocks),
+// reduce-scattered over the wave into 42 partial sums.
+__global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
     const LmState* st = g.st;
-    if (st->done || st->solve_state != 0) return;
+    if (!(st->mode & MODE_TRIAL)) return;
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= g.n_blk) return;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
+    // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
+    // instead of eight (speed only; any placement is correct).  gridDim.x is a multiple of 8.
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int ch = wg * 4 + (threadIdx.x >> 6);
+    if (ch >= g.n_sch) return;
     const double lambda = st->lambda;
-    const int i = g.blk_i[b], j = g.blk_j[b];
-    const bool diag = (i == j);
-    double acc[36], accb[6];
+    const int b = g.sch_blk[ch];
+    const bool diag = (g.blk_i[b] == g.blk_j[b]);
+    const int e = g.sch_ptr[ch] + lane;
+    const int e_end = min(g.sch_ptr[ch] + SCH_CHUNK, g.blk_ptr[b + 1]);
+    double acc[21];
+    double keep0 = 0.0, keep1 = 0.0;
+    int off0 = 0, len0 = 21, off1 = 0, len1 = 21;
+    const bool have = e < e_end;
+    // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
+    const int4 pr = have ? g.blk_pairs[e] : make_int4(0, 0, 0, 0);
+    double Y[18], Wb[18], B[3] = { 0.0, 0.0, 0.0 };
+    {
+        const double* H = g.Hll + 6 * (size_t)pr.z;
+        const double2* pa = reinterpret_cast<const double2*>(g.W + 18 * (size_t)pr.x);
+        const double2* pb = reinterpret_cast<const double2*>(g.W + 18 * (size_t)pr.y);
+        double Wa[18];
 #pragma unroll
-    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+        for (int q = 0; q < 9; ++q) { const double2 t = have ? pa[q] : make_double2(0.0, 0.0); Wa[2 * q] = t.x; Wa[2 * q + 1] = t.y; }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) accb[q] = 0.0;
-    const int e0 = g.blk_ptr[b], e1 = g.blk_ptr[b + 1];
-    for (int e = e0 + lane; e < e1; e += 64) {
-        const int2 pr = g.blk_pairs[e];
-        const int ka = pr.x, kb = pr.y;
-        if (g.obs_w[ka] == 0.0 || g.obs_w[kb] == 0.0) continue;
-        const int l = g.obs_pt[ka];
-        const double* H = g.Hll + 6 * (size_t)l;
-        const double h[6] = { H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda };
+        for (int q = 0; q < 9; ++q) { const double2 t = have ? pb[q] : make_double2(0.0, 0.0); Wb[2 * q] = t.x; Wb[2 * q + 1] = t.y; }
+        double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 };
+        if (have) {
+            h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
+            if (diag) { const double* Bl = g.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
+        }
         double D[6];
         sym3_inverse(h, D);
-        double Wa[18], Wb[18];
-        const double2* pa = reinterpret_cast<const double2*>(g.W + 18 * (size_t)ka);
-        const double2* pb = reinterpret_cast<const double2*>(g.W + 18 * (size_t)kb);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 t = pa[q]; Wa[2 * q] = t.x; Wa[2 * q + 1] = t.y; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 t = pb[q]; Wb[2 * q] = t.x; Wb[2 * q + 1] = t.y; }
-        double Y[18];
+        // a landmark without any active edge has Hll = 0 and (Gauss-Newton, lambda = 0) a singular block: its tiles are
+        // all zero, so drop the term instead of multiplying 0 by inf
+        const bool okD = (D[0] == D[0]) && (fabs(D[0]) <= DBL_MAX) && (D[3] == D[3]) && (fabs(D[3]) <= DBL_MAX) && (D[5] == D[5]) && (fabs(D[5]) <= DBL_MAX);
+        if (!okD) { D[0] = D[1] = D[2] = D[3] = D[4] = D[5] = 0.0; }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             Y[r * 3 + 0] = Wa[r * 3] * D[0] + Wa[r * 3 + 1] * D[1] + Wa[r * 3 + 2] * D[2];
             Y[r * 3 + 1] = Wa[r * 3] * D[1] + Wa[r * 3 + 1] * D[3] + Wa[r * 3 + 2] * D[4];
             Y[r * 3 + 2] = Wa[r * 3] * D[2] + Wa[r * 3 + 1] * D[4] + Wa[r * 3 + 2] * D[5];
         }
+    }
+    // two halves of 21 sums (block rows 0-2 + b_s 0-2, block rows 3-5 + b_s 3-5): halves the live accumulator registers
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int rr = 3 * half + r;
 #pragma unroll
             for (int c = 0; c < 6; ++c)
-                acc[r * 6 + c] += Y[r * 3] * Wb[c * 3] + Y[r * 3 + 1] * Wb[c * 3 + 1] + Y[r * 3 + 2] * Wb[c * 3 + 2];
-        if (diag) {
-            const double* B = g.bl + 3 * (size_t)l;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) accb[r] += Y[r * 3] * B[0] + Y[r * 3 + 1] * B[1] + Y[r * 3 + 2] * B[2];
+                acc[r * 6 + c] = Y[rr * 3] * Wb[c * 3] + Y[rr * 3 + 1] * Wb[c * 3 + 1] + Y[rr * 3 + 2] * Wb[c * 3 + 2];
+            acc[18 + r] = Y[rr * 3] * B[0] + Y[rr * 3 + 1] * B[1] + Y[rr * 3 + 2] * B[2];
         }
+        int off = 0, len = 21;
+        ReduceScatter<21, 32>::run(acc, lane, off, len);
+        if (half == 0) { keep0 = acc[0]; off0 = off; len0 = len; } else { keep1 = acc[0]; off1 = off; len1 = len; }
     }
-    // fixed-order butterfly; element t of the block lands in lane t
-    double mine = 0.0, mineb = 0.0;
-#pragma unroll
-    for (int q = 0; q < 36; ++q) { const double s = wave_sum(acc[q]); if (lane == q) mine = s; }
-    if (diag) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { const double s = wave_sum(accb[q]); if (lane == q) mineb = s; }
+    // element index inside a half: 0..17 → block entry (row 3*half + idx/6, col idx%6); 18..20 → b_s entry 3*half + (idx-18)
+    double* out = g.sch_part + 42 * (size_t)ch;
+    if (len0 >= 1) out[off0 < 18 ? off0 : 36 + (off0 - 18)] = keep0;
+    if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
+}
+
+// k_schur_finalize: one wavefront per stored block:
+//   S_ij = Hpp_ij (+lambda I on the diagonal) - sum of the chunk partials;  diagonal waves also produce
+//   b_s_i = b_p_i - ..., Hpp_ii / b_p_i (for computeScale) and Minv_i = S_ii^-1 (block-Jacobi preconditioner).
+// Poses without any active edge are outside g2o's active set: their block is pinned to I (dx = 0).
+// It also clears the hand-off words of the persistent PCG that follows (one zeroing per damped solve).
+__global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= g.n_blk) return;
+    {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
+        const int nwords = 4 * 6 * g.Npf;
+        for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
     }
+    const double lambda = st->lambda;
+    const int i = g.blk_i[b], j = g.blk_j[b];
+    const bool diag = (i == j);
     const int r = lane / 6, c = lane % 6;    // meaningful for lane < 36
+    double part = 0.0;
+    if (lane < 42) for (int ch = g.blk_chunk_ptr[b]; ch < g.blk_chunk_ptr[b + 1]; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
+    if (!diag) {
+        if (lane < 36) {
+            double base = 0.0;
+            for (int n = g.blk_odo_ptr[b]; n < g.blk_odo_ptr[b + 1]; ++n) {
+                const int code = g.blk_odo[n];
+                base += g.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
+            }
+            g.S[36 * (size_t)b + lane] = base - part;
+        }
+        return;
+    }
+    const double hv = (lane < 42) ? hpp_entry(g, i, lane) : 0.0;
+    const bool on_diag = lane < 36 && r == c;
+    const unsigned long long nz = __ballot(on_diag && hv != 0.0);
+    const bool pin = (nz == 0ull);
     double val = 0.0;
     if (lane < 36) {
-        double base = 0.0;
-        if (diag) base = g.Hpp[36 * (size_t)i + lane] + (r == c ? lambda : 0.0);
-        for (int n = g.blk_odo_ptr[b]; n < g.blk_odo_ptr[b + 1]; ++n) {
-            const int code = g.blk_odo[n];
-            base += g.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
-        }
-        val = base - mine;
-        if (diag && g.pose_pin[i]) val = (r == c) ? 1.0 : 0.0;
+        val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? lambda : 0.0) - part);
         g.S[36 * (size_t)b + lane] = val;
+        g.Hpp[36 * (size_t)i + lane] = hv;
+    } else if (lane < 42) {
+        g.bp[6 * (size_t)i + (lane - 36)] = hv;
+        g.bs[6 * (size_t)i + (lane - 36)] = pin ? 0.0 : (hv - part);
     }
-    if (diag) {
-        if (lane < 6) g.bs[6 * (size_t)i + lane] = g.pose_pin[i] ? 0.0 : (g.bp[6 * (size_t)i + lane] - mineb);
-        // 36-lane Gauss-Jordan inverse of the SPD diagonal block (no pivoting needed)
-        double a = (lane < 36) ? val : 0.0;
-        double v = (lane < 36 && r == c) ? 1.0 : 0.0;
+    // 36-lane Gauss-Jordan inverse of the SPD diagonal block (no pivoting needed)
+    double a = (lane < 36) ? val : 0.0;
+    double v = on_diag ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int rr = lane < 36 ? r : 0, cc = lane < 36 ? c : 0;
-            const double p = __shfl(a, k * 6 + k, 64);
-            const double rk_a = __shfl(a, k * 6 + cc, 64);
-            const double rk_v = __shfl(v, k * 6 + cc, 64);
-            const double ck = __shfl(a, rr * 6 + k, 64);
-            const double ip = 1.0 / p;
-            if (rr == k) { a = rk_a * ip; v = rk_v * ip; }
-            else { a -= ck * (rk_a * ip); v -= ck * (rk_v * ip); }
-        }
-        if (lane < 36) g.Minv[36 * (size_t)i + lane] = v;
+    for (int k = 0; k < 6; ++k) {
+        const int rr = lane < 36 ? r : 0, cc = lane < 36 ? c : 0;
+        const double p = __shfl(a, k * 6 + k, 64);
+        const double rk_a = __shfl(a, k * 6 + cc, 64);
+        const double rk_v = __shfl(v, k * 6 + cc, 64);
+        const double ck = __shfl(a, rr * 6 + k, 64);
+        const double ip = 1.0 / p;
+        if (rr == k) { a = rk_a * ip; v = rk_v * ip; }
+        else { a -= ck * (rk_a * ip); v -= ck * (rk_v * ip); }
+    }
+    if (lane < 36) g.Minv[36 * (size_t)i + lane] = v;
+    if (b == 0 && lane == 0) {
+        st->pcg_res_in = st->pcg_residual;
+        st->n_active[1] += 1;
+        if (st->mode & MODE_LIN) st->n_active[0] += 1;
     }
 }
 
-// ================================================================= K6: block-Jacobi PCG on S
-// [g2o-upstream] LinearSolverPCG::solve: x0 = 0, tolerance 1e-6 on r^T M^-1 r, maxIter = rows,
-// absolute tolerance carried in _residual between the solves of one optimize() call.
+// ================================================================= K6: block-Jacobi PCG on S, persistent
+// [g2o-upstream] LinearSolverPCG::solve: x0 = 0, tolerance 1e-6 on r^T M^-1 r, maxIter = rows, absolute
+// tolerance carried in _residual between the solves of one optimize() call.
 //
-// k_pcg_init (one workgroup) starts a solve; k_pcg_iter (one wave per block row of S) performs, per
-// launch, the vector half of iteration t-1 — redundantly and bitwise identically in every workgroup,
-// from the q slices all rows wrote in the previous launch — then its own row of q = S d for iteration t.
-// Control words and vectors are double-buffered on a host-supplied launch parity `hp`, so no launch
-// ever reads a word that the same launch writes.
-__global__ __launch_bounds__(256) void k_pcg_init(const DeviceGraph g, const int hp_write) {
-    LmState* st = g.st;
-    if (st->done || st->solve_state != 0) return;
-    __shared__ double red[4];
-    const int n6 = 6 * g.Npf, tid = threadIdx.x;
-    double* r = g.pcg_r[hp_write];
-    double* d = g.pcg_d[hp_write];
-    double dn = 0.0;
-    for (int t = tid; t < n6; t += 256) {
-        const int a = t / 6, rr = t % 6;
-        const double* M = g.Minv + 36 * (size_t)a + 6 * rr;
-        const double* bb = g.bs + 6 * (size_t)a;
-        const double dv = M[0] * bb[0] + M[1] * bb[1] + M[2] * bb[2] + M[3] * bb[3] + M[4] * bb[4] + M[5] * bb[5];
-        r[t] = bb[rr];
-        d[t] = dv;
-        g.x[t] = 0.0;
-        dn += bb[rr] * dv;
-    }
-    dn = block_sum_256(dn, red);
-    if (tid == 0) {
-        double d0 = 1e-6 * dn;
-        if (st->pcg_residual > 0.0 && st->pcg_residual > d0) d0 = st->pcg_residual;
-        st->pcg_d0 = d0;
-        PcgCtl* c = g.pcg_ctl + hp_write;
-        c->go = 1; c->has_q = 0; c->iter = 0; c->dn = dn;
-        st->solve_state = 1;
-    }
+// One launch per damped solve; one workgroup (4 waves) per block row of S.  Every workgroup keeps the
+// full vectors r, d, q, s in LDS and performs the (tiny) vector recurrences redundantly and bitwise identically,
+// so all workgroups take the same branch at every convergence test.  Only q = S d is distributed: row i computes
+// its six entries and publishes them as twelve 8-byte granules {epoch:32 | half of the double:32} with one
+// write-through store each; every workgroup then sweeps all granules of the iteration until their tags match
+// (cdna_hip_programming.md §6 Guideline 16, form R2: the data is the flag — no fence, no separate flag word).
+// Granules are double-buffered on the iteration parity and zeroed by k_schur_finalize before every solve.
+// Residency: grid = Npf <= 341 workgroups of 4 waves with <= 64 KiB of LDS each (>= 2 per CU) — always co-resident.
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(64) void k_pcg_iter(const DeviceGraph g, const int hp) {
-    const PcgCtl ctl = g.pcg_ctl[hp];
-    PcgCtl* nxt = g.pcg_ctl + (hp ^ 1);
-    const int lane = threadIdx.x, i = blockIdx.x;
-    if (!ctl.go) { if (i == 0 && lane == 0) nxt->go = 0; return; }
-    if (i == 0 && lane == 0) g.st->n_active[2] += 1;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int n6 = 6 * g.Npf;
-    double* sd = smem;                 // d (new)
-    const double* r_old = g.pcg_r[hp];
-    const double* d_old = g.pcg_d[hp];
-    const double* q_old = g.pcg_q[hp];
-    double dn = ctl.dn;
-    int iter = ctl.iter;
+__global__ __launch_bounds__(256) void k_pcg(const DeviceGraph g) {
     LmState* st = g.st;
-    double xown = (lane < 6) ? g.x[6 * i + lane] : 0.0;
-    if (ctl.has_q) {
-        // vector half of the previous iteration (identical in every workgroup)
-        double dq = 0.0;
-        for (int t = lane; t < n6; t += 64) dq += d_old[t] * q_old[t];
-        dq = wave_sum(dq);
-        const double alpha = dn / dq;
-        double* sr = smem + n6;        // r (new)
-        double* ss = smem + 2 * n6;    // s = Minv r
-        for (int t = lane; t < n6; t += 64) sr[t] = r_old[t] - alpha * q_old[t];
-        __syncthreads();
-        double dnn = 0.0;
+    if (!(st->mode & MODE_TRIAL)) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
+    const int n6 = 6 * g.Npf;
+    double* sr = smem;
+    double* sd = smem + n6;
+    double* sq = smem + 2 * n6;
+    double* ss = smem + 3 * n6;
+    double* sP = smem + 4 * n6;                                       // [4][8] per-wave partial rows of q_i, then scalars
+    double* sM = sP + 40;                                             // [Npf][36] when pcg_lds_minv
+    double* sS = sM + (g.pcg_lds_minv ? 36 * g.Npf : 0);              // [row blocks][36] when pcg_lds_srow
+    const double* Minv = g.pcg_lds_minv ? sM : g.Minv;
+    const int rb = g.row_ptr[i], nb = g.row_ptr[i + 1] - rb;
+    int* sCol = reinterpret_cast<int*>(sS + (g.pcg_lds_srow ? 36 * g.pcg_max_row : 0));   // [nb] column block of each entry
+    int* sCode = sCol + g.pcg_max_row;                                                      // [nb] stored block * 2 + transposed
+    for (int n = tid; n < nb; n += 256) { sCol[n] = g.row_col[rb + n]; sCode[n] = g.row_blk[rb + n]; }
+    if (g.pcg_lds_minv) {
+#pragma unroll 4
+        for (int t = tid; t < 36 * g.Npf; t += 256) sM[t] = g.Minv[t];
+    }
+    for (int t = tid; t < n6; t += 256) sr[t] = g.bs[t];
+    if (tid == 0) sP[34] = 0.0;                                        // hand-off timeout flag of the workgroup
+    __syncthreads();
+    if (g.pcg_lds_srow) {
+        // own block row; transposed blocks are stored transposed so that the mat-vec reads every block row-major.
+        // The block codes come from LDS, so the S loads do not wait on other global loads.
+#pragma unroll 4
+        for (int t = tid; t < 36 * nb; t += 256) {
+            const int n = t / 36, q = t - 36 * n, code = sCode[n];
+            const double* Sb = g.S + 36 * (size_t)(code >> 1);
+            sS[t] = (code & 1) ? Sb[(q % 6) * 6 + q / 6] : Sb[q];
+        }
+    }
+    // r = b ; d = M^-1 r ; dn = r.d   (wave 0; fixed order)
+    double dn = 0.0, d0 = 0.0;
+    if (wave == 0) {
         for (int t = lane; t < n6; t += 64) {
             const int a = t / 6, rr = t % 6;
-            const double* M = g.Minv + 36 * (size_t)a + 6 * rr;
-            const double* rb = sr + 6 * a;
-            const double sv = M[0] * rb[0] + M[1] * rb[1] + M[2] * rb[2] + M[3] * rb[3] + M[4] * rb[4] + M[5] * rb[5];
-            ss[t] = sv;
-            dnn += sr[t] * sv;
+            const double* M = Minv + 36 * a + 6 * rr;
+            const double* rbk = sr + 6 * a;
+            const double dv = M[0] * rbk[0] + M[1] * rbk[1] + M[2] * rbk[2] + M[3] * rbk[3] + M[4] * rbk[4] + M[5] * rbk[5];
+            sd[t] = dv;
+            dn += sr[t] * dv;
         }
-        dnn = wave_sum(dnn);
-        const double beta = dnn / dn;
-        for (int t = lane; t < n6; t += 64) sd[t] = ss[t] + beta * d_old[t];
-        __syncthreads();
-        // own slices: x += alpha d, r, d
-        if (lane < 6) {
-            const int t = 6 * i + lane;
-            xown += alpha * d_old[t];
-            g.x[t] = xown;
-            g.pcg_r[hp ^ 1][t] = sr[t];
-            g.pcg_d[hp ^ 1][t] = sd[t];
-        }
-        dn = dnn;
-        iter += 1;
-    } else {
-        for (int t = lane; t < n6; t += 64) sd[t] = d_old[t];
-        if (lane < 6) { const int t = 6 * i + lane; g.pcg_r[hp ^ 1][t] = r_old[t]; g.pcg_d[hp ^ 1][t] = d_old[t]; }
+        dn = wave_sum(dn);
+        d0 = 1e-6 * dn;
+        const double res_in = st->pcg_res_in;
+        if (res_in > 0.0 && res_in > d0) d0 = res_in;
+        if (lane == 0) { sP[32] = dn; sP[33] = d0; }
     }
     __syncthreads();
-    if (dn <= st->pcg_d0 || iter >= n6 || !(dn == dn)) {
-        // converged (or maxIter / NaN): x is final. K8 for this row's pose; row 0 publishes the verdict.
+    dn = sP[32]; d0 = sP[33];
+    double xown = 0.0;                                                // wave 0, lanes 0..5: x of this block row
+    int iter = 0;
+    bool timeout = false;
+    while (true) {
+        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
+        // ---- own block row of q = S d: 32 slots (8 per wave) x 8 lanes (6 rows used)
+        const int slot = tid >> 3, rr = tid & 7;
+        double acc = 0.0;
+        if (rr < 6) {
+            for (int n = slot; n < nb; n += 32) {
+                const double* dj = sd + 6 * sCol[n];
+                if (g.pcg_lds_srow) {
+                    const double* Sr = sS + 36 * n + 6 * rr;
+                    acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5];
+                } else {
+                    const int code = sCode[n];
+                    const double* Sb = g.S + 36 * (size_t)(code >> 1);
+                    if (code & 1) acc += Sb[rr] * dj[0] + Sb[6 + rr] * dj[1] + Sb[12 + rr] * dj[2] + Sb[18 + rr] * dj[3] + Sb[24 + rr] * dj[4] + Sb[30 + rr] * dj[5];
+                    else { const double* Sr = Sb + 6 * rr; acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5]; }
+                }
+            }
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < 8) sP[wave * 8 + lane] = acc;
+        __syncthreads();
+        // ---- publish: thread 2r + h carries half h of q_i[r] (sum of the four waves' partials, fixed order)
+        const unsigned epoch = (unsigned)iter + 1u;
+        unsigned long long* gr = g.granules + (size_t)(iter & 1) * (2 * n6);
+        if (tid < 12) {
+            const int r6 = tid >> 1;
+            const double qv = ((sP[r6] + sP[8 + r6]) + sP[16 + r6]) + sP[24 + r6];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(qv);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
+            st_granule(gr + 2 * (6 * i) + tid, ((unsigned long long)epoch << 32) | half);
+        }
+        // ---- gather every row's q: every pass re-reads ALL granules of the chunk (loads in flight together), until
+        //      every tag matches (Guideline 16, sweep_granules) — one L2 round trip per pass, not per element
+        constexpr int SW = 4;
+        for (int base = 0; base < n6 && !timeout; base += 256 * SW) {
+            unsigned long long lo[SW], hi[SW];
+            unsigned spins = 0;
+            while (true) {
+#pragma unroll
+                for (int jj = 0; jj < SW; ++jj) {
+                    const int t = base + jj * 256 + tid;
+                    if (t < n6) { lo[jj] = ld_granule(gr + 2 * t); hi[jj] = ld_granule(gr + 2 * t + 1); }
+                }
+                bool ok = true;
+#pragma unroll
+                for (int jj = 0; jj < SW; ++jj) {
+                    const int t = base + jj * 256 + tid;
+                    if (t < n6) ok = ok && ((unsigned)(lo[jj] >> 32) == epoch) && ((unsigned)(hi[jj] >> 32) == epoch);
+                }
+                if (__all(ok)) break;                                  // per wave; the workgroup meets at the barrier below
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) { timeout = true; break; }
+            }
+            if (!timeout) {
+#pragma unroll
+                for (int jj = 0; jj < SW; ++jj) {
+                    const int t = base + jj * 256 + tid;
+                    if (t < n6) sq[t] = __longlong_as_double((long long)((hi[jj] << 32) | (lo[jj] & 0xffffffffull)));
+                }
+            }
+        }
+        if (timeout) sP[34] = 1.0;
+        __syncthreads();
+        // ---- vector recurrences on wave 0 (identical in every workgroup: same data, same order)
+        if (wave == 0) {
+            double dq = 0.0;
+            for (int t = lane; t < n6; t += 64) dq += sd[t] * sq[t];
+            dq = wave_sum(dq);
+            const double alpha = dn / dq;
+            if (lane < 6) xown += alpha * sd[6 * i + lane];
+            for (int t = lane; t < n6; t += 64) sr[t] -= alpha * sq[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            double dnn = 0.0;
+            for (int t = lane; t < n6; t += 64) {
+                const int a = t / 6, rr2 = t % 6;
+                const double* M = Minv + 36 * a + 6 * rr2;
+                const double* rbk = sr + 6 * a;
+                const double sv = M[0] * rbk[0] + M[1] * rbk[1] + M[2] * rbk[2] + M[3] * rbk[3] + M[4] * rbk[4] + M[5] * rbk[5];
+                ss[t] = sv;
+                dnn += sr[t] * sv;
+            }
+            dnn = wave_sum(dnn);
+            const double beta = dnn / dn;
+            for (int t = lane; t < n6; t += 64) sd[t] = ss[t] + beta * sd[t];
+            if (lane == 0) sP[32] = dnn;
+        }
+        __syncthreads();
+        if (sP[34] != 0.0) { timeout = true; break; }
+        dn = sP[32];
+        iter += 1;
+    }
+    if (timeout) { if (tid == 0) st->pcg_timeout = 1; return; }
+    // x is final: K8 (oplus) for this row's pose; row 0 publishes the solver statistics
+    if (wave == 0) {
+        if (lane < 6) g.x[6 * i + lane] = xown;
         double dx[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) dx[q] = __shfl(xown, q, 64);
@@ -525,40 +698,20 @@ __global__ __launch_bounds__(64) void k_pcg_iter(const DeviceGraph g, const int 
             const int ip = g.free_pose[i];
             const int sel = st->sel;
             pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
-        }
-        if (i == 0 && lane == 0) {
-            nxt->go = 0;
-            st->pcg_residual = 0.5 * dn;
-            st->pcg_iter = iter;
-            st->pcg_total += iter;
-            if (iter > st->pcg_max) st->pcg_max = iter;
-            st->solve_state = 2;
-        }
-        return;
-    }
-    // own block row of q = S d: 8 slots x 8 lanes (6 rows used)
-    const int slot = lane >> 3, rr = lane & 7;
-    double acc = 0.0;
-    if (rr < 6) {
-        for (int n = g.row_ptr[i] + slot; n < g.row_ptr[i + 1]; n += 8) {
-            const int j = g.row_col[n], code = g.row_blk[n];
-            const double* Sb = g.S + 36 * (size_t)(code >> 1);
-            const double* dj = sd + 6 * j;
-            if (code & 1) acc += Sb[rr] * dj[0] + Sb[6 + rr] * dj[1] + Sb[12 + rr] * dj[2] + Sb[18 + rr] * dj[3] + Sb[24 + rr] * dj[4] + Sb[30 + rr] * dj[5];
-            else { const double* Sr = Sb + 6 * rr; acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5]; }
+            if (i == 0) {
+                st->pcg_residual = 0.5 * dn;
+                st->pcg_iter = iter;
+                st->pcg_total += iter;
+                if (iter > st->pcg_max) st->pcg_max = iter;
+            }
         }
     }
-    acc += __shfl_xor(acc, 8, 64);
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
-    if (lane < 6) g.pcg_q[hp ^ 1][6 * i + lane] = acc;
-    if (i == 0 && lane == 0) { nxt->go = 1; nxt->has_q = 1; nxt->iter = iter; nxt->dn = dn; }
 }
 
 // ---- direct solver (Optimizer/Solver 0,1,3: sparse Cholesky in the reference) ----
 __global__ __launch_bounds__(256) void k_dense_assemble(const DeviceGraph g) {
     const LmState* st = g.st;
-    if (st->done || st->solve_state != 0) return;
+    if (!(st->mode & MODE_TRIAL)) return;
     const int n6 = 6 * g.Npf;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < g.n_blk * 36; t += gridDim.x * 256) {
         const int b = t / 36, q = t % 36, r = q / 6, c = q % 6;
@@ -573,7 +726,7 @@ __global__ __launch_bounds__(256) void k_dense_assemble(const DeviceGraph g) {
 // factor fills in), forward/back substitution, K8 pose update.
 __global__ __launch_bounds__(1024) void k_cholesky(const DeviceGraph g) {
     LmState* st = g.st;
-    if (st->done || st->solve_state != 0) return;
+    if (!(st->mode & MODE_TRIAL)) return;
     const int n = 6 * g.Npf, tid = threadIdx.x;
     double* A = g.dense;
     __shared__ double s_piv;
@@ -589,11 +742,9 @@ __global__ __launch_bounds__(1024) void k_cholesky(const DeviceGraph g) {
         __syncthreads();
         if (s_fail) break;
         const double piv = s_piv;
-        // scale column k (stored in row k of the lower triangle: A[i][k], i > k)
         for (int i2 = k + 1 + tid; i2 < n; i2 += 1024) A[(size_t)i2 * n + k] /= piv;
         if (tid == 0) A[(size_t)k * n + k] = piv;
         __syncthreads();
-        // trailing update of the lower triangle
         const int m = n - k - 1;
         for (int t = tid; t < m * m; t += 1024) {
             const int ii = k + 1 + t / m, jj = k + 1 + t % m;
@@ -601,8 +752,7 @@ __global__ __launch_bounds__(1024) void k_cholesky(const DeviceGraph g) {
         }
         __syncthreads();
     }
-    if (s_fail) { if (tid == 0) st->solve_state = 3; return; }
-    // L y = b ; L^T x = y  (serial over rows, parallel dot products)
+    if (s_fail) { if (tid == 0) st->solver_failed = 1; return; }
     __shared__ double red[1024];
     double* x = g.x;
     for (int i2 = 0; i2 < n; ++i2) {
@@ -630,14 +780,13 @@ __global__ __launch_bounds__(1024) void k_cholesky(const DeviceGraph g) {
         for (int q = 0; q < 6; ++q) dx[q] = x[6 * a + q];
         pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
     }
-    if (tid == 0) st->solve_state = 2;
 }
 
 // ================================================================= K7/K8 + chi2 at the trial state
 template <int G>
 __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
     const LmState* st = g.st;
-    if (st->done || st->solve_state != 2) return;
+    if (!(st->mode & MODE_TRIAL) || st->solver_failed || st->pcg_timeout) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;
     double* red = smem + 12 * g.Np;
@@ -650,7 +799,7 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
     const int bid = blockIdx.x, tid = threadIdx.x;
     if (bid == g.n_lin_a) {
-        // odometry chi2 at the trial state + the pose part of computeScale is done in k_decide
+        // odometry chi2 at the trial state (the pose part of computeScale is done in k_decide)
         const double ic = g.inv_odo_cov;
         double chi_acc = 0.0;
         for (int e_ = tid; e_ < g.Ne; e_ += 256) {
@@ -732,13 +881,13 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
 }
 
 // ================================================================= K9: Levenberg-Marquardt control
-// [g2o-upstream] OptimizationAlgorithmLevenberg::solve, second half; one workgroup.
+// [g2o-upstream] OptimizationAlgorithmLevenberg::solve, second half; one workgroup.  Sets the gate of the next unit.
 __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
     LmState* st = g.st;
-    if (st->done || st->solve_state < 2) return;
+    if (!(st->mode & MODE_TRIAL)) return;
     __shared__ double red[4];
     const int tid = threadIdx.x;
-    const bool ok = st->solve_state == 2;
+    const bool ok = !st->solver_failed && !st->pcg_timeout;
     const double lambda = st->lambda;
     double chi = 0.0, sc = 0.0;
     if (ok) {
@@ -750,16 +899,16 @@ __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
     if (tid != 0) return;
     const int ph = st->phase;
     st->trials_run[ph] += 1;
-    st->solve_state = 0;
-    st->n_active[1] += 1;
+    st->solver_failed = 0;
     if (ok) st->n_active[3] += 1;
+    if (st->pcg_timeout) { st->status = 8; st->done = 1; st->mode = 0; return; }     // VISFS_BA_ERR_DEVICE
     if (st->gauss_newton) {
         // OptimizationAlgorithmGaussNewton: always take the step; Fail ends the phase
         if (ok) st->sel ^= 1;
         if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = 0.0; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
+        if (ok) st->current_chi = chi;
         st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
-        st->need_lin = 1;
-        if (!ok || st->phase_iter >= st->max_iter) st->done = 1;
+        if (!ok || st->phase_iter >= st->max_iter) { st->done = 1; st->mode = 0; } else st->mode = MODE_LIN | MODE_TRIAL;
         return;
     }
     const double tempChi = ok ? chi : DBL_MAX;
@@ -791,8 +940,11 @@ __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
         if (st->trial_q == 10 || rho == 0.0) terminate = true;
         if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = st->lambda; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
         st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
-        st->need_lin = 1;
-        if (terminate || st->phase_iter >= st->max_iter) st->done = 1;
+        st->trial_q = 0;
+        if (terminate || st->phase_iter >= st->max_iter) { st->done = 1; st->mode = 0; }
+        else st->mode = MODE_LIN | MODE_TRIAL;      // next unit linearises at the (possibly unchanged) estimate
+    } else {
+        st->mode = MODE_TRIAL;                      // same linearisation, larger lambda
     }
 }
 
@@ -867,8 +1019,9 @@ __global__ __launch_bounds__(256) void k_phase_end(const DeviceGraph g, const in
         st->n_outliers = (int)nout;
         // arm phase 2: initializeOptimization(0) + optimize(iterations/2) re-initialise lambda and the PCG residual
         st->phase = 1; st->phase_iter = 0; st->max_iter = next_max_iter; st->trial_q = 0;
-        st->need_lin = 1; st->solve_state = 0; st->pcg_residual = -1.0;
+        st->solver_failed = 0; st->pcg_residual = -1.0;
         st->done = (st->status != 0 || next_max_iter <= 0 || g.huber_delta <= 0.0) ? 1 : 0;
+        st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL);
     } else {
         st->chi2_final = chi;
         if (chi > 1000000000000.0) st->status = 5;                       // VISFS_BA_ERR_HUGE_CHI2_2
@@ -887,25 +1040,24 @@ __global__ __launch_bounds__(256) void k_reset(const DeviceGraph g, const int ma
     if (gid == 0) {
         LmState* st = g.st;
         st->lambda = 0.0; st->ni = 2.0; st->current_chi = 0.0; st->temp_chi = 0.0; st->rho = 0.0; st->scale = 0.0; st->max_diag = 0.0;
-        st->pcg_dn = 0.0; st->pcg_d0 = 0.0; st->pcg_residual = -1.0;
+        st->pcg_res_in = -1.0; st->pcg_residual = -1.0;
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
         if (restore) st->sel = 0;
-        st->pcg_max = 0; st->pad_ = 0;
+        st->pcg_max = 0; st->pcg_timeout = 0;
         st->n_active[0] = st->n_active[1] = st->n_active[2] = st->n_active[3] = 0;
         st->phase = 0; st->max_iter = max_iter; st->phase_iter = 0; st->trial_q = 0;
-        st->need_lin = 1; st->done = (max_iter <= 0) ? 1 : 0; st->solve_state = 0;
+        st->done = (max_iter <= 0) ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->solver_failed = 0;
         st->pcg_iter = 0; st->pcg_total = 0; st->gauss_newton = gauss_newton; st->status = 0;
         st->n_outliers = 0; st->n_trace = 0;
         st->iterations_run[0] = st->iterations_run[1] = 0; st->trials_run[0] = st->trials_run[1] = 0;
-        g.pcg_ctl[0].go = 0; g.pcg_ctl[1].go = 0;
     }
 }
 
-// Test hook: force the LM gates for a single stage call (visfs_ba_stage_*).
-__global__ void k_stage_arm(const DeviceGraph g, const double lambda, const int need_lin) {
+// Test hook: force the gates for a single stage call (visfs_ba_stage_*).
+__global__ void k_stage_arm(const DeviceGraph g, const double lambda, const int mode) {
     LmState* st = g.st;
-    st->done = 0; st->need_lin = need_lin; st->solve_state = 0; st->lambda = lambda; st->phase_iter = 1;
-    st->max_iter = 1 << 30; st->trial_q = 0;
+    st->done = 0; st->mode = mode; st->solver_failed = 0; st->lambda = lambda; st->phase_iter = 1;
+    st->max_iter = 1 << 30; st->trial_q = 0; st->gauss_newton = 0;
 }
 
 // ================================================================= launchers
@@ -913,8 +1065,7 @@ static inline size_t lds_poses(const DeviceGraph& g, int extra) { return (size_t
 
 template <int G>
 static void launch_lin_t(const DeviceGraph& g, hipStream_t s) {
-    const int grid = g.n_lin_a + g.n_chunks + 1;
-    hipLaunchKernelGGL(k_linearize<G>, dim3(grid), dim3(256), lds_poses(g, 4 * 27), s, g);
+    hipLaunchKernelGGL(k_linearize<G>, dim3(g.n_lin_a + g.n_chunks), dim3(256), lds_poses(g, 4 * 27), s, g);
 }
 template <int G>
 static void launch_backsub_t(const DeviceGraph& g, hipStream_t s) {
@@ -929,22 +1080,23 @@ void launch_linearize(const DeviceGraph& g, hipStream_t s) {
         case 32: launch_lin_t<32>(g, s); break;
         default: launch_lin_t<64>(g, s); break;
     }
+    if (g.Ne > 0) hipLaunchKernelGGL(k_odo_linearize, dim3(1), dim3(256), 0, s, g);     // lin_part[n_lin_a] stays 0 otherwise
 }
 
-void launch_lin_finalize(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(1024), 0, s, g);
+void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) {
+    hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(1024), 0, s, g, force);
 }
 
-void launch_schur(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_schur, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
+void launch_schur_partial(const DeviceGraph& g, hipStream_t s) {
+    if (g.n_sch > 0) hipLaunchKernelGGL(k_schur_partial, dim3((((g.n_sch + 3) / 4) + 7) / 8 * 8), dim3(256), 0, s, g);
 }
 
-void launch_pcg_init(const DeviceGraph& g, int hp_write, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(256), 0, s, g, hp_write);
+void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) {
+    hipLaunchKernelGGL(k_schur_finalize, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
 }
 
-void launch_pcg_iter(const DeviceGraph& g, int hp, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_iter, dim3(g.Npf), dim3(64), (size_t)(3 * 6 * g.Npf) * sizeof(double), s, g, hp);
+void launch_pcg(const DeviceGraph& g, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg, dim3(g.Npf), dim3(256), (size_t)g.pcg_lds_bytes, s, g);
 }
 
 void launch_direct(const DeviceGraph& g, hipStream_t s) {
@@ -982,15 +1134,14 @@ void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int rest
     hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, s, g, max_iter, gauss_newton, restore);
 }
 
-void launch_stage_arm(const DeviceGraph& g, double lambda, int need_lin, hipStream_t s) {
-    hipLaunchKernelGGL(k_stage_arm, dim3(1), dim3(1), 0, s, g, lambda, need_lin);
+void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_stage_arm, dim3(1), dim3(1), 0, s, g, lambda, mode);
 }
 
 int configure_kernels(const DeviceGraph& g) {
-    // dynamic LDS above 64 KiB needs an explicit opt-in
-    const size_t need = (size_t)(3 * 6 * g.Npf) * sizeof(double);
-    if (need > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_iter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return -1;
+    // dynamic LDS above 64 KiB needs an explicit opt-in (never the case with the limits in ba_device.hpp, kept for safety)
+    if (g.pcg_lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg), hipFuncAttributeMaxDynamicSharedMemorySize, g.pcg_lds_bytes) != hipSuccess) return -1;
     }
     return 0;
 }

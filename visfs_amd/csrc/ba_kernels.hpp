@@ -10,15 +10,15 @@ namespace visfs_ba {
 
 int configure_kernels(const DeviceGraph& g);
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s);
-void launch_linearize(const DeviceGraph& g, hipStream_t s);
-void launch_lin_finalize(const DeviceGraph& g, hipStream_t s);
-void launch_schur(const DeviceGraph& g, hipStream_t s);
-void launch_pcg_init(const DeviceGraph& g, int hp_write, hipStream_t s);
-void launch_pcg_iter(const DeviceGraph& g, int hp, hipStream_t s);
+void launch_linearize(const DeviceGraph& g, hipStream_t s);          // k_linearize (+ k_odo_linearize when the window has odometry edges)
+void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s);
+void launch_schur_partial(const DeviceGraph& g, hipStream_t s);
+void launch_schur_finalize(const DeviceGraph& g, hipStream_t s);
+void launch_pcg(const DeviceGraph& g, hipStream_t s);                // persistent block-Jacobi PCG, one launch per damped solve
 void launch_direct(const DeviceGraph& g, hipStream_t s);             // dense assemble + Cholesky
 void launch_backsub(const DeviceGraph& g, hipStream_t s);
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
-void launch_stage_arm(const DeviceGraph& g, double lambda, int need_lin, hipStream_t s);
+void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
 
 }  // namespace visfs_ba
