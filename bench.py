@@ -130,7 +130,7 @@ def main():
         byts = algorithmic_bytes(dom, d)
         achieved = byts / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": None,
+                    "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(args.config, dom),
                     "bytes_per_launch": byts, "avg_launch_us": round(avg_s * 1e6, 3), "launches": p["active_launches"]}
     out = {
         "metric": "BA iterations/sec (50 KF, 5k pts, 50k obs) @1 GPU; max-pose-err vs g2o",
@@ -152,6 +152,21 @@ def main():
         # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
         out["max_pose_err_vs_oracle"] = parity_vs_oracle(args, prm, solvers[0])
     print(json.dumps(out))
+
+
+def pmc_traffic(config, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this bench, gfx950 correction 2*FETCH applied — see the
+    file's _method).  None when no counters were collected for this config / kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return round(d[config][kernel]["traffic_bytes"])
+    except (KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(args, prm):
