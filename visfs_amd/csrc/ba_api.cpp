@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -271,6 +272,17 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     }
     blk_chunk_ptr[n_blk] = (int32_t)sch_blk.size();
     const int n_sch = (int)sch_blk.size();
+    std::vector<int4> sch_desc(std::max(n_sch, 1)), blk_desc(2 * (size_t)std::max(n_blk, 1));
+    for (int c = 0; c < n_sch; ++c) {
+        const int b = sch_blk[c];
+        sch_desc[c] = make_int4(sch_ptr[c], std::min(sch_ptr[c] + SCH_CHUNK, blk_ptr[b + 1]), free_pose[blk_i[b]], free_pose[blk_j[b]]);
+    }
+    for (int b = 0; b < n_blk; ++b) {
+        const int a = blk_i[b];
+        const bool dg = (a == blk_j[b]);
+        blk_desc[2 * b] = make_int4(blk_chunk_ptr[b], blk_chunk_ptr[b + 1], dg ? pose_odo_ptr[a] : blk_odo_ptr[b], dg ? pose_odo_ptr[a + 1] : blk_odo_ptr[b + 1]);
+        blk_desc[2 * b + 1] = make_int4(a, blk_j[b], pose_chunk_ptr[a], pose_chunk_ptr[a + 1]);
+    }
     // persistent PCG: LDS plan (4 vectors always; all Minv blocks and the own block row of S when they fit in 60 KiB)
     if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 341 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
     int max_row = 0;
@@ -317,8 +329,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.blk_ptr = A.take<int32_t>(n_blk + 1);
         g.blk_pairs = A.take<int4>(pairs.size());
         g.blk_chunk_ptr = A.take<int32_t>(n_blk + 1);
-        g.sch_blk = A.take<int32_t>(std::max(n_sch, 1));
-        g.sch_ptr = A.take<int32_t>(std::max(n_sch, 1));
+        g.sch_desc = A.take<int4>(std::max(n_sch, 1));
+        g.blk_desc = A.take<int4>(2 * (size_t)std::max(n_blk, 1));
         g.blk_odo_ptr = A.take<int32_t>(n_blk + 1);
         g.blk_odo = A.take<int32_t>(std::max<size_t>(blk_odo.size(), 1));
         g.row_ptr = A.take<int32_t>(Npf + 1);
@@ -341,6 +353,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);
         g.obs_chi2 = A.take<double>(std::max(No, 1));
         g.obs_w = A.take<double>(std::max(No, 1));
+        g.obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
         g.W = A.take<double>((size_t)std::max(No, 1) * 18);
         g.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
         g.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
@@ -408,7 +421,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         std::memcpy(const_cast<int32_t*>(hg.blk_ptr), blk_ptr.data(), (size_t)(n_blk + 1) * 4);
         std::memcpy(const_cast<int4*>(hg.blk_pairs), pairs.data(), pairs.size() * sizeof(int4));
         std::memcpy(const_cast<int32_t*>(hg.blk_chunk_ptr), blk_chunk_ptr.data(), (size_t)(n_blk + 1) * 4);
-        if (n_sch) { std::memcpy(const_cast<int32_t*>(hg.sch_blk), sch_blk.data(), (size_t)n_sch * 4); std::memcpy(const_cast<int32_t*>(hg.sch_ptr), sch_ptr.data(), (size_t)n_sch * 4); }
+        std::memcpy(const_cast<int4*>(hg.sch_desc), sch_desc.data(), sch_desc.size() * sizeof(int4));
+        std::memcpy(const_cast<int4*>(hg.blk_desc), blk_desc.data(), blk_desc.size() * sizeof(int4));
         std::memcpy(const_cast<int32_t*>(hg.blk_odo_ptr), blk_odo_ptr.data(), (size_t)(n_blk + 1) * 4);
         if (!blk_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.blk_odo), blk_odo.data(), blk_odo.size() * 4);
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);

@@ -93,8 +93,9 @@ struct DeviceGraph {
     const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
     const int4* blk_pairs;      // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block
-    const int32_t* sch_blk;     // [n_sch] block of the chunk
-    const int32_t* sch_ptr;     // [n_sch] first pair of the chunk (it ends at min(+64, end of block))
+    const int4* sch_desc;       // [n_sch] (first pair, last pair + 1, pose index of i, pose index of j): ONE load gives a wave all it needs
+    const int4* blk_desc;       // [n_blk][2]: (first Schur chunk, last + 1, first odometry entry, last + 1) — entries of blk_odo for an
+                                //   off-diagonal block, of pose_odo for a diagonal one — and (i, j, first pose-major chunk of i, last + 1)
     const int32_t* blk_odo_ptr; // [n_blk+1]
     const int32_t* blk_odo;     // [..] edge*2 + transposed
     const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)
@@ -112,7 +113,8 @@ struct DeviceGraph {
     double* obs_err;            // [No][3]   (written only when debug != 0)
     double* obs_chi2;           // [No]
     double* obs_w;              // [No]      rho' (0: inactive)
-    double* W;                  // [No][18]  Hpl tiles, 6x3 row-major
+    double* obs_pcw;            // [No][4]   tile seed: Pc = R Pw + t (3) and the effective weight rho' / sigma^2 (0: no Hpl tile)
+    double* W;                  // [No][18]  Hpl tiles, 6x3 row-major — written only for the stage hooks (debug)
     double* Hll;                // [Nl][6]
     double* bl;                 // [Nl][3]
     double* hpp_part;           // [n_chunks][27] 21 upper + 6 b

@@ -121,27 +121,32 @@ __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x
 // Upper-triangle index of (r,c), r <= c, in the 21-entry packing used by role B.
 __device__ __forceinline__ int upper_idx(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
-// Entry q (< 36: Hpp(r,c); 36..41: b_p) of free pose a: fixed-order sum of the pose-major chunk partials and
-// of the odometry edges incident to the pose.
-__device__ __forceinline__ double hpp_entry(const DeviceGraph& g, int a, int q) {
+// Entry q (< 36: Hpp(r,c); 36..41: b_p) of a free pose: fixed-order sum of its pose-major chunk partials [c0, c1)
+// and of the odometry edges incident to it (entries [o0, o1) of pose_odo).
+__device__ __forceinline__ double hpp_entry_r(const DeviceGraph& g, int q, int c0, int c1, int o0, int o1) {
     double v = 0.0;
     if (q < 36) {
         const int r = q / 6, c = q % 6;
         const int u = r <= c ? upper_idx(r, c) : upper_idx(c, r);
-        for (int ch = g.pose_chunk_ptr[a]; ch < g.pose_chunk_ptr[a + 1]; ++ch) v += g.hpp_part[27 * (size_t)ch + u];
-        for (int n = g.pose_odo_ptr[a]; n < g.pose_odo_ptr[a + 1]; ++n) {
+#pragma unroll 4
+        for (int ch = c0; ch < c1; ++ch) v += g.hpp_part[27 * (size_t)ch + u];
+        for (int n = o0; n < o1; ++n) {
             const int code = g.pose_odo[n];
             v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 36 : 0) + q];
         }
     } else {
         const int r = q - 36;
-        for (int ch = g.pose_chunk_ptr[a]; ch < g.pose_chunk_ptr[a + 1]; ++ch) v += g.hpp_part[27 * (size_t)ch + 21 + r];
-        for (int n = g.pose_odo_ptr[a]; n < g.pose_odo_ptr[a + 1]; ++n) {
+#pragma unroll 4
+        for (int ch = c0; ch < c1; ++ch) v += g.hpp_part[27 * (size_t)ch + 21 + r];
+        for (int n = o0; n < o1; ++n) {
             const int code = g.pose_odo[n];
             v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 114 : 108) + r];
         }
     }
     return v;
+}
+__device__ __forceinline__ double hpp_entry(const DeviceGraph& g, int a, int q) {
+    return hpp_entry_r(g, q, g.pose_chunk_ptr[a], g.pose_chunk_ptr[a + 1], g.pose_odo_ptr[a], g.pose_odo_ptr[a + 1]);
 }
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
             g.obs_w[k] = active ? rho1 : 0.0;
             g.obs_chi2[k] = active ? c2 : 0.0;
             if (g.debug) { g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
-            double2* Wk = reinterpret_cast<double2*>(g.W + 18 * (size_t)k);
             const bool pfree = g.pose_free[ip] >= 0;
+            double wo_tile = 0.0;
             if (active) {
                 chi_acc += rho0;
                 const double wo = rho1 * iv;        // weightedOmega = rho' * Omega
@@ -209,22 +214,18 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
                     hb[7] -= Jp[1] * wo * e.x + Jp[4] * wo * e.y + Jp[7] * wo * e.z;
                     hb[8] -= Jp[2] * wo * e.x + Jp[5] * wo * e.y + Jp[8] * wo * e.z;
                 }
-                if (pfree && lfree) {
-                    double Wv[18];
+                if (pfree && lfree) wo_tile = wo;
+            }
+            // the 32-byte tile seed (Hpl is rebuilt from it where it is consumed)
+            double2* seed = reinterpret_cast<double2*>(g.obs_pcw + 4 * (size_t)k);
+            seed[0] = make_double2(pc.x, pc.y);
+            seed[1] = make_double2(pc.z, wo_tile);
+            if (g.debug) {
+                double Wv[18];
+                hpl_tile(T, pc, wo_tile, K, Wv);
+                double2* Wk = reinterpret_cast<double2*>(g.W + 18 * (size_t)k);
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            Wv[r * 3 + c] = Jx[r] * wo * Jp[c] + Jx[6 + r] * wo * Jp[3 + c] + Jx[12 + r] * wo * Jp[6 + c];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) Wk[q] = make_double2(Wv[2 * q], Wv[2 * q + 1]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) Wk[q] = make_double2(0.0, 0.0);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) Wk[q] = make_double2(0.0, 0.0);
+                for (int q = 0; q < 9; ++q) Wk[q] = make_double2(Wv[2 * q], Wv[2 * q + 1]);
             }
         }
         // 9 sums over the G lanes of the landmark; each lane ends up owning rs_slots(9,G) of them
@@ -390,10 +391,13 @@ __global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
     const int ch = wg * 4 + (threadIdx.x >> 6);
     if (ch >= g.n_sch) return;
     const double lambda = st->lambda;
-    const int b = g.sch_blk[ch];
-    const bool diag = (g.blk_i[b] == g.blk_j[b]);
-    const int e = g.sch_ptr[ch] + lane;
-    const int e_end = min(g.sch_ptr[ch] + SCH_CHUNK, g.blk_ptr[b + 1]);
+    // one descriptor load, then the pair list and the two poses can be fetched together (no dependent index chain)
+    const int4 dsc = g.sch_desc[ch];
+    const int e = dsc.x + lane, e_end = dsc.y;
+    const bool diag = (dsc.z == dsc.w);
+    const double* pose = g.pose[st->sel];
+    const Rt Ti = pose_to_Rt(pose + POSE_STRIDE * dsc.z);
+    const Rt Tj = pose_to_Rt(pose + POSE_STRIDE * dsc.w);
     double acc[21];
     double keep0 = 0.0, keep1 = 0.0;
     int off0 = 0, len0 = 21, off1 = 0, len1 = 21;
@@ -403,13 +407,14 @@ __global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
     double Y[18], Wb[18], B[3] = { 0.0, 0.0, 0.0 };
     {
         const double* H = g.Hll + 6 * (size_t)pr.z;
-        const double2* pa = reinterpret_cast<const double2*>(g.W + 18 * (size_t)pr.x);
-        const double2* pb = reinterpret_cast<const double2*>(g.W + 18 * (size_t)pr.y);
+        const double2* sa = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.x);
+        const double2* sb = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.y);
+        const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
+        const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
+        const Intrinsics K = intr_of(g);
         double Wa[18];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 t = have ? pa[q] : make_double2(0.0, 0.0); Wa[2 * q] = t.x; Wa[2 * q + 1] = t.y; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 t = have ? pb[q] : make_double2(0.0, 0.0); Wb[2 * q] = t.x; Wb[2 * q + 1] = t.y; }
+        hpl_tile(Ti, Vec3{ a0.x, a0.y, a1.x }, a1.y, K, Wa);
+        hpl_tile(Tj, Vec3{ b0.x, b0.y, b1.x }, b1.y, K, Wb);
         double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 };
         if (have) {
             h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
@@ -465,15 +470,20 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
         for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
     }
     const double lambda = st->lambda;
-    const int i = g.blk_i[b], j = g.blk_j[b];
+    const int4 bd = g.blk_desc[2 * b];           // (first chunk, last + 1, first odometry entry, last + 1)
+    const int4 be = g.blk_desc[2 * b + 1];       // (i, j, first pose-major chunk of i, last + 1)
+    const int i = be.x, j = be.y;
     const bool diag = (i == j);
     const int r = lane / 6, c = lane % 6;    // meaningful for lane < 36
     double part = 0.0;
-    if (lane < 42) for (int ch = g.blk_chunk_ptr[b]; ch < g.blk_chunk_ptr[b + 1]; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
+    if (lane < 42) {
+#pragma unroll 4
+        for (int ch = bd.x; ch < bd.y; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
+    }
     if (!diag) {
         if (lane < 36) {
             double base = 0.0;
-            for (int n = g.blk_odo_ptr[b]; n < g.blk_odo_ptr[b + 1]; ++n) {
+            for (int n = bd.z; n < bd.w; ++n) {
                 const int code = g.blk_odo[n];
                 base += g.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
             }
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
         }
         return;
     }
-    const double hv = (lane < 42) ? hpp_entry(g, i, lane) : 0.0;
+    const double hv = (lane < 42) ? hpp_entry_r(g, lane, be.z, be.w, bd.z, bd.w) : 0.0;
     const bool on_diag = lane < 36 && r == c;
     const unsigned long long nz = __ballot(on_diag && hv != 0.0);
     const bool pin = (nz == 0ull);
@@ -814,7 +824,9 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
         if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; }
         return;
     }
+    double* sRt0 = red + 8;                   // poses of the linearisation point (tiles are rebuilt there)
     stage_poses(pose_t, g.Np, sRt);
+    stage_poses(g.pose[sel], g.Np, sRt0);
     __syncthreads();
     constexpr int LPW = 256 / G;
     const int l = bid * LPW + tid / G, sub = tid % G;
@@ -833,12 +845,13 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
         const double w = g.obs_w[k];
         if (w == 0.0) continue;
         any = 1.0;
-        const int a = g.pose_free[g.obs_pose[k]];
+        const int ipk = g.obs_pose[k];
+        const int a = g.pose_free[ipk];
         if (a < 0 || !lfree) continue;
-        const double2* pw2 = reinterpret_cast<const double2*>(g.W + 18 * (size_t)k);
+        const double2* seed = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)k);
+        const double2 s0 = seed[0], s1 = seed[1];
         double Wv[18];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const double2 t = pw2[q]; Wv[2 * q] = t.x; Wv[2 * q + 1] = t.y; }
+        hpl_tile(load_Rt(sRt0, ipk), Vec3{ s0.x, s0.y, s1.x }, s1.y, K, Wv);
         const double* xp = g.x + 6 * (size_t)a;
 #pragma unroll
         for (int r = 0; r < 6; ++r) { const double xr = xp[r]; t0 += Wv[r * 3] * xr; t1 += Wv[r * 3 + 1] * xr; t2 += Wv[r * 3 + 2] * xr; }
@@ -1069,7 +1082,7 @@ static void launch_lin_t(const DeviceGraph& g, hipStream_t s) {
 }
 template <int G>
 static void launch_backsub_t(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_backsub<G>, dim3(g.n_lin_a + 1), dim3(256), lds_poses(g, 8), s, g);
+    hipLaunchKernelGGL(k_backsub<G>, dim3(g.n_lin_a + 1), dim3(256), (size_t)(24 * g.Np + 8) * sizeof(double), s, g);
 }
 
 void launch_linearize(const DeviceGraph& g, hipStream_t s) {

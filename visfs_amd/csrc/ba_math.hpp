@@ -156,59 +156,87 @@ BA_HD Vec3 stereo_error(const Rt& T, const Vec3& pw, double u, double v, double 
 // EdgeStereo::linearizeOplus (OptimizeTypeDefine.h:134-178).
 // Jp: d e / d point, 3x3 row-major (":145-155").  Jx: d e / d pose (dt | dtheta), 3x6 row-major (":157-176"),
 // including the reference's SE(3)-style -[Pc]x rotation block (SURVEY §8a a6 quirk — reproduced as written).
+// The reference divides by z and z^2 term by term (~24 fp64 divisions); on the GPU one reciprocal is taken and
+// multiplied through (a division costs ~15 VALU instructions): values agree with the literal form to ~1 ulp.
 BA_HD void stereo_jacobians(const Rt& T, const Vec3& pc, const Intrinsics& K, double Jp[9], double Jx[18]) {
-    const double x = pc.x, y = pc.y, z = pc.z, z_2 = z * z;
+    const double x = pc.x, y = pc.y;
+    const double iz = 1.0 / pc.z, iz2 = iz * iz;
+    const double fxz = K.fx * iz, fyz = K.fy * iz;              // fx/z, fy/z
+    const double fxx = K.fx * x * iz2, fyy = K.fy * y * iz2;    // fx x/z^2, fy y/z^2
+    const double bz = K.bf * iz2;                               // bf/z^2
     const Mat3& R = T.R;
-    Jp[0] = -K.fx * R.m00 / z + K.fx * x * R.m20 / z_2;
-    Jp[1] = -K.fx * R.m01 / z + K.fx * x * R.m21 / z_2;
-    Jp[2] = -K.fx * R.m02 / z + K.fx * x * R.m22 / z_2;
-    Jp[3] = -K.fy * R.m10 / z + K.fy * y * R.m20 / z_2;
-    Jp[4] = -K.fy * R.m11 / z + K.fy * y * R.m21 / z_2;
-    Jp[5] = -K.fy * R.m12 / z + K.fy * y * R.m22 / z_2;
-    Jp[6] = Jp[0] - K.bf * R.m20 / z_2;
-    Jp[7] = Jp[1] - K.bf * R.m21 / z_2;
-    Jp[8] = Jp[2] - K.bf * R.m22 / z_2;
-    Jx[0] = -1. / z * K.fx;
+    Jp[0] = -fxz * R.m00 + fxx * R.m20;
+    Jp[1] = -fxz * R.m01 + fxx * R.m21;
+    Jp[2] = -fxz * R.m02 + fxx * R.m22;
+    Jp[3] = -fyz * R.m10 + fyy * R.m20;
+    Jp[4] = -fyz * R.m11 + fyy * R.m21;
+    Jp[5] = -fyz * R.m12 + fyy * R.m22;
+    Jp[6] = Jp[0] - bz * R.m20;
+    Jp[7] = Jp[1] - bz * R.m21;
+    Jp[8] = Jp[2] - bz * R.m22;
+    Jx[0] = -fxz;
     Jx[1] = 0.;
-    Jx[2] = x / z_2 * K.fx;
-    Jx[3] = x * y / z_2 * K.fx;
-    Jx[4] = -(1. + (x * x / z_2)) * K.fx;
-    Jx[5] = y / z * K.fx;
+    Jx[2] = fxx;
+    Jx[3] = fxx * y;
+    Jx[4] = -(K.fx + fxx * x);
+    Jx[5] = fxz * y;
     Jx[6] = 0.;
-    Jx[7] = -1. / z * K.fy;
-    Jx[8] = y / z_2 * K.fy;
-    Jx[9] = (1. + y * y / z_2) * K.fy;
-    Jx[10] = -x * y / z_2 * K.fy;
-    Jx[11] = -x / z * K.fy;
+    Jx[7] = -fyz;
+    Jx[8] = fyy;
+    Jx[9] = K.fy + fyy * y;
+    Jx[10] = -fyy * x;
+    Jx[11] = -fyz * x;
     Jx[12] = Jx[0];
     Jx[13] = 0.;
-    Jx[14] = Jx[2] - K.bf / z_2;
-    Jx[15] = Jx[3] - K.bf * y / z_2;
-    Jx[16] = Jx[4] + K.bf * x / z_2;
+    Jx[14] = Jx[2] - bz;
+    Jx[15] = Jx[3] - bz * y;
+    Jx[16] = Jx[4] + bz * x;
     Jx[17] = Jx[5];
 }
 
 // Only the pose Jacobian (pose-major pass).
 BA_HD void stereo_jacobian_pose(const Vec3& pc, const Intrinsics& K, double Jx[18]) {
-    const double x = pc.x, y = pc.y, z = pc.z, z_2 = z * z;
-    Jx[0] = -1. / z * K.fx;
+    const double x = pc.x, y = pc.y;
+    const double iz = 1.0 / pc.z, iz2 = iz * iz;
+    const double fxz = K.fx * iz, fyz = K.fy * iz;
+    const double fxx = K.fx * x * iz2, fyy = K.fy * y * iz2;
+    const double bz = K.bf * iz2;
+    Jx[0] = -fxz;
     Jx[1] = 0.;
-    Jx[2] = x / z_2 * K.fx;
-    Jx[3] = x * y / z_2 * K.fx;
-    Jx[4] = -(1. + (x * x / z_2)) * K.fx;
-    Jx[5] = y / z * K.fx;
+    Jx[2] = fxx;
+    Jx[3] = fxx * y;
+    Jx[4] = -(K.fx + fxx * x);
+    Jx[5] = fxz * y;
     Jx[6] = 0.;
-    Jx[7] = -1. / z * K.fy;
-    Jx[8] = y / z_2 * K.fy;
-    Jx[9] = (1. + y * y / z_2) * K.fy;
-    Jx[10] = -x * y / z_2 * K.fy;
-    Jx[11] = -x / z * K.fy;
+    Jx[7] = -fyz;
+    Jx[8] = fyy;
+    Jx[9] = K.fy + fyy * y;
+    Jx[10] = -fyy * x;
+    Jx[11] = -fyz * x;
     Jx[12] = Jx[0];
     Jx[13] = 0.;
-    Jx[14] = Jx[2] - K.bf / z_2;
-    Jx[15] = Jx[3] - K.bf * y / z_2;
-    Jx[16] = Jx[4] + K.bf * x / z_2;
+    Jx[14] = Jx[2] - bz;
+    Jx[15] = Jx[3] - bz * y;
+    Jx[16] = Jx[4] + bz * x;
     Jx[17] = Jx[5];
+}
+
+// Hpl tile of one stereo edge, J_pose^T (rho' Omega) J_point (6x3 row-major), rebuilt from its 32-byte seed
+// (Pc, wo) with the SAME formulas as linearizeOplus — the Schur gather and the back-substitution recompute the
+// tile instead of re-reading 144 bytes per use.
+BA_HD void hpl_tile(const Rt& T, const Vec3& pc, double wo, const Intrinsics& K, double Wv[18]) {
+    if (wo == 0.0) {
+#pragma unroll
+        for (int q = 0; q < 18; ++q) Wv[q] = 0.0;
+        return;
+    }
+    double Jp[9], Jx[18];
+    stereo_jacobians(T, pc, K, Jp, Jx);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Wv[r * 3 + c] = Jx[r] * wo * Jp[c] + Jx[6 + r] * wo * Jp[3 + c] + Jx[12 + r] * wo * Jp[6 + c];
 }
 
 // [g2o-upstream] RobustKernelHuber::robustify on chi2 = e^T Omega e (delta compared SQUARED).
