@@ -106,6 +106,33 @@ def test_optimize_parity(olib, cfg, solver):
     s.close(); o.close()
 
 
+@pytest.mark.parametrize("n_kf,n_lm,n_obs", [(100, 1000, 8000), (257, 1500, 9000)])
+def test_pcg_register_block_variants(olib, n_kf, n_lm, n_obs):
+    """The persistent PCG keeps ceil(Npf/64) 6-blocks per lane in registers: 1 (C1..C3), 2 (99 free poses) and
+    4 (256 free poses, the maximum; also C4) blocks per lane are separate template instances."""
+    w = synth.make_window("custom", n_kf=n_kf, n_lm=n_lm, n_obs=n_obs, seed=17)
+    o, s, gb = make_pair(olib, w, iterations=6, solver=2)
+    check_stages(o, s)
+    check_optimize(o, s, pose_tol=1e-5)
+    s.close(); o.close()
+
+
+def test_pcg_refuses_more_than_256_free_poses_but_direct_solves(olib):
+    """One PCG workgroup per block row must be co-resident (256 CUs): larger systems are refused for Solver=2, never hung;
+    the direct solver takes them."""
+    from visfs_amd import backend
+    w = synth.make_window("custom", n_kf=300, n_lm=1500, n_obs=9000, seed=17)
+    prm = abi.default_params(iterations=4, solver=2)
+    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+    s = backend.Solver(prm)
+    with pytest.raises(backend.BackendError, match="256 free poses"):
+        s.upload(gb)
+    s.close()
+    o, s, gb = make_pair(olib, w, iterations=4, solver=0)
+    check_optimize(o, s, pose_tol=1e-5)
+    s.close(); o.close()
+
+
 def test_optimize_parity_default_iterations(olib):
     """Reference defaults: Iterations=10 → 5+5 (Parameters.h:187)."""
     o, s, gb = make_pair(olib, synth.make_window("C1"))

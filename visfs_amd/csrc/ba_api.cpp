@@ -284,14 +284,20 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         blk_desc[2 * b + 1] = make_int4(a, blk_j[b], pose_chunk_ptr[a], pose_chunk_ptr[a + 1]);
     }
     // persistent PCG: LDS plan (4 vectors always; all Minv blocks and the own block row of S when they fit in 60 KiB)
-    if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 341 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
+    if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 256 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
     int max_row = 0;
     for (int a = 0; a < Npf; ++a) max_row = std::max(max_row, row_ptr[a + 1] - row_ptr[a]);
-    size_t pcg_lds = (size_t)4 * 6 * Npf * 8 + 40 * 8;
+    // persistent PCG: LDS plan.  d, q (+ s beyond 64 free poses), scalars, the row's column/code tables always; all Minv
+    // blocks (beyond 64 free poses; below that they live in registers) and the own block row of S when they fit.
+    // Co-residency of the hand-off needs every workgroup resident: <= 200 workgroups may own most of a CU's LDS each,
+    // more than that must fit two per CU.
+    size_t pcg_lds = (size_t)((Npf > 64 ? 3 : 2) * 6 * Npf + 32 + 32) * 8 + (size_t)8 * max_row + 16;
     int lds_minv = 0, lds_srow = 0;
-    if (pcg_lds + (size_t)288 * Npf <= 60 * 1024) { lds_minv = 1; pcg_lds += (size_t)288 * Npf; }
-    if (pcg_lds + (size_t)288 * max_row <= 60 * 1024) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
-    pcg_lds += (size_t)8 * max_row + 16;      // column / block-code tables of the row
+    {
+        const size_t budget = (size_t)150 * 1024;        // one workgroup per CU may own most of its 160 KiB
+        if (Npf > 64 && pcg_lds + (size_t)288 * Npf <= budget) { lds_minv = 1; pcg_lds += (size_t)288 * Npf; }
+        if (pcg_lds + (size_t)288 * max_row <= budget) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
+    }
 
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -301,6 +307,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     const int n_eval = (No + 255) / 256 + 1;
     const int n_parts = std::max(n_lin_a + 1, n_eval);
     const size_t n6 = (size_t)6 * Npf;
+    const size_t chol_np = std::max<size_t>(32, (n6 + 31) / 32 * 32);
 
     // ---- lay out the static section (host staging == device layout), then the mutable section
     auto layout = [&](Arena& A, DeviceGraph& g, bool is_static_pass) {
@@ -370,7 +377,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.granules = A.take<unsigned long long>(std::max<size_t>(4 * n6, 1));
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
-        g.dense = A.take<double>(prm.solver == 2 ? 1 : std::max<size_t>(n6 * n6, 1));
+        g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
+        g.chol_y = A.take<double>(chol_np);
+        g.chol_linv = A.take<double>(32 * 32);
+        g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };
     layout_dyn(dyn, dg);
@@ -435,12 +445,13 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     layout_dyn(dd, dg);
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group;
-    dg.n_sch = n_sch; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds;
+    dg.n_sch = n_sch; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
     dg.huber_delta = prm.robust_kernel_delta;             // Optimizer.cpp:212-216
     dg.debug = 0;
+    { const char* e = std::getenv("VISFS_BA_STAMP_WG"); dg.stamp_wg = e ? std::atoi(e) : 0; }
     w.g = dg;
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
@@ -782,7 +793,10 @@ int visfs_ba_solve_window(visfs_ba_handle* h, const visfs_ba_window* w, visfs_ba
 int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r) {
     if (!h || n < 0 || (n > 0 && (!w || !r))) return VISFS_BA_ERR_BAD_ARGUMENT;
     // independent windows: one workspace + stream + host thread per in-flight window
-    const int lanes = std::min<int>(n, 8);
+    // the persistent PCG needs all of a window's workgroups resident: keep the sum of the in-flight grids <= 256 CUs
+    int max_poses = 1;
+    for (int i = 0; i < n; ++i) max_poses = std::max(max_poses, (int)w[i]->n_poses);
+    const int lanes = std::max(1, std::min<int>(std::min<int>(n, 8), h->prm.solver == 2 ? 256 / max_poses : 8));
     while ((int)h->batch.size() < lanes) h->batch.push_back(new Workspace());
     std::vector<int> rcs(n, VISFS_BA_OK);
     std::vector<std::string> errs(lanes);
@@ -915,6 +929,12 @@ int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t 
         case VISFS_BA_BUF_POINT_TRIAL: src = g.pt[sel ^ 1]; m = (size_t)g.Nl * 3; break;
         case VISFS_BA_BUF_HPP: case VISFS_BA_BUF_S: m = n6 * n6; break;
         case VISFS_BA_BUF_POSE_TRIAL: m = (size_t)g.Np * 7; break;
+        case 100: {   // diagnostic: raw PCG stamps (only meaningful in a -DVISFS_BA_STAMPS build)
+            if (n_doubles < 128) return bad(h, "destination too small");
+            HIP_TRY(h, hipMemcpyAsync(dst, g.stamps, 128 * 8, hipMemcpyDeviceToHost, w.stream));
+            HIP_TRY(h, hipStreamSynchronize(w.stream));
+            return VISFS_BA_OK;
+        }
         default: return bad(h, "unknown buffer id");
     }
     if (n_doubles < m) return bad(h, "destination too small");

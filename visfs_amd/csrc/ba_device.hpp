@@ -19,7 +19,7 @@ constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
 constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
 constexpr int MAX_STAGED_POSES = 640; // 12 doubles each in LDS (60 KiB)
-constexpr int MAX_PCG_FREE_POSES = 341; // persistent PCG keeps 4 vectors of 6*Npf doubles in <= 64 KiB of LDS
+constexpr int MAX_PCG_FREE_POSES = 256; // persistent PCG: one workgroup per block row, all co-resident (256 CUs, >= 1 workgroup each)
 constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront
 
 // LM / phase state machine, resident in HBM; every kernel of a "unit" reads its gate from here.
@@ -63,6 +63,7 @@ struct DeviceGraph {
     int32_t pcg_lds_srow;   // ... and its own block row of S
     int32_t pcg_max_row;    // longest block row of S (blocks)
     int32_t pcg_lds_bytes;
+    int32_t chol_np;        // padded order of the dense reduced camera matrix (direct solver)
     int32_t n_lin_a;        // workgroups of the landmark-major role
     int32_t group;          // lanes per landmark (4/8/16/32/64)
     double fx, fy, cx, cy, bf;
@@ -133,9 +134,13 @@ struct DeviceGraph {
     unsigned long long* granules; // [2][2*6Npf] {epoch:32 | half of a double:32} hand-off words of the persistent PCG
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
-    double* dense;              // [6Npf][6Npf] scratch for the direct solver
+    double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)
+    double* chol_y;             // [chol_np]
+    double* chol_linv;          // [32][32] inverse of the current diagonal block
 
     LmState* st;
+    unsigned long long* stamps;  // [128] diagnostic build (-DVISFS_BA_STAMPS) only: real-time stamps of one PCG workgroup
+    int32_t stamp_wg;
     int32_t debug;
 };
 

@@ -26,10 +26,25 @@
 namespace visfs_ba {
 
 // ---------------------------------------------------------------- wave helpers
+// Wave-wide sum, every lane gets the result.  DPP lane moves (quad_perm, row_ror) build the four 16-lane row sums in
+// the VALU — no LDS-crossbar ds_bpermute round trips — and four readlanes combine them in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);     // row_ror:4
+    v += dpp_mov<0x128>(v);     // row_ror:8  → every lane holds the sum of its row of 16
+    return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -537,7 +552,8 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
 // write-through store each; every workgroup then sweeps all granules of the iteration until their tags match
 // (cdna_hip_programming.md §6 Guideline 16, form R2: the data is the flag — no fence, no separate flag word).
 // Granules are double-buffered on the iteration parity and zeroed by k_schur_finalize before every solve.
-// Residency: grid = Npf <= 341 workgroups of 4 waves with <= 64 KiB of LDS each (>= 2 per CU) — always co-resident.
+// Residency: grid = Npf <= 256 workgroups of 4 waves: one per CU always fits, so the grid is co-resident on an otherwise
+// idle device; concurrent windows (visfs_ba_solve_batch) are limited so that the sum of their grids stays <= 256.
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -545,97 +561,146 @@ __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long 
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// BPL = 6-blocks owned by each lane of wave 0 (ceil(Npf / 64)); MREG: the lane keeps its Minv block in registers (BPL == 1).
+template <int BPL, bool MREG>
 __global__ __launch_bounds__(256) void k_pcg(const DeviceGraph g) {
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
+#ifdef VISFS_BA_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == (unsigned)g.stamp_wg) g.stamps[127] = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n6 = 6 * g.Npf;
-    double* sr = smem;
-    double* sd = smem + n6;
-    double* sq = smem + 2 * n6;
-    double* ss = smem + 3 * n6;
-    double* sP = smem + 4 * n6;                                       // [4][8] per-wave partial rows of q_i, then scalars
-    double* sM = sP + 40;                                             // [Npf][36] when pcg_lds_minv
-    double* sS = sM + (g.pcg_lds_minv ? 36 * g.Npf : 0);              // [row blocks][36] when pcg_lds_srow
+    constexpr int R = 1;                                              // one block row of S per workgroup (more rows per workgroup measured slower)
+    const int i0 = blockIdx.x, i1 = i0 + 1;
+    double* sd = smem;                                                // d (every workgroup holds the full vector)
+    double* sq = smem + n6;                                           // q of the current iteration
+    double* sP = smem + 2 * n6;                                       // [32] scalars
+    double* sQ = sP + 32;                                             // [R][4][8] per-wave partial rows of q
+    double* ss = sQ + 32 * R;                                         // [n6] s = Minv r, only when BPL > 1 (else registers)
+    double* sM = ss + (BPL > 1 ? n6 : 0);                             // [Npf][36] when pcg_lds_minv
+    double* sS = sM + (g.pcg_lds_minv ? 36 * g.Npf : 0);              // [R][max_row][36] when pcg_lds_srow
     const double* Minv = g.pcg_lds_minv ? sM : g.Minv;
-    const int rb = g.row_ptr[i], nb = g.row_ptr[i + 1] - rb;
-    int* sCol = reinterpret_cast<int*>(sS + (g.pcg_lds_srow ? 36 * g.pcg_max_row : 0));   // [nb] column block of each entry
-    int* sCode = sCol + g.pcg_max_row;                                                      // [nb] stored block * 2 + transposed
-    for (int n = tid; n < nb; n += 256) { sCol[n] = g.row_col[rb + n]; sCode[n] = g.row_blk[rb + n]; }
-    if (g.pcg_lds_minv) {
+    int* sCol = reinterpret_cast<int*>(sS + (g.pcg_lds_srow ? 36 * (size_t)R * g.pcg_max_row : 0));   // [R][max_row]
+    int* sCode = sCol + R * g.pcg_max_row;
+    const int MR = g.pcg_max_row;
+    for (int li = 0; li < i1 - i0; ++li) {
+        const int rb = g.row_ptr[i0 + li], nb = g.row_ptr[i0 + li + 1] - rb;
+        for (int n = tid; n < nb; n += 256) { sCol[li * MR + n] = g.row_col[rb + n]; sCode[li * MR + n] = g.row_blk[rb + n]; }
+    }
+    if (g.pcg_lds_minv && !MREG) {
 #pragma unroll 4
         for (int t = tid; t < 36 * g.Npf; t += 256) sM[t] = g.Minv[t];
     }
-    for (int t = tid; t < n6; t += 256) sr[t] = g.bs[t];
-    if (tid == 0) sP[34] = 0.0;                                        // hand-off timeout flag of the workgroup
-    __syncthreads();
-    if (g.pcg_lds_srow) {
-        // own block row; transposed blocks are stored transposed so that the mat-vec reads every block row-major.
-        // The block codes come from LDS, so the S loads do not wait on other global loads.
-#pragma unroll 4
-        for (int t = tid; t < 36 * nb; t += 256) {
-            const int n = t / 36, q = t - 36 * n, code = sCode[n];
-            const double* Sb = g.S + 36 * (size_t)(code >> 1);
-            sS[t] = (code & 1) ? Sb[(q % 6) * 6 + q / 6] : Sb[q];
-        }
-    }
-    // r = b ; d = M^-1 r ; dn = r.d   (wave 0; fixed order)
+    if (tid == 0) sP[2] = 0.0;                                         // hand-off timeout flag of the workgroup
+    // ---- wave 0: lane owns the 6-blocks a = lane + 64 k.  r = b ; d = M^-1 r ; dn = r.d   (fixed order)
+    double rr_[BPL][6], dd_[BPL][6], xown[6], mm_[MREG ? 36 : 1];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xown[c] = 0.0;
     double dn = 0.0, d0 = 0.0;
     if (wave == 0) {
-        for (int t = lane; t < n6; t += 64) {
-            const int a = t / 6, rr = t % 6;
-            const double* M = Minv + 36 * a + 6 * rr;
-            const double* rbk = sr + 6 * a;
-            const double dv = M[0] * rbk[0] + M[1] * rbk[1] + M[2] * rbk[2] + M[3] * rbk[3] + M[4] * rbk[4] + M[5] * rbk[5];
-            sd[t] = dv;
-            dn += sr[t] * dv;
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const int a = lane + 64 * k;
+            const bool own = a < g.Npf;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rr_[k][c] = own ? g.bs[6 * a + c] : 0.0;
+            if (MREG) {
+#pragma unroll
+                for (int q = 0; q < 36; ++q) mm_[q] = own ? g.Minv[36 * (size_t)a + q] : 0.0;
+            }
         }
-        dn = wave_sum(dn);
+        if (!MREG) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+        // (for !MREG the Minv copy above is completed by the barrier below before it is read)
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            const int a = lane + 64 * k;
+            const bool own = a < g.Npf;
+#pragma unroll
+            for (int r6 = 0; r6 < 6; ++r6) {
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v += (MREG ? mm_[6 * r6 + c] : (own ? Minv[36 * a + 6 * r6 + c] : 0.0)) * rr_[k][c];
+                dd_[k][r6] = v;
+                part += rr_[k][r6] * v;
+                if (own) sd[6 * a + r6] = v;
+            }
+        }
+        dn = wave_sum(part);
         d0 = 1e-6 * dn;
         const double res_in = st->pcg_res_in;
         if (res_in > 0.0 && res_in > d0) d0 = res_in;
-        if (lane == 0) { sP[32] = dn; sP[33] = d0; }
+        if (lane == 0) { sP[0] = dn; sP[1] = d0; }
     }
-    __syncthreads();
-    dn = sP[32]; d0 = sP[33];
-    double xown = 0.0;                                                // wave 0, lanes 0..5: x of this block row
-    int iter = 0;
-    bool timeout = false;
-    while (true) {
-        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
-        // ---- own block row of q = S d: 32 slots (8 per wave) x 8 lanes (6 rows used)
-        const int slot = tid >> 3, rr = tid & 7;
-        double acc = 0.0;
-        if (rr < 6) {
-            for (int n = slot; n < nb; n += 32) {
-                const double* dj = sd + 6 * sCol[n];
-                if (g.pcg_lds_srow) {
-                    const double* Sr = sS + 36 * n + 6 * rr;
-                    acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5];
-                } else {
-                    const int code = sCode[n];
-                    const double* Sb = g.S + 36 * (size_t)(code >> 1);
-                    if (code & 1) acc += Sb[rr] * dj[0] + Sb[6 + rr] * dj[1] + Sb[12 + rr] * dj[2] + Sb[18 + rr] * dj[3] + Sb[24 + rr] * dj[4] + Sb[30 + rr] * dj[5];
-                    else { const double* Sr = Sb + 6 * rr; acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5]; }
-                }
+    if (g.pcg_lds_srow) {
+        // own block rows; transposed blocks are stored transposed so that the mat-vec reads every block row-major.
+        // The block codes come from LDS, so the S loads do not wait on other global loads.
+        for (int li = 0; li < i1 - i0; ++li) {
+            const int nb = g.row_ptr[i0 + li + 1] - g.row_ptr[i0 + li];
+#pragma unroll 4
+            for (int t = tid; t < 36 * nb; t += 256) {
+                const int n = t / 36, q = t - 36 * n, code = sCode[li * MR + n];
+                const double* Sb = g.S + 36 * (size_t)(code >> 1);
+                sS[36 * (size_t)(li * MR) + t] = (code & 1) ? Sb[(q % 6) * 6 + q / 6] : Sb[q];
             }
         }
-        acc += __shfl_xor(acc, 8, 64);
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
-        if (lane < 8) sP[wave * 8 + lane] = acc;
+    }
+    __syncthreads();
+    dn = sP[0]; d0 = sP[1];
+    int iter = 0;
+    bool timeout = false;
+#ifdef VISFS_BA_STAMPS
+#define PCG_STAMP(slot) do { if (tid == 0 && blockIdx.x == (unsigned)g.stamp_wg && (slot) < 126) g.stamps[(slot)] = wall_clock64(); } while (0)
+    PCG_STAMP(0);
+#else
+#define PCG_STAMP(slot) do { } while (0)
+#endif
+    while (true) {
+        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
+        // ---- owned block rows of q = S d: 32 slots (8 per wave) x 8 lanes (6 rows used), fixed-order partials
+        const int slot = tid >> 3, rr = tid & 7;
+        for (int li = 0; li < i1 - i0; ++li) {
+            const int nb = g.row_ptr[i0 + li + 1] - g.row_ptr[i0 + li];
+            double acc = 0.0;
+            if (rr < 6) {
+                for (int n = slot; n < nb; n += 32) {
+                    const double* dj = sd + 6 * sCol[li * MR + n];
+                    if (g.pcg_lds_srow) {
+                        const double* Sr = sS + 36 * (size_t)(li * MR + n) + 6 * rr;
+                        acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5];
+                    } else {
+                        const int code = sCode[li * MR + n];
+                        const double* Sb = g.S + 36 * (size_t)(code >> 1);
+                        if (code & 1) acc += Sb[rr] * dj[0] + Sb[6 + rr] * dj[1] + Sb[12 + rr] * dj[2] + Sb[18 + rr] * dj[3] + Sb[24 + rr] * dj[4] + Sb[30 + rr] * dj[5];
+                        else { const double* Sr = Sb + 6 * rr; acc += Sr[0] * dj[0] + Sr[1] * dj[1] + Sr[2] * dj[2] + Sr[3] * dj[3] + Sr[4] * dj[4] + Sr[5] * dj[5]; }
+                    }
+                }
+            }
+            acc += __shfl_xor(acc, 8, 64);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < 8) sQ[li * 32 + wave * 8 + lane] = acc;
+        }
         __syncthreads();
-        // ---- publish: thread 2r + h carries half h of q_i[r] (sum of the four waves' partials, fixed order)
+        PCG_STAMP(1 + 4 * iter);
+        // ---- publish: thread 12 li + 2 r + h carries half h of q[i0 + li][r] (sum of the four waves' partials, fixed order)
         const unsigned epoch = (unsigned)iter + 1u;
         unsigned long long* gr = g.granules + (size_t)(iter & 1) * (2 * n6);
-        if (tid < 12) {
-            const int r6 = tid >> 1;
-            const double qv = ((sP[r6] + sP[8 + r6]) + sP[16 + r6]) + sP[24 + r6];
+        if (tid < 12 * (i1 - i0)) {
+            const int li = tid / 12, r6 = (tid % 12) >> 1;
+            const double* qp = sQ + li * 32;
+            const double qv = ((qp[r6] + qp[8 + r6]) + qp[16 + r6]) + qp[24 + r6];
             const unsigned long long bits = (unsigned long long)__double_as_longlong(qv);
             const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
-            st_granule(gr + 2 * (6 * i) + tid, ((unsigned long long)epoch << 32) | half);
+            st_granule(gr + 2 * (6 * i0) + tid, ((unsigned long long)epoch << 32) | half);
         }
+        PCG_STAMP(2 + 4 * iter);
         // ---- gather every row's q: every pass re-reads ALL granules of the chunk (loads in flight together), until
         //      every tag matches (Guideline 16, sweep_granules) — one L2 round trip per pass, not per element
         constexpr int SW = 4;
@@ -666,128 +731,299 @@ __global__ __launch_bounds__(256) void k_pcg(const DeviceGraph g) {
                 }
             }
         }
-        if (timeout) sP[34] = 1.0;
+        if (timeout) sP[2] = 1.0;
         __syncthreads();
-        // ---- vector recurrences on wave 0 (identical in every workgroup: same data, same order)
+        PCG_STAMP(3 + 4 * iter);
+        // ---- vector recurrences on wave 0, blocks in registers (identical in every workgroup: same data, same order)
         if (wave == 0) {
-            double dq = 0.0;
-            for (int t = lane; t < n6; t += 64) dq += sd[t] * sq[t];
-            dq = wave_sum(dq);
-            const double alpha = dn / dq;
-            if (lane < 6) xown += alpha * sd[6 * i + lane];
-            for (int t = lane; t < n6; t += 64) sr[t] -= alpha * sq[t];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            double dnn = 0.0;
-            for (int t = lane; t < n6; t += 64) {
-                const int a = t / 6, rr2 = t % 6;
-                const double* M = Minv + 36 * a + 6 * rr2;
-                const double* rbk = sr + 6 * a;
-                const double sv = M[0] * rbk[0] + M[1] * rbk[1] + M[2] * rbk[2] + M[3] * rbk[3] + M[4] * rbk[4] + M[5] * rbk[5];
-                ss[t] = sv;
-                dnn += sr[t] * sv;
+            // q of the owned blocks: registers when one block per lane, re-read from LDS otherwise (register budget)
+            double qq[BPL == 1 ? 6 : 1], sv1[BPL == 1 ? 6 : 1];
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < BPL; ++k) {
+                const int a = lane + 64 * k;
+                const bool own = a < g.Npf;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double qv = own ? sq[6 * a + c] : 0.0;
+                    if (BPL == 1) qq[c] = qv;
+                    part += dd_[k][c] * qv;
+                }
             }
-            dnn = wave_sum(dnn);
+            const double dq = wave_sum(part);
+            const double alpha = dn / dq;
+            part = 0.0;
+#pragma unroll
+            for (int k = 0; k < BPL; ++k) {
+                const int a = lane + 64 * k;
+                const bool own = a < g.Npf;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double qv = (BPL == 1) ? qq[c] : (own ? sq[6 * a + c] : 0.0);
+                    if (a == i0) xown[c] += alpha * dd_[k][c];
+                    rr_[k][c] -= alpha * qv;
+                }
+#pragma unroll
+                for (int r6 = 0; r6 < 6; ++r6) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v += (MREG ? mm_[6 * r6 + c] : (own ? Minv[36 * a + 6 * r6 + c] : 0.0)) * rr_[k][c];
+                    if (BPL == 1) sv1[r6] = v; else if (own) ss[6 * a + r6] = v;
+                    part += rr_[k][r6] * v;
+                }
+            }
+            const double dnn = wave_sum(part);
             const double beta = dnn / dn;
-            for (int t = lane; t < n6; t += 64) sd[t] = ss[t] + beta * sd[t];
-            if (lane == 0) sP[32] = dnn;
+#pragma unroll
+            for (int k = 0; k < BPL; ++k) {
+                const int a = lane + 64 * k;
+                const bool own = a < g.Npf;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double sv = (BPL == 1) ? sv1[c] : (own ? ss[6 * a + c] : 0.0);     // own writes, own reads: no fence needed
+                    dd_[k][c] = sv + beta * dd_[k][c];
+                    if (own) sd[6 * a + c] = dd_[k][c];
+                }
+            }
+            if (lane == 0) sP[0] = dnn;
         }
         __syncthreads();
-        if (sP[34] != 0.0) { timeout = true; break; }
-        dn = sP[32];
+        PCG_STAMP(4 + 4 * iter);
+        if (sP[2] != 0.0) { timeout = true; break; }
+        dn = sP[0];
         iter += 1;
     }
     if (timeout) { if (tid == 0) st->pcg_timeout = 1; return; }
-    // x is final: K8 (oplus) for this row's pose; row 0 publishes the solver statistics
+    // x is final: the lane owning this workgroup's block row stores it and does K8 (oplus); workgroup 0 publishes the statistics.
     if (wave == 0) {
-        if (lane < 6) g.x[6 * i + lane] = xown;
-        double dx[6];
+        if (lane == (i0 & 63)) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) dx[q] = __shfl(xown, q, 64);
-        if (lane == 0) {
-            const int ip = g.free_pose[i];
+            for (int c = 0; c < 6; ++c) g.x[6 * i0 + c] = xown[c];
+            const int ip = g.free_pose[i0];
             const int sel = st->sel;
-            pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
-            if (i == 0) {
-                st->pcg_residual = 0.5 * dn;
-                st->pcg_iter = iter;
-                st->pcg_total += iter;
-                if (iter > st->pcg_max) st->pcg_max = iter;
-            }
+            pose_oplus(g.pose[sel] + POSE_STRIDE * ip, xown, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+        }
+        if (lane == 0 && blockIdx.x == 0) {
+            st->pcg_residual = 0.5 * dn;
+            st->pcg_iter = iter;
+            st->pcg_total += iter;
+            if (iter > st->pcg_max) st->pcg_max = iter;
         }
     }
 }
 
-// ---- direct solver (Optimizer/Solver 0,1,3: sparse Cholesky in the reference) ----
+// ================================================================= K6 (direct): blocked Cholesky of the reduced camera matrix
+// Optimizer/Solver 0, 1, 3 (CSparse / Cholmod / Eigen sparse Cholesky in the reference, Optimizer.cpp:76-91) all factor
+// S = L L^T and back-substitute; here S is assembled dense (n = 6 Npf padded to a multiple of 32 with an identity tail)
+// and factored right-looking with 32-wide panels:
+//   k_chol_diag   (one wavefront)  : wave-synchronous Cholesky of the 32x32 diagonal block and its inverse;
+//   k_chol_trsm   (all CUs)        : L21 = A21 L11^-T as independent dot products, one thread per row;
+//   k_chol_syrk   (all CUs)        : A22 -= L21 L21^T on 32x32 tiles per wave with fp64 MFMA (v_mfma_f64_16x16x4_f64) — the
+//                                    dense reduced-camera GEMM, the only MFMA-shaped work on this path;
+//   k_chol_solve  (one workgroup)  : blocked forward / backward substitution, then K8 (pose oplus).
+// A non-positive or non-finite pivot sets LmState::solver_failed (g2o: solver returns false → the LM trial is rejected).
+constexpr int CH_NB = 32;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_dense_assemble(const DeviceGraph g) {
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
-    const int n6 = 6 * g.Npf;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < g.n_blk * 36; t += gridDim.x * 256) {
+    const int n6 = 6 * g.Npf, NP = g.chol_np;
+    const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int t = gid; t < g.n_blk * 36; t += stride) {
         const int b = t / 36, q = t % 36, r = q / 6, c = q % 6;
         const int i = g.blk_i[b], j = g.blk_j[b];
         const double v = g.S[t];
-        g.dense[(size_t)(6 * i + r) * n6 + 6 * j + c] = v;
-        g.dense[(size_t)(6 * j + c) * n6 + 6 * i + r] = v;
+        g.dense[(size_t)(6 * i + r) * NP + 6 * j + c] = v;
+        g.dense[(size_t)(6 * j + c) * NP + 6 * i + r] = v;
+    }
+    for (int t = n6 + gid; t < NP; t += stride) g.dense[(size_t)t * NP + t] = 1.0;       // identity tail of the padding
+}
+
+// One wavefront: Cholesky of the 32x32 diagonal block and its inverse (lanes 0..31 own one row / one column each).
+__global__ __launch_bounds__(64) void k_chol_diag(const DeviceGraph g, const int kb) {
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
+    const int NP = g.chol_np, tid = threadIdx.x;
+    double* A = g.dense;
+    __shared__ double sL[CH_NB][CH_NB + 1];        // L11, row-major (padded)
+    __shared__ double sCol[CH_NB];                 // the column being eliminated
+    __shared__ double sInv[CH_NB];                 // 1 / L11[c][c]
+    const int r = tid & 31;
+    const bool act = tid < 32;
+    double a[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) a[c] = act ? A[(size_t)(kb + r) * NP + kb + c] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        const double p = __shfl(a[c], c, 64);                       // pivot: already reduced by the columns before it
+        if (!(p > 0.0) || !(p <= DBL_MAX)) bad = true;
+        const double piv = sqrt(p), inv = 1.0 / piv;
+        const double l = (r == c) ? piv : a[c] * inv;                  // L[r][c] for r >= c
+        a[c] = (r >= c) ? l : 0.0;
+        if (act) sCol[r] = a[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c2 = c + 1; c2 < CH_NB; ++c2) a[c2] -= a[c] * sCol[c2];  // eager update of the row (rows < c carry 0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (r == c && act) sInv[c] = inv;
+    }
+    if (__any(bad)) { if (tid == 0) st->solver_failed = 1; return; }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) { sL[r][c] = a[c]; A[(size_t)(kb + r) * NP + kb + c] = a[c]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // L11^-1: lane c builds column c by forward substitution, X[r][c] = (d_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r];
+    // a[] is reused as the column (no cross-lane traffic: L comes from LDS broadcasts)
+#pragma unroll
+    for (int rr = 0; rr < CH_NB; ++rr) {
+        double v = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) v -= sL[rr][k] * a[k];
+        a[rr] = (rr >= r) ? v * sInv[rr] : 0.0;
+    }
+    if (act) {
+#pragma unroll
+        for (int rr = 0; rr < CH_NB; ++rr) g.chol_linv[rr * CH_NB + r] = a[rr];      // row-major L11^-1
     }
 }
 
-// One workgroup: in-place right-looking Cholesky of the dense S (scratch cleared by the launcher: the
-// factor fills in), forward/back substitution, K8 pose update.
-__global__ __launch_bounds__(1024) void k_cholesky(const DeviceGraph g) {
-    LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
-    const int n = 6 * g.Npf, tid = threadIdx.x;
-    double* A = g.dense;
-    __shared__ double s_piv;
-    __shared__ int s_fail;
-    if (tid == 0) s_fail = 0;
+// L21 = A21 L11^-T: x[c] = sum_{k<=c} a[k] Linv[c][k] — independent dot products, one thread per row, rows over all CUs.
+__global__ __launch_bounds__(256) void k_chol_trsm(const DeviceGraph g, const int kb) {
+    const LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
+    const int NP = g.chol_np, tid = threadIdx.x;
+    __shared__ double sLi[CH_NB][CH_NB + 1];
+    for (int t = tid; t < CH_NB * CH_NB; t += 256) sLi[t / CH_NB][t % CH_NB] = g.chol_linv[t];
     __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        if (tid == 0) {
-            const double p = A[(size_t)k * n + k];
-            if (!(p > 0.0) || !(p <= DBL_MAX)) s_fail = 1;
-            s_piv = sqrt(p);
+    const int row = kb + CH_NB + blockIdx.x * 256 + tid;
+    if (row >= NP) return;
+    double a[CH_NB];
+    double* Ar = g.dense + (size_t)row * NP + kb;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) a[c] = Ar[c];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k <= c; ++k) v += a[k] * sLi[c][k];
+        Ar[c] = v;
+    }
+}
+
+// A22 -= L21 L21^T.  One wave = one 32x32 tile (2x2 MFMA tiles of 16x16, K = 32 in 8 steps of 4); workgroup = 64x64.
+// fp64 MFMA operand maps (cdna_hip_programming.md §3): A[l&15][k = l>>4], B[k = l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
+__global__ __launch_bounds__(256) void k_chol_syrk(const DeviceGraph g, const int kb) {
+    const LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
+    const int NP = g.chol_np;
+    const int t0 = kb + CH_NB;                          // first row / column of the trailing matrix
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;                                // lower triangle of 64x64 tiles
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ri = t0 + 64 * ti + 32 * (wave >> 1), rj = t0 + 64 * tj + 32 * (wave & 1);
+    if (ri >= NP || rj >= NP || rj > ri + 31) return;   // outside the matrix / strictly above the diagonal
+    const double* A = g.dense;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[u][v][q] = A[(size_t)(ri + 16 * u + lk + 4 * q) * NP + rj + 16 * v + lr];
+#pragma unroll
+    for (int s = 0; s < CH_NB / 4; ++s) {
+        const int k = kb + 4 * s + lk;
+        const double a0 = -A[(size_t)(ri + lr) * NP + k], a1 = -A[(size_t)(ri + 16 + lr) * NP + k];
+        const double b0 = A[(size_t)(rj + lr) * NP + k], b1 = A[(size_t)(rj + 16 + lr) * NP + k];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    double* Aw = g.dense;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Aw[(size_t)(ri + 16 * u + lk + 4 * q) * NP + rj + 16 * v + lr] = acc[u][v][q];
+}
+
+// Blocked forward (L y = b) and backward (L^T x = y) substitution, then K8.  One workgroup.
+__global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
+    const int NP = g.chol_np, n6 = 6 * g.Npf, tid = threadIdx.x;
+    const double* A = g.dense;
+    double* y = g.chol_y;                               // [NP] work vector
+    __shared__ double sy[CH_NB];
+    for (int t = tid; t < NP; t += 1024) y[t] = (t < n6) ? g.bs[t] : 0.0;
+    __syncthreads();
+    // ---- forward
+    for (int kb = 0; kb < NP; kb += CH_NB) {
+        if (tid < 64) {
+            const int r = tid & 31;
+            double acc = y[kb + r];
+            const double* Lr = A + (size_t)(kb + r) * NP + kb;
+            const double inv = 1.0 / Lr[r];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                const double yc = __shfl(acc * inv, c, 64);               // lane c holds the finished y_c
+                if (r > c) acc -= Lr[c] * yc;
+                if (r == c) acc = yc;
+            }
+            if (tid < 32) { sy[r] = acc; y[kb + r] = acc; }
         }
         __syncthreads();
-        if (s_fail) break;
-        const double piv = s_piv;
-        for (int i2 = k + 1 + tid; i2 < n; i2 += 1024) A[(size_t)i2 * n + k] /= piv;
-        if (tid == 0) A[(size_t)k * n + k] = piv;
-        __syncthreads();
-        const int m = n - k - 1;
-        for (int t = tid; t < m * m; t += 1024) {
-            const int ii = k + 1 + t / m, jj = k + 1 + t % m;
-            if (jj <= ii) A[(size_t)ii * n + jj] -= A[(size_t)ii * n + k] * A[(size_t)jj * n + k];
+        for (int row = kb + CH_NB + tid; row < NP; row += 1024) {
+            const double* Lr = A + (size_t)row * NP + kb;
+            double v = y[row];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) v -= Lr[c] * sy[c];
+            y[row] = v;
         }
         __syncthreads();
     }
-    if (s_fail) { if (tid == 0) st->solver_failed = 1; return; }
-    __shared__ double red[1024];
-    double* x = g.x;
-    for (int i2 = 0; i2 < n; ++i2) {
-        double acc = 0.0;
-        for (int k = tid; k < i2; k += 1024) acc += A[(size_t)i2 * n + k] * x[k];
-        red[tid] = acc;
+    // ---- backward
+    for (int kb = NP - CH_NB; kb >= 0; kb -= CH_NB) {
+        if (tid < 64) {
+            const int r = tid & 31;
+            double acc = y[kb + r];
+            const double inv = 1.0 / A[(size_t)(kb + r) * NP + kb + r];
+#pragma unroll
+            for (int c = CH_NB - 1; c >= 0; --c) {
+                const double xc = __shfl(acc * inv, c, 64);
+                if (r < c) acc -= A[(size_t)(kb + c) * NP + kb + r] * xc;   // L^T[r][c] = L[c][r]
+                if (r == c) acc = xc;
+            }
+            if (tid < 32) { sy[r] = acc; y[kb + r] = acc; }
+        }
         __syncthreads();
-        for (int s = 512; s >= 1; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-        if (tid == 0) x[i2] = (g.bs[i2] - red[0]) / A[(size_t)i2 * n + i2];
+        for (int row = tid; row < kb; row += 1024) {
+            double v = y[row];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) v -= A[(size_t)(kb + c) * NP + row] * sy[c];
+            y[row] = v;
+        }
         __syncthreads();
     }
-    for (int i2 = n - 1; i2 >= 0; --i2) {
-        double acc = 0.0;
-        for (int k = i2 + 1 + tid; k < n; k += 1024) acc += A[(size_t)k * n + i2] * x[k];
-        red[tid] = acc;
-        __syncthreads();
-        for (int s = 512; s >= 1; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-        if (tid == 0) x[i2] = (x[i2] - red[0]) / A[(size_t)i2 * n + i2];
-        __syncthreads();
-    }
+    for (int t = tid; t < n6; t += 1024) g.x[t] = y[t];
+    __syncthreads();
     const int sel = st->sel;
     for (int a = tid; a < g.Npf; a += 1024) {
         const int ip = g.free_pose[a];
         double dx[6];
-        for (int q = 0; q < 6; ++q) dx[q] = x[6 * a + q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dx[q] = y[6 * a + q];
         pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
     }
 }
@@ -1108,16 +1344,33 @@ void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) {
     hipLaunchKernelGGL(k_schur_finalize, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
 }
 
+template <int BPL, bool MREG>
+static void launch_pcg_t(const DeviceGraph& g, hipStream_t s) {
+    hipLaunchKernelGGL((k_pcg<BPL, MREG>), dim3(g.Npf), dim3(256), (size_t)g.pcg_lds_bytes, s, g);
+}
+
 void launch_pcg(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg, dim3(g.Npf), dim3(256), (size_t)g.pcg_lds_bytes, s, g);
+    if (g.Npf <= 64) launch_pcg_t<1, true>(g, s);
+    else if (g.Npf <= 128) launch_pcg_t<2, false>(g, s);
+    else launch_pcg_t<4, false>(g, s);                          // Npf <= MAX_PCG_FREE_POSES = 256
 }
 
 void launch_direct(const DeviceGraph& g, hipStream_t s) {
-    const int grid = (g.n_blk * 36 + 255) / 256;
-    const size_t n6 = (size_t)6 * g.Npf;
-    (void)hipMemsetAsync(g.dense, 0, n6 * n6 * sizeof(double), s);
-    hipLaunchKernelGGL(k_dense_assemble, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, g);
-    hipLaunchKernelGGL(k_cholesky, dim3(1), dim3(1024), 0, s, g);
+    const int NP = g.chol_np;
+    int grid = (g.n_blk * 36 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    (void)hipMemsetAsync(g.dense, 0, (size_t)NP * NP * sizeof(double), s);     // the factor fills in: clear the scratch every solve
+    hipLaunchKernelGGL(k_dense_assemble, dim3(grid), dim3(256), 0, s, g);
+    for (int kb = 0; kb < NP; kb += CH_NB) {
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, g, kb);
+        const int m = NP - kb - CH_NB;
+        if (m > 0) {
+            hipLaunchKernelGGL(k_chol_trsm, dim3((m + 255) / 256), dim3(256), 0, s, g, kb);
+            const int T = (m + 63) / 64;
+            hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, s, g, kb);
+        }
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, s, g);
 }
 
 void launch_backsub(const DeviceGraph& g, hipStream_t s) {
@@ -1154,7 +1407,9 @@ void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t
 int configure_kernels(const DeviceGraph& g) {
     // dynamic LDS above 64 KiB needs an explicit opt-in (never the case with the limits in ba_device.hpp, kept for safety)
     if (g.pcg_lds_bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg), hipFuncAttributeMaxDynamicSharedMemorySize, g.pcg_lds_bytes) != hipSuccess) return -1;
+        const void* f = g.Npf <= 64 ? reinterpret_cast<const void*>(k_pcg<1, true>) : g.Npf <= 128 ? reinterpret_cast<const void*>(k_pcg<2, false>)
+                      : reinterpret_cast<const void*>(k_pcg<4, false>);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, g.pcg_lds_bytes) != hipSuccess) return -1;
     }
     return 0;
 }
