@@ -56,9 +56,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = local_rank if world > 1 else 0
+    # rehearsal on a 1-GPU box: VISFS_BENCH_DEVICE pins every rank to one device, VISFS_BENCH_DIST_BACKEND=gloo replaces RCCL
+    if os.environ.get("VISFS_BENCH_DEVICE") is not None:
+        dev = int(os.environ["VISFS_BENCH_DEVICE"])
+    dist_backend = os.environ.get("VISFS_BENCH_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     torch.cuda.set_device(dev)
     if world > 1:
-        vdist.init_process_group("nccl", rank, world)
+        vdist.init_process_group(dist_backend, rank, world)
+    red_dev = f"cuda:{dev}" if (world > 1 and dist_backend == "nccl") else "cpu"
+    bar_dev = dev if (world > 1 and dist_backend == "nccl") else None
 
     prm = abi.default_params(iterations=args.iterations, solver=args.solver)
     lib = backend.load_library()
@@ -73,21 +79,24 @@ def main():
         solvers.append(s)
         descs.append(s.describe())
 
+    pool = None
+    if B > 1:
+        # independent windows: one host thread per resident window, each on its own HIP stream (ctypes drops the GIL),
+        # so their kernels overlap on the device — BASELINE config 5 puts 8 windows on every GPU
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=B)
+
+    def solve_one(s):
+        s.reset()
+        rc, st = s.optimize()
+        assert rc == abi.OK, rc
+        return st.iterations_run[0] + st.iterations_run[1], st
+
     def step():
-        its = 0
         if B == 1:
-            solvers[0].reset()
-            rc, st = solvers[0].optimize()
-            assert rc == abi.OK, rc
-            return st.iterations_run[0] + st.iterations_run[1], st
-        st = None
-        for s in solvers:
-            s.reset()
-        for s in solvers:          # windows are independent: each has its own stream
-            rc, st = s.optimize()
-            assert rc == abi.OK, rc
-            its += st.iterations_run[0] + st.iterations_run[1]
-        return its, st
+            return solve_one(solvers[0])
+        res = list(pool.map(solve_one, solvers))
+        return sum(r[0] for r in res), res[0][1]
 
     for _ in range(args.warmup):
         step()
@@ -101,7 +110,7 @@ def main():
     dom = max(cand, key=lambda k: calib[k]["active_ms"]) if cand else None
     # timed region: events only around the dominant kernel's launches (on the library's own stream), every 8th step
     solvers[0].profile_enable(False)
-    vdist.barrier(world, dev if world > 1 else None)
+    vdist.barrier(world, bar_dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     iters = 0
@@ -113,10 +122,10 @@ def main():
         n, last = step()
         iters += n
     torch.cuda.synchronize()
-    vdist.barrier(world, dev if world > 1 else None)
+    vdist.barrier(world, bar_dev)
     t1 = time.perf_counter()
-    elapsed = vdist.reduce_max(t1 - t0, world, f"cuda:{dev}" if world > 1 else "cpu")
-    total_iters = vdist.reduce_sum(iters, world, f"cuda:{dev}" if world > 1 else "cpu")
+    elapsed = vdist.reduce_max(t1 - t0, world, red_dev)
+    total_iters = vdist.reduce_sum(iters, world, red_dev)
 
     if rank != 0:
         return
