@@ -34,3 +34,24 @@ def build_hip(force=False, verbose=False):
         raise RuntimeError("hipcc failed:\n" + res.stderr)
     return LIB
 
+
+
+HOST = os.path.join(ROOT, "visfs_amd", "host")
+WINDOW_LIB = os.path.join(LIB_DIR, "libvisfs_window.so")
+WINDOW_SOURCES = ["WindowMap.cpp", "window_capi.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """g++ → visfs_amd/lib/libvisfs_window.so: the host-side sliding-window container (include/visfs_window.h), no GPU code."""
+    srcs = [os.path.join(HOST, s) for s in WINDOW_SOURCES]
+    deps = srcs + [os.path.join(HOST, "WindowMap.h"), os.path.join(ROOT, "include", "visfs_window.h"), os.path.join(ROOT, "include", "visfs_ba.h")]
+    if not force and not _stale(WINDOW_LIB, deps):
+        return WINDOW_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", "-o", WINDOW_LIB] + srcs
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd)); print(res.stdout); print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + res.stderr)
+    return WINDOW_LIB
