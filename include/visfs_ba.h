@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VISFS_BA_ABI_VERSION 1
+#define VISFS_BA_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 /* The reference signals failure by returning an EMPTY pose map
@@ -66,6 +66,16 @@ void visfs_ba_default_params(visfs_ba_params* p);
 /* ---- WINDOW layer: the arguments of localOptimize, flattened -------------- */
 /* 3x4 transforms are ROW-MAJOR [r00 r01 r02 tx  r10 r11 r12 ty  r20 r21 r22 tz]
  * (the top three rows of Eigen::Isometry3d::matrix()). */
+/* Map::Grid2D as EdgeOccupiedObservation reads it through GridArrayAdapter (TypeOccupiedSpace2D.h:22-48):
+ * limits (MapLimits.h:25-37) and getCorrespondenceCost(Array2i(x, y)) (Grid2d.h:33-36) for every cell, i.e. the
+ * float the reference obtains from its uint16 cells via the value table (unknown cells carry the table's entry 0). */
+typedef struct visfs_ba_grid {
+    double  resolution;           /* limits().resolution() */
+    double  max_x, max_y;         /* limits().max() */
+    int32_t num_x_cells, num_y_cells;   /* limits().cellLimits() */
+    const float* correspondence_cost;   /* [num_y_cells][num_x_cells], flat index num_x_cells * y + x (Grid2d.h:93-95) */
+} visfs_ba_grid;
+
 typedef struct visfs_ba_window {
     uint64_t root_id;             /* _rootId: pose fixed iff id == root_id (Optimizer.cpp:111) */
 
@@ -95,7 +105,11 @@ typedef struct visfs_ba_window {
     const float*    ref_v;        /* [n_refs] kpt.pt.y */
     const float*    ref_depth;    /* [n_refs] FeatureBA::depth */
 
-    int32_t  n_laser_points;      /* must be 0: laser factor is out of scope this round */
+    /* laser occupied-space factor (Optimizer.cpp:224-258): active iff n_laser_points > 0 AND grid != NULL
+     * (the reference's `!_pointClouds.empty() && _submap != nullptr`). */
+    int32_t  n_laser_points;      /* all points of all _pointClouds, concatenated in iteration order */
+    const double* laser_xyz;      /* [n_laser_points][3] RangefinderPoint::position (robot frame of the newest pose) */
+    const visfs_ba_grid* grid;    /* _submap->getGrid() */
 } visfs_ba_window;
 
 typedef struct visfs_ba_result {
@@ -132,6 +146,13 @@ typedef struct visfs_ba_graph {
     const int32_t* odo_to;        /* [n_odo] vertex(1) */
     const double*  odo_tq;        /* [n_odo][7] T_c1c2 = Trc^-1 T_r1r2 Trc as SE3Quat (Optimizer.cpp:131-140) */
     double fx, fy, cx, cy, bf;    /* EdgeStereo intrinsics (Optimizer.cpp:191-195) */
+    /* EdgeOccupiedObservation edges (Optimizer.cpp:224-258): unary on pose `laser_pose` (the newest), information
+     * 1 / laserCovariance, no robust kernel; inactive when that pose is fixed (allVerticesFixed). */
+    int32_t n_laser;
+    int32_t laser_pose;           /* index of _poses.rbegin() */
+    const double* laser_xyz;      /* [n_laser][3] */
+    const visfs_ba_grid* grid;    /* NULL iff n_laser == 0 */
+    double Tcr[12];               /* transformRobotToImage_ = getTansformImageToRobot().inverse() (TypeOccupiedSpace2D.h:81-82) */
 } visfs_ba_graph;
 
 /* Per-solve statistics of the two optimise phases (Optimizer.cpp:261-318). */

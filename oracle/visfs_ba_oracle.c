@@ -286,6 +286,114 @@ void oracle_odo_edge(const double tq1[7], const double tq2[7], const double m[7]
     }
 }
 
+/* ===================================================================== */
+/* EdgeOccupiedObservation (TypeOccupiedSpace2D.h:75-185)                     */
+/* ===================================================================== */
+#define ORACLE_K_PADDING (2147483647 / 4)            /* kPadding = INT_MAX / 4, TypeOccupiedSpace2D.h:20 */
+#define ORACLE_K_MAX_COST (1.0 - 0.1)                /* Map::kMaxCorrespondenceCost = 1 - kMinProbability, ProbabilityValues.h:41-44 */
+
+/* GridArrayAdapter::GetValue (TypeOccupiedSpace2D.h:28-37) over Grid2D::getCorrespondenceCost (Grid2d.h:33-36). */
+static double grid_value(const visfs_ba_grid* g, int row, int col) {
+    const int num_rows = g->num_y_cells + 2 * ORACLE_K_PADDING, num_cols = g->num_x_cells + 2 * ORACLE_K_PADDING;
+    if (row < ORACLE_K_PADDING || col < ORACLE_K_PADDING || row >= num_rows - ORACLE_K_PADDING || col >= num_cols - ORACLE_K_PADDING)
+        return ORACLE_K_MAX_COST;
+    const int x = col - ORACLE_K_PADDING, y = row - ORACLE_K_PADDING;      /* Array2i(column - kPadding, row - kPadding) */
+    return (double)g->correspondence_cost[g->num_x_cells * y + x];         /* toFlatIndex, Grid2d.h:93-95 */
+}
+
+/* [ceres-upstream] CubicHermiteSpline<1> (ceres/cubic_interpolation.h): Catmull-Rom, Horner form. */
+static void cubic_hermite(double p0, double p1, double p2, double p3, double x, double* f, double* dfdx) {
+    const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
+    const double b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
+    const double c = 0.5 * (-p0 + p2);
+    const double d = p1;
+    if (f) *f = d + x * (c + x * (b + x * a));
+    if (dfdx) *dfdx = c + x * (2.0 * b + 3.0 * a * x);
+}
+
+/* [ceres-upstream] BiCubicInterpolator::Evaluate(r, c, f, dfdr, dfdc): rows first, then the column spline. */
+void oracle_bicubic(const visfs_ba_grid* g, double r, double c, double* f, double* dfdr, double* dfdc) {
+    const int row = (int)floor(r), col = (int)floor(c);
+    double fr[4], dfr[4];
+    for (int i = 0; i < 4; ++i) {
+        const double p0 = grid_value(g, row - 1 + i, col - 1), p1 = grid_value(g, row - 1 + i, col);
+        const double p2 = grid_value(g, row - 1 + i, col + 1), p3 = grid_value(g, row - 1 + i, col + 2);
+        cubic_hermite(p0, p1, p2, p3, c - col, &fr[i], &dfr[i]);
+    }
+    cubic_hermite(fr[0], fr[1], fr[2], fr[3], r - row, f, dfdr);
+    if (dfdc) cubic_hermite(dfr[0], dfr[1], dfr[2], dfr[3], r - row, dfdc, NULL);
+}
+
+/* A ceres::Jet restricted to the six pose directions: value + 6 partials. */
+typedef struct { double a; double v[6]; } jet6;
+static jet6 jc(double a) { jet6 r; r.a = a; for (int i = 0; i < 6; ++i) r.v[i] = 0.0; return r; }
+static jet6 jadd(jet6 x, jet6 y) { jet6 r; r.a = x.a + y.a; for (int i = 0; i < 6; ++i) r.v[i] = x.v[i] + y.v[i]; return r; }
+static jet6 jsub(jet6 x, jet6 y) { jet6 r; r.a = x.a - y.a; for (int i = 0; i < 6; ++i) r.v[i] = x.v[i] - y.v[i]; return r; }
+static jet6 jmul(jet6 x, jet6 y) { jet6 r; r.a = x.a * y.a; for (int i = 0; i < 6; ++i) r.v[i] = x.a * y.v[i] + x.v[i] * y.a; return r; }
+static jet6 jneg(jet6 x) { jet6 r; r.a = -x.a; for (int i = 0; i < 6; ++i) r.v[i] = -x.v[i]; return r; }
+static jet6 jscale(jet6 x, double k) { jet6 r; r.a = x.a * k; for (int i = 0; i < 6; ++i) r.v[i] = x.v[i] * k; return r; }
+
+/* The functor body (TypeOccupiedSpace2D.h:97-124) on jets: Quaternion(w,x,y,z).toRotationMatrix() WITHOUT normalisation
+ * (Eigen), Tiw = [R | t], Twc = Tiw.inverse() (Isometry: R^T, -R^T t) * Tcr, Po = Twc * P, then the grid coordinates. */
+static void laser_functor(const jet6 pose[7], const double P[3], const double Tcr[12], const visfs_ba_grid* g, jet6* rr, jet6* cc) {
+    const jet6 w = pose[6], x = pose[3], y = pose[4], z = pose[5];
+    const jet6 tx = jscale(x, 2.0), ty = jscale(y, 2.0), tz = jscale(z, 2.0);
+    const jet6 twx = jmul(tx, w), twy = jmul(ty, w), twz = jmul(tz, w);
+    const jet6 txx = jmul(tx, x), txy = jmul(ty, x), txz = jmul(tz, x);
+    const jet6 tyy = jmul(ty, y), tyz = jmul(tz, y), tzz = jmul(tz, z);
+    const jet6 one = jc(1.0);
+    jet6 R[9];
+    R[0] = jsub(one, jadd(tyy, tzz)); R[1] = jsub(txy, twz);            R[2] = jadd(txz, twy);
+    R[3] = jadd(txy, twz);            R[4] = jsub(one, jadd(txx, tzz)); R[5] = jsub(tyz, twx);
+    R[6] = jsub(txz, twy);            R[7] = jadd(tyz, twx);            R[8] = jsub(one, jadd(txx, tyy));
+    /* inverse: linear = R^T, translation = -(R^T t) */
+    jet6 Ri[9], ti[3];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Ri[3 * r + c] = R[3 * c + r];
+    for (int r = 0; r < 3; ++r)
+        ti[r] = jneg(jadd(jadd(jmul(Ri[3 * r], pose[0]), jmul(Ri[3 * r + 1], pose[1])), jmul(Ri[3 * r + 2], pose[2])));
+    /* Twc = inverse * Tcr */
+    jet6 L[9], T[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            L[3 * r + c] = jadd(jadd(jscale(Ri[3 * r], Tcr[c]), jscale(Ri[3 * r + 1], Tcr[4 + c])), jscale(Ri[3 * r + 2], Tcr[8 + c]));
+        T[r] = jadd(jadd(jadd(jscale(Ri[3 * r], Tcr[3]), jscale(Ri[3 * r + 1], Tcr[7])), jscale(Ri[3 * r + 2], Tcr[11])), ti[r]);
+    }
+    jet6 Po[2];
+    for (int r = 0; r < 2; ++r)
+        Po[r] = jadd(jadd(jadd(jscale(L[3 * r], P[0]), jscale(L[3 * r + 1], P[1])), jscale(L[3 * r + 2], P[2])), T[r]);
+    /* (max - Po) / resolution - 0.5 + kPadding, TypeOccupiedSpace2D.h:115-118 */
+    const double pad = (double)ORACLE_K_PADDING;
+    jet6 dx = jsub(jc(g->max_x), Po[0]), dy = jsub(jc(g->max_y), Po[1]);
+    jet6 qx, qy;
+    qx.a = dx.a / g->resolution; qy.a = dy.a / g->resolution;            /* Jet / double divides value and partials */
+    for (int i = 0; i < 6; ++i) { qx.v[i] = dx.v[i] / g->resolution; qy.v[i] = dy.v[i] / g->resolution; }
+    *rr = jadd(jsub(qx, jc(0.5)), jc(pad));
+    *cc = jadd(jsub(qy, jc(0.5)), jc(pad));
+}
+
+/* computeError (TypeOccupiedSpace2D.h:126-131) and linearizeOplus (:145-179).
+ * The reference differentiates with ceres::internal::AutoDifferentiate over StaticParameterDims<6, 3>: the pose block
+ * holds SIX jets (t1 t2 t3 qx qy qz) and the functor's `pose[6]` therefore reads the next jet in the array — the first
+ * coordinate of the range point.  The Jacobian the reference uses is that of the functor with q.w := point.x (no
+ * normalisation), taken w.r.t. (t, qx, qy, qz) and fed to the 6-dof oplus as is.  Reproduced here; the error itself
+ * (computeError) uses the true 7-vector. */
+void oracle_laser_edge(const double tq[7], const double Tcr[12], const double P[3], const visfs_ba_grid* g, double* e, double J[6]) {
+    jet6 pose[7], r, c;
+    if (e) {
+        for (int i = 0; i < 7; ++i) pose[i] = jc(tq[i]);
+        laser_functor(pose, P, Tcr, g, &r, &c);
+        oracle_bicubic(g, r.a, c.a, e, NULL, NULL);
+    }
+    if (J) {
+        for (int i = 0; i < 6; ++i) { pose[i] = jc(tq[i]); pose[i].v[i] = 1.0; }
+        pose[6] = jc(P[0]);                                               /* the aliasing described above */
+        laser_functor(pose, P, Tcr, g, &r, &c);
+        double f, dfdr, dfdc;
+        oracle_bicubic(g, r.a, c.a, &f, &dfdr, &dfdc);
+        for (int i = 0; i < 6; ++i) J[i] = dfdr * r.v[i] + dfdc * c.v[i];  /* BiCubicInterpolator::Evaluate(JetT) */
+    }
+}
+
 void oracle_huber(double e2, double delta, double rho[2]) {
     /* [g2o-upstream] RobustKernelHuber::robustify */
     const double dsqr = delta * delta;
@@ -376,6 +484,12 @@ int oracle_pack_window(const visfs_ba_params* params, const visfs_ba_window* w,
     g->odo_from = odo_from; g->odo_to = odo_to; g->odo_tq = odo_tq;
     g->fx = w->fx; g->fy = w->fy; g->cx = w->cx; g->cy = w->cy;
     g->bf = ((w->n_cameras > 1) ? (double)w->baseline : 0.0) * w->fx;    /* :195 */
+    /* range points: Optimizer.cpp:225-258 — every point of every cloud hangs off the newest pose */
+    if (w->n_laser_points > 0 && w->grid != NULL && w->laser_xyz != NULL) {
+        g->n_laser = w->n_laser_points; g->laser_pose = w->n_poses - 1;
+        g->laser_xyz = w->laser_xyz; g->grid = w->grid;
+    }
+    memcpy(g->Tcr, Tcr, 96);
     return VISFS_BA_OK;
 }
 
@@ -403,6 +517,11 @@ struct oracle_sys {
     uint8_t *pose_fixed, *pt_fixed;
     int32_t *obs_pt, *obs_pose, *odo_i, *odo_j;
     double *obs_uvr, *odo_tq;
+    /* laser occupied-space edges (owned copies) */
+    int Nz, laser_pose;
+    double *laser_xyz, Tcr[12];
+    visfs_ba_grid grid;
+    float *grid_cost;
     int *pose_idx;              /* free index or -1 (hessianIndex) */
     int *lm_ptr;                /* CSR over obs by landmark */
     /* estimates */
@@ -440,6 +559,17 @@ oracle_sys* oracle_sys_create(const visfs_ba_params* prm, const visfs_ba_graph* 
     s->obs_uvr = xcalloc((size_t)No * 3, 8); memcpy(s->obs_uvr, g->obs_uvr, (size_t)No * 24);
     s->odo_i = xcalloc(Ne, 4); s->odo_j = xcalloc(Ne, 4); s->odo_tq = xcalloc((size_t)Ne * 7, 8);
     if (Ne) { memcpy(s->odo_i, g->odo_from, (size_t)Ne * 4); memcpy(s->odo_j, g->odo_to, (size_t)Ne * 4); memcpy(s->odo_tq, g->odo_tq, (size_t)Ne * 56); }
+    /* laser edges are active only if their pose is free (allVerticesFixed otherwise: the range points are fixed) */
+    s->Nz = 0;
+    if (g->n_laser > 0 && g->grid && g->laser_pose >= 0 && g->laser_pose < Np && !g->pose_fixed[g->laser_pose]) {
+        s->Nz = g->n_laser; s->laser_pose = g->laser_pose;
+        s->laser_xyz = xcalloc((size_t)s->Nz * 3, 8); memcpy(s->laser_xyz, g->laser_xyz, (size_t)s->Nz * 24);
+        memcpy(s->Tcr, g->Tcr, 96);
+        s->grid = *g->grid;
+        const size_t cells = (size_t)g->grid->num_x_cells * g->grid->num_y_cells;
+        s->grid_cost = xcalloc(cells, 4); memcpy(s->grid_cost, g->grid->correspondence_cost, cells * 4);
+        s->grid.correspondence_cost = s->grid_cost;
+    }
     /* buildIndexMapping: non-fixed poses in id (= index) order */
     s->pose_idx = xcalloc(Np, sizeof(int));
     int npf = 0;
@@ -483,6 +613,7 @@ void oracle_sys_destroy(oracle_sys* s) {
     free(s->err); free(s->chi2); free(s->wgt); free(s->W); free(s->Hll); free(s->bl); free(s->Hpp); free(s->bp);
     free(s->odo_err); free(s->Dinv); free(s->S); free(s->bs); free(s->chol); free(s->dxp); free(s->dxl);
     free(s->pcg_r); free(s->pcg_d); free(s->pcg_q); free(s->pcg_s); free(s->pcg_J); free(s->final_chi2); free(s->outlier);
+    free(s->laser_xyz); free(s->grid_cost);
     free(s);
 }
 
@@ -519,6 +650,13 @@ static double active_robust_chi2(oracle_sys* s, const double* pose, const double
         double c = 0.0;
         for (int d = 0; d < 6; ++d) c += e[d] * (inv_cov * e[d]);
         total += c;
+    }
+    /* laser edges: information 1 / laserCovariance, no robust kernel (Optimizer.cpp:232,244-249) */
+    const double inv_laser = 1.0 / s->prm.laser_covariance;
+    for (int k = 0; k < s->Nz; ++k) {
+        double e;
+        oracle_laser_edge(pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, NULL);
+        total += e * (inv_laser * e);
     }
     return total;
 }
@@ -612,6 +750,15 @@ void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag) 
             hpp_add(s, a, b, Ji, Jj, 6, inv_cov);
             hpp_add(s, b, a, Jj, Ji, 6, inv_cov);
         }
+    }
+    /* laser edges: the range point is fixed, only the pose block receives J^T Omega J and -J^T Omega e */
+    const double inv_laser = 1.0 / s->prm.laser_covariance;
+    for (int k = 0; k < s->Nz; ++k) {
+        double e, J[6];
+        oracle_laser_edge(s->pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, J);
+        const int a = s->pose_idx[s->laser_pose];
+        hpp_add(s, a, a, J, J, 1, inv_laser);
+        for (int r = 0; r < 6; ++r) s->bp[6 * a + r] -= J[r] * inv_laser * e;
     }
     /* computeLambdaInit's maxDiagonal over pose and landmark diagonals [g2o-upstream] */
     double md = 0.0;
@@ -974,7 +1121,7 @@ int oracle_solve_window(const visfs_ba_params* prm, const visfs_ba_window* w, vi
     r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
     r->iterations_run[0] = r->iterations_run[1] = 0;
     r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
-    if (prm->framework != 0 || w->n_laser_points != 0) return r->status = VISFS_BA_ERR_UNSUPPORTED;
+    if (prm->framework != 0) return r->status = VISFS_BA_ERR_UNSUPPORTED;
     /* guards: Optimizer.cpp:74, 360-364 */
     if (!(w->n_poses >= 2 && prm->iterations > 0 && w->pose_ids[0] > 0)) {
         if (w->n_poses == 1 || prm->iterations <= 0) {

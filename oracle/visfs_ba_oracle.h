@@ -38,6 +38,10 @@ void oracle_stereo_edge(const double tq[7], const double pw[3], const double uvr
 /* EdgePoseConstraint::computeError + linearizeOplus (OptimizeTypeDefine.cpp:35-88). Ji,Jj 6x6 row-major. */
 void oracle_odo_edge(const double tq1[7], const double tq2[7], const double meas_tq[7],
                      double e[6], double Ji[36], double Jj[36]);
+/* EdgeOccupiedObservation::computeError / linearizeOplus (TypeOccupiedSpace2D.h:126-179) incl. the reference's
+ * autodiff parameter aliasing (see the .c file); [ceres-upstream] bicubic interpolation.  J is 1x6, either may be NULL. */
+void oracle_laser_edge(const double tq[7], const double Tcr[12], const double P[3], const visfs_ba_grid* g, double* e, double J[6]);
+void oracle_bicubic(const visfs_ba_grid* g, double r, double c, double* f, double* dfdr, double* dfdc);
 /* RobustKernelHuber::robustify [g2o-upstream]: rho[0]=rho(e2), rho[1]=rho'(e2). */
 void oracle_huber(double e2, double delta, double rho[2]);
 

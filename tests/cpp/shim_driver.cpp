@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: shim_driver in.bin out.bin [Key=Value ...]\n"); return 2; }
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;
-    auto hdr = rd<int64_t>(f, 7);      // root_id n_poses n_links n_points n_refs n_cameras with_laser_stub
+    auto hdr = rd<int64_t>(f, 7);      // root_id n_poses n_links n_points n_refs n_cameras n_laser
     auto cam = rd<double>(f, 5);       // fx fy cx cy baseline
     auto trc = rd<double>(f, 12);
     const size_t Np = hdr[1], Nk = hdr[2], Nl = hdr[3], Nr = hdr[4];
@@ -30,6 +30,9 @@ int main(int argc, char** argv) {
     auto pid = rd<uint64_t>(f, Nl); auto pxyz = rd<double>(f, Nl * 3); auto pfix = rd<uint8_t>(f, Nl);
     auto rf = rd<uint64_t>(f, Nr); auto rp = rd<uint64_t>(f, Nr);
     auto ru = rd<float>(f, Nr); auto rv = rd<float>(f, Nr); auto rdep = rd<float>(f, Nr);
+    // laser part: resolution max_x max_y | nx ny | cost[ny][nx] | xyz[n_laser][3]
+    std::vector<double> glim, lxyz; std::vector<int64_t> gdim; std::vector<float> gcost;
+    if (hdr[6] > 0) { glim = rd<double>(f, 3); gdim = rd<int64_t>(f, 2); gcost = rd<float>(f, (size_t)(gdim[0] * gdim[1])); lxyz = rd<double>(f, (size_t)hdr[6] * 3); }
     std::fclose(f);
 
     VISFS::ParametersMap prm;
@@ -53,7 +56,13 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < Nr; ++i) refs[rf[i]].emplace(rp[i], VISFS::Optimizer::FeatureBA(cv::KeyPoint(ru[i], rv[i], 1.f), rdep[i]));
     std::vector<VISFS::Sensor::PointCloud> clouds;
     std::shared_ptr<const VISFS::Map::Submap2D> submap;
-    if (hdr[6]) { clouds.resize(1); clouds[0].pts_.resize(3); submap = std::make_shared<VISFS::Map::Submap2D>(); }
+    if (hdr[6] > 0) {
+        clouds.resize(2);                                 // two clouds: the factor concatenates them (Optimizer.cpp:235)
+        for (int64_t i = 0; i < hdr[6]; ++i) { VISFS::Sensor::RangefinderPoint p; p.position = Eigen::Vector3d(lxyz[3 * i], lxyz[3 * i + 1], lxyz[3 * i + 2]); clouds[i < hdr[6] / 2 ? 0 : 1].pts_.push_back(p); }
+        VISFS::Map::CellLimits cl; cl.numXcells = (int)gdim[0]; cl.numYcells = (int)gdim[1];
+        auto grid = std::make_shared<VISFS::Map::Grid2D>(VISFS::Map::MapLimits(glim[0], Eigen::Vector2d(glim[1], glim[2]), cl), gcost);
+        submap = std::make_shared<VISFS::Map::Submap2D>(grid);
+    }
     std::vector<std::tuple<std::size_t, std::size_t>> outliers;
     outliers.emplace_back(123456, 654321);          // pre-existing entry: localOptimize must APPEND
 

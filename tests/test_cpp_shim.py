@@ -26,16 +26,23 @@ def driver(tmp_path_factory, hiplib):
     return exe
 
 
-def dump_window(path, w, laser=False):
+def dump_window(path, w):
+    n_laser = len(w.get("laser_xyz", [])) if w.get("grid") is not None else 0
     with open(path, "wb") as f:
         f.write(np.array([w["root_id"], len(w["pose_ids"]), len(w["link_from"]), len(w["point_ids"]), len(w["ref_feature"]),
-                          w.get("n_cameras", 2), int(laser)], np.int64).tobytes())
+                          w.get("n_cameras", 2), n_laser], np.int64).tobytes())
         f.write(np.array([w["fx"], w["fy"], w["cx"], w["cy"], np.float64(np.float32(w["baseline"]))], np.float64).tobytes())
         f.write(np.asarray(w["Trc"], np.float64).reshape(12).tobytes())
         for k, dt in (("pose_ids", np.uint64), ("pose_Twr", np.float64), ("link_from", np.uint64), ("link_to", np.uint64), ("link_T", np.float64),
                       ("point_ids", np.uint64), ("point_xyz", np.float64), ("point_fixed", np.uint8), ("ref_feature", np.uint64),
                       ("ref_pose", np.uint64), ("ref_u", np.float32), ("ref_v", np.float32), ("ref_depth", np.float32)):
             f.write(np.ascontiguousarray(w[k], dtype=dt).tobytes())
+        if n_laser:
+            g = w["grid"]
+            f.write(np.array([g["resolution"], g["max_x"], g["max_y"]], np.float64).tobytes())
+            f.write(np.array([g["cost"].shape[1], g["cost"].shape[0]], np.int64).tobytes())
+            f.write(np.ascontiguousarray(g["cost"], np.float32).tobytes())
+            f.write(np.ascontiguousarray(w["laser_xyz"], np.float64).tobytes())
 
 
 def read_result(path):
@@ -88,13 +95,31 @@ def test_shim_matches_oracle_through_the_reference_signature(driver, olib, tmp_p
 
 
 @pytest.mark.gpu
+def test_shim_laser_factor_matches_the_c_abi(driver, tmp_path):
+    """Point clouds + Submap2D through the reference's signature (Optimizer.cpp:225-258) == the flat window through the C ABI."""
+    from visfs_amd import backend
+    w = synth.make_laser_window(with_visual=True, n_points=400, seed=2)
+    dump_window(tmp_path / "in.bin", w)
+    subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Iterations=10", "Optimizer/Solver=2"], check=True, capture_output=True)
+    status, poses, pts, outl = read_result(tmp_path / "out.bin")
+    s = backend.Solver(abi.default_params(iterations=10, solver=2))
+    wb = abi.WindowBuffers(w)
+    rc, rb = s.solve_window(wb)
+    s.close()
+    assert status == rc == abi.OK and sorted(poses) == [int(i) for i in w["pose_ids"]]
+    assert np.array_equal(np.array([poses[k] for k in sorted(poses)]), rb.pose_Twr_out[:len(poses)])
+    assert outl[1:] == rb.outliers()
+    # and the factor was really there
+    w2 = dict(w); w2["grid"] = None
+    dump_window(tmp_path / "in.bin", w2)
+    subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Iterations=10", "Optimizer/Solver=2"], check=True, capture_output=True)
+    _, poses2, _, _ = read_result(tmp_path / "out.bin")
+    assert not np.array_equal(np.array([poses2[k] for k in sorted(poses2)]), rb.pose_Twr_out[:len(poses)])
+
+
+@pytest.mark.gpu
 def test_shim_error_convention(driver, tmp_path):
     w = synth.make_window("PROD")
-    # laser inputs present → the factor would be built by the reference; this backend reports UNSUPPORTED and returns an empty map
-    dump_window(tmp_path / "in.bin", w, laser=True)
-    subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Iterations=10"], check=True, capture_output=True)
-    status, poses, pts, outl = read_result(tmp_path / "out.bin")
-    assert status == abi.ERR_UNSUPPORTED and poses == {}
     # Ceres framework is not implemented
     dump_window(tmp_path / "in.bin", w)
     subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Framework=1"], check=True, capture_output=True)

@@ -170,6 +170,94 @@ def test_odometry_edge_zero_residual_and_jacobians(olib):
 
 
 # ---------------------------------------------------------------- graph build
+# ---------------------------------------------------------------- laser occupied-space factor
+PAD = 2147483647 // 4
+
+
+def _bicubic(olib, gb, r, c):
+    f, dr, dc = C.c_double(), C.c_double(), C.c_double()
+    olib.oracle_bicubic(C.byref(gb.struct), C.c_double(r), C.c_double(c), C.byref(f), C.byref(dr), C.byref(dc))
+    return f.value, dr.value, dc.value
+
+
+def _laser_coords(tq, w, Tcr, P, g, pad=PAD):
+    """numpy restatement of the functor's geometry (TypeOccupiedSpace2D.h:97-118) for quaternion (x, y, z, w) used raw."""
+    x, y, z = tq[3:6]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    Tcr = np.asarray(Tcr).reshape(3, 4)
+    Po = R.T @ (Tcr[:, :3] @ P + Tcr[:, 3] - tq[:3])
+    return (g["max_x"] - Po[0]) / g["resolution"] - 0.5 + pad, (g["max_y"] - Po[1]) / g["resolution"] - 0.5 + pad
+
+
+def _laser_setup(olib):
+    olib.oracle_bicubic.argtypes = [C.POINTER(abi.Grid), C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 3
+    olib.oracle_bicubic.restype = None
+    olib.oracle_laser_edge.argtypes = [C.POINTER(C.c_double)] * 3 + [C.POINTER(abi.Grid)] + [C.POINTER(C.c_double)] * 2
+    olib.oracle_laser_edge.restype = None
+
+
+def test_bicubic_interpolator_properties(olib):
+    """[ceres-upstream] BiCubicInterpolator over GridArrayAdapter: exact at cell centres, C1 across cell borders, the
+    analytic derivatives match central differences, 0.9 outside the padded grid (TypeOccupiedSpace2D.h:28-37)."""
+    _laser_setup(olib)
+    g = synth.make_grid(); gb = abi.GridBuffers(g)
+    for row, col in ((14, 70), (100, 120), (0, 0), (199, 239)):
+        assert _bicubic(olib, gb, PAD + float(row), PAD + float(col))[0] == float(g["cost"][row, col])
+    assert _bicubic(olib, gb, PAD - 10.0, PAD + 5.0) == (0.9, 0.0, 0.0)
+    r, c, h = PAD + 14.3, PAD + 70.6, 2.0 ** -12       # coordinates ~5e8: steps must be exactly representable
+    f, dr, dc = _bicubic(olib, gb, r, c)
+    assert abs(dr - (_bicubic(olib, gb, r + h, c)[0] - _bicubic(olib, gb, r - h, c)[0]) / (2 * h)) < 1e-5
+    assert abs(dc - (_bicubic(olib, gb, r, c + h)[0] - _bicubic(olib, gb, r, c - h)[0]) / (2 * h)) < 1e-5
+    e = 2.0 ** -20
+    lo, hi = _bicubic(olib, gb, PAD + 15.0 - e, c), _bicubic(olib, gb, PAD + 15.0 + e, c)
+    assert abs(lo[0] - hi[0]) < 1e-6 and abs(lo[1] - hi[1]) < 1e-4 and abs(lo[2] - hi[2]) < 1e-4
+
+
+def test_laser_edge_error_and_aliased_jacobian(olib):
+    """computeError uses the true pose; linearizeOplus differentiates the functor with q.w aliased to the range point's x
+    (ceres autodiff over StaticParameterDims<6, 3>, TypeOccupiedSpace2D.h:145-179): the restated Jacobian must equal
+    central differences of THAT function, and in general differ from the derivative of the error itself."""
+    _laser_setup(olib)
+    w = synth.make_laser_window()
+    wb, gb, _, _, _ = graph_of(olib.oracle_pack_window, abi.default_params(), w)
+    g = w["grid"]; Tcr = np.array(list(gb.struct.Tcr)); tq = gb.pose_tq[-1].copy()
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    checked = 0
+    for k in range(0, len(wb.laser_xyz), 7):
+        P = wb.laser_xyz[k].copy(); e = C.c_double(); J = np.zeros(6)
+        olib.oracle_laser_edge(p(tq), p(Tcr), p(P), C.byref(wb.grid.struct), C.byref(e), p(J))
+        r, c = _laser_coords(tq, tq[6], Tcr, P, g)
+        assert abs(e.value - _bicubic(olib, wb.grid, r, c)[0]) < 1e-6
+        ra, ca = _laser_coords(tq, P[0], Tcr, P, g)
+        if not (PAD + 3 < ra < PAD + g["cost"].shape[0] - 3 and PAD + 3 < ca < PAD + g["cost"].shape[1] - 3):
+            continue                                       # aliased point falls outside the grid: constant cost, zero Jacobian
+        f, dfr, dfc = _bicubic(olib, wb.grid, ra, ca)
+        Jfd = np.zeros(6)
+        for i in range(6):
+            h = 1e-6
+            tp, tm = tq.copy(), tq.copy(); tp[i] += h; tm[i] -= h
+            # differences taken without the 5e8 padding offset, which would quantise them to 6e-8
+            rp, cp = _laser_coords(tp, P[0], Tcr, P, g, 0.0); rm, cm = _laser_coords(tm, P[0], Tcr, P, g, 0.0)
+            Jfd[i] = dfr * (rp - rm) / (2 * h) + dfc * (cp - cm) / (2 * h)
+        assert np.abs(J - Jfd).max() <= 1e-5 * max(1.0, np.abs(Jfd).max())
+        checked += 1
+    assert checked >= 5
+
+
+def test_laser_factor_enters_the_objective(olib):
+    w = synth.make_laser_window(with_visual=True)
+    prm = abi.default_params(iterations=10, solver=0)
+    wb = abi.WindowBuffers(w); rb = abi.ResultBuffers(6, wb.struct.n_refs)
+    assert olib.oracle_solve_window(C.byref(prm), C.byref(wb.struct), C.byref(rb.struct), 1) == abi.OK
+    w2 = dict(w); w2["grid"] = None
+    wb2 = abi.WindowBuffers(w2); rb2 = abi.ResultBuffers(6, wb2.struct.n_refs)
+    assert olib.oracle_solve_window(C.byref(prm), C.byref(wb2.struct), C.byref(rb2.struct), 1) == abi.OK
+    # ~720 points with cost ~0.13 each at information 1 / 0.1
+    assert 50.0 < rb.struct.chi2_final - rb2.struct.chi2_final < 400.0
+
+
 def test_pack_window_matches_hand_computation(olib):
     w = synth.make_window("C1")
     prm = abi.default_params()

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_TRACE = 64
 
 # status codes (include/visfs_ba.h)
@@ -41,6 +41,24 @@ def default_params(**kw):
     return p
 
 
+class Grid(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("max_x", C.c_double), ("max_y", C.c_double),
+                ("num_x_cells", C.c_int32), ("num_y_cells", C.c_int32), ("correspondence_cost", _pf)]
+
+
+class GridBuffers:
+    """Owns the float cost array behind a `Grid` struct.  g: dict(resolution, max_x, max_y, cost[num_y][num_x])."""
+
+    def __init__(self, g):
+        self.cost = _arr(g["cost"], np.float32)
+        assert self.cost.ndim == 2
+        s = Grid()
+        s.resolution, s.max_x, s.max_y = float(g["resolution"]), float(g["max_x"]), float(g["max_y"])
+        s.num_y_cells, s.num_x_cells = self.cost.shape
+        s.correspondence_cost = _ptr(self.cost, C.c_float)
+        self.struct = s
+
+
 class Window(C.Structure):
     _fields_ = [("root_id", C.c_uint64),
                 ("n_poses", C.c_int32), ("pose_ids", _pu64), ("pose_Twr", _pd),
@@ -50,7 +68,7 @@ class Window(C.Structure):
                 ("n_points", C.c_int32), ("point_ids", _pu64), ("point_xyz", _pd), ("point_fixed", _pu8),
                 ("n_refs", C.c_int32), ("ref_feature", _pu64), ("ref_pose", _pu64),
                 ("ref_u", _pf), ("ref_v", _pf), ("ref_depth", _pf),
-                ("n_laser_points", C.c_int32)]
+                ("n_laser_points", C.c_int32), ("laser_xyz", _pd), ("grid", C.POINTER(Grid))]
 
 
 class Result(C.Structure):
@@ -67,7 +85,9 @@ class Graph(C.Structure):
                 ("pose_tq", _pd), ("pose_fixed", _pu8), ("point_xyz", _pd), ("point_fixed", _pu8),
                 ("obs_point", _pi32), ("obs_pose", _pi32), ("obs_uvr", _pd),
                 ("odo_from", _pi32), ("odo_to", _pi32), ("odo_tq", _pd),
-                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("n_laser", C.c_int32), ("laser_pose", C.c_int32), ("laser_xyz", _pd), ("grid", C.POINTER(Grid)),
+                ("Tcr", C.c_double * 12)]
 
 
 K_NAMES = ["k_linearize", "k_lin_finalize", "k_schur_partial", "k_schur_finalize", "k_pcg", "k_direct", "k_backsub",
@@ -136,7 +156,13 @@ class WindowBuffers:
         s.n_refs = len(self.ref_feature); s.ref_feature = _ptr(self.ref_feature, C.c_uint64)
         s.ref_pose = _ptr(self.ref_pose, C.c_uint64); s.ref_u = _ptr(self.ref_u, C.c_float)
         s.ref_v = _ptr(self.ref_v, C.c_float); s.ref_depth = _ptr(self.ref_depth, C.c_float)
-        s.n_laser_points = int(w.get("n_laser_points", 0))
+        self.laser_xyz = _arr(w.get("laser_xyz", np.zeros((0, 3))), np.float64).reshape(-1, 3)
+        s.n_laser_points = int(w.get("n_laser_points", len(self.laser_xyz)))
+        if len(self.laser_xyz):
+            s.laser_xyz = _ptr(self.laser_xyz, C.c_double)
+        self.grid = GridBuffers(w["grid"]) if w.get("grid") is not None else None
+        if self.grid is not None:
+            s.grid = C.pointer(self.grid.struct)
         self.struct = s
 
 
@@ -167,7 +193,7 @@ class GraphBuffers:
     """Flat factor graph (camera-frame) as numpy arrays + the `Graph` struct over them."""
 
     def __init__(self, pose_tq, pose_fixed, point_xyz, point_fixed, obs_point, obs_pose, obs_uvr,
-                 odo_from, odo_to, odo_tq, fx, fy, cx, cy, bf):
+                 odo_from, odo_to, odo_tq, fx, fy, cx, cy, bf, laser_xyz=None, laser_pose=0, grid=None, Tcr=None):
         self.pose_tq = _arr(pose_tq, np.float64).reshape(-1, 7)
         self.pose_fixed = _arr(pose_fixed, np.uint8)
         self.point_xyz = _arr(point_xyz, np.float64).reshape(-1, 3)
@@ -188,6 +214,15 @@ class GraphBuffers:
         g.odo_from = _ptr(self.odo_from, C.c_int32); g.odo_to = _ptr(self.odo_to, C.c_int32)
         g.odo_tq = _ptr(self.odo_tq, C.c_double)
         g.fx, g.fy, g.cx, g.cy, g.bf = float(fx), float(fy), float(cx), float(cy), float(bf)
+        # laser occupied-space edges: grid is a GridBuffers (kept alive here) or None
+        self.laser_xyz = _arr(laser_xyz if laser_xyz is not None else np.zeros((0, 3)), np.float64).reshape(-1, 3)
+        self.grid = grid
+        if grid is not None and len(self.laser_xyz):
+            g.n_laser = len(self.laser_xyz); g.laser_pose = int(laser_pose)
+            g.laser_xyz = _ptr(self.laser_xyz, C.c_double); g.grid = C.pointer(grid.struct)
+        tcr = _arr(Tcr if Tcr is not None else [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64).reshape(12)
+        for i in range(12):
+            g.Tcr[i] = tcr[i]
         self.struct = g
 
     @property
@@ -220,7 +255,9 @@ def pack_window_with(lib_pack, params, wb):
         raise RuntimeError(f"pack_window failed: status {rc}")
     no, ne = g.n_obs, g.n_odo
     gb = GraphBuffers(pose_tq, pose_fixed, wb.point_xyz, wb.point_fixed, op[:no], oc[:no], uvr[:no],
-                      of[:ne], ot[:ne], otq[:ne], g.fx, g.fy, g.cx, g.cy, g.bf)
+                      of[:ne], ot[:ne], otq[:ne], g.fx, g.fy, g.cx, g.cy, g.bf,
+                      laser_xyz=wb.laser_xyz if g.n_laser else None, laser_pose=g.laser_pose, grid=wb.grid if g.n_laser else None,
+                      Tcr=list(g.Tcr))
     return gb, used[:Nl].copy(), oref[:no].copy(), mono.value
 
 

@@ -139,6 +139,18 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     for (int e = 0; e < Ne; ++e)
         if (gr->odo_from[e] < 0 || gr->odo_from[e] >= Np || gr->odo_to[e] < 0 || gr->odo_to[e] >= Np || gr->odo_from[e] == gr->odo_to[e])
             return bad(h, "odometry edge index out of range");
+    // laser occupied-space edges (Optimizer.cpp:224-258): active only while their pose is free (allVerticesFixed otherwise)
+    int Nz = 0;
+    size_t grid_cells = 0;
+    if (gr->n_laser < 0) return bad(h, "negative sizes");
+    if (gr->n_laser > 0) {
+        if (!gr->grid || !gr->laser_xyz) return bad(h, "laser points need a grid and coordinates");
+        const visfs_ba_grid& G = *gr->grid;
+        if (gr->laser_pose < 0 || gr->laser_pose >= Np) return bad(h, "laser pose index out of range");
+        if (!(G.resolution > 0.0) || G.num_x_cells <= 0 || G.num_y_cells <= 0 || !G.correspondence_cost) return bad(h, "invalid grid");
+        if ((int64_t)G.num_x_cells * G.num_y_cells > (int64_t)1 << 28) { h->err = "grid larger than 2^28 cells"; return VISFS_BA_ERR_UNSUPPORTED; }
+        if (!gr->pose_fixed[gr->laser_pose]) { Nz = gr->n_laser; grid_cells = (size_t)G.num_x_cells * G.num_y_cells; }
+    }
     int rc = ws_init(h, w);
     if (rc != VISFS_BA_OK) return rc;
 
@@ -181,6 +193,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
             if (a >= 0) inc[a].push_back(2 * e);
             if (b >= 0) inc[b].push_back(2 * e + 1);
         }
+        // the laser edges' aggregate lives in slot Ne of odo_blk as the "from" side of a pseudo edge (added last, as g2o does)
+        if (Nz > 0) inc[pose_free[gr->laser_pose]].push_back(2 * Ne);
         for (int a = 0; a < Npf; ++a) { pose_odo_ptr[a] = (int32_t)pose_odo.size(); pose_odo.insert(pose_odo.end(), inc[a].begin(), inc[a].end()); }
         pose_odo_ptr[Npf] = (int32_t)pose_odo.size();
     }
@@ -343,6 +357,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.row_ptr = A.take<int32_t>(Npf + 1);
         g.row_col = A.take<int32_t>(std::max<size_t>(row_col.size(), 1));
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
+        g.laser_xyz = A.take<double>((size_t)std::max(Nz, 1) * 3);
+        g.grid.cost = A.take<float>(std::max<size_t>(grid_cells, 1));
     };
     DeviceGraph hg{};                 // pointers into the pinned staging arena
     Arena sizing{ nullptr, 0, 0 };
@@ -365,7 +381,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
         g.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
-        g.odo_blk = A.take<double>((size_t)std::max(Ne, 1) * 120);
+        g.odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
         g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.bp = A.take<double>(std::max<size_t>(n6, 1));
         g.lin_part = A.take<double>((size_t)n_parts * 2);
@@ -437,6 +453,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (!blk_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.blk_odo), blk_odo.data(), blk_odo.size() * 4);
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
+        if (Nz) {
+            std::memcpy(const_cast<double*>(hg.laser_xyz), gr->laser_xyz, (size_t)Nz * 24);
+            std::memcpy(const_cast<float*>(hg.grid.cost), gr->grid->correspondence_cost, grid_cells * 4);
+        }
     }
     // device pointers: same offsets
     Arena ds{ w.d_base, w.d_cap, 0 };
@@ -450,6 +470,11 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
     dg.huber_delta = prm.robust_kernel_delta;             // Optimizer.cpp:212-216
+    dg.Nz = Nz; dg.laser_pose = Nz ? gr->laser_pose : 0;
+    dg.inv_laser_cov = 1.0 / prm.laser_covariance;        // Optimizer.cpp:232
+    std::memcpy(dg.Tcr, gr->Tcr, 96);
+    if (Nz) { dg.grid.nx = gr->grid->num_x_cells; dg.grid.ny = gr->grid->num_y_cells; dg.grid.resolution = gr->grid->resolution;
+              dg.grid.max_x = gr->grid->max_x; dg.grid.max_y = gr->grid->max_y; }
     dg.debug = 0;
     { const char* e = std::getenv("VISFS_BA_STAMP_WG"); dg.stamp_wg = e ? std::atoi(e) : 0; }
     w.g = dg;
@@ -591,7 +616,7 @@ int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win
     r->iterations_run[0] = r->iterations_run[1] = 0;
     r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
     if (prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return r->status = VISFS_BA_ERR_UNSUPPORTED; }
-    if (win->n_laser_points != 0) { h->err = "laser occupied-space factor is out of scope"; return r->status = VISFS_BA_ERR_UNSUPPORTED; }
+    if (win->n_laser_points < 0 || (win->n_laser_points > 0 && win->grid && !win->laser_xyz)) return r->status = bad(h, "laser points without coordinates");
     if (win->n_poses < 0 || win->n_points < 0 || win->n_refs < 0 || win->n_links < 0) return r->status = bad(h, "negative sizes");
     // guards of Optimizer.cpp:74 and :360-364
     if (!(win->n_poses >= 2 && prm.iterations > 0 && win->pose_ids[0] > 0)) {
@@ -748,6 +773,12 @@ int visfs_ba_pack_window(const visfs_ba_params* params, const visfs_ba_window* w
     g->odo_from = odo_from; g->odo_to = odo_to; g->odo_tq = odo_tq;
     g->fx = w->fx; g->fy = w->fy; g->cx = w->cx; g->cy = w->cy;
     g->bf = ((w->n_cameras > 1) ? (double)w->baseline : 0.0) * w->fx;          // :195
+    // range points (Optimizer.cpp:225-258): `!_pointClouds.empty() && _submap != nullptr`; every point hangs off the newest pose
+    if (w->n_laser_points > 0 && w->grid != nullptr && w->laser_xyz != nullptr) {
+        g->n_laser = w->n_laser_points; g->laser_pose = w->n_poses - 1;
+        g->laser_xyz = w->laser_xyz; g->grid = w->grid;
+    }
+    std::memcpy(g->Tcr, Tcr, 96);                                             // transformRobotToImage_ (TypeOccupiedSpace2D.h:81-82)
     return VISFS_BA_OK;
 }
 

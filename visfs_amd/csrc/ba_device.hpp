@@ -13,6 +13,8 @@
 
 #include <stdint.h>
 
+#include "ba_math.hpp"
+
 namespace visfs_ba {
 
 constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
@@ -68,6 +70,12 @@ struct DeviceGraph {
     int32_t group;          // lanes per landmark (4/8/16/32/64)
     double fx, fy, cx, cy, bf;
     double inv_pixel_var, inv_odo_cov, huber_delta;
+    // laser occupied-space edges (Optimizer.cpp:224-258): Nz unary edges on pose `laser_pose`; aggregated into slot Ne of odo_blk
+    int32_t Nz, laser_pose;
+    double inv_laser_cov;
+    double Tcr[12];
+    GridView grid;              // cost points into the static section
+    const double* laser_xyz;    // [Nz][3]
 
     // ---- static graph ----
     const double* pose0;        // [Np][8]  initial Tcw (tx ty tz qx qy qz qw pad)

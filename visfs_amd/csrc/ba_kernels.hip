@@ -347,6 +347,45 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const DeviceGraph g) {
             o[114 + r] = fj ? -bj : 0.0;
         }
     }
+    // laser occupied-space edges (EdgeOccupiedObservation, Omega = 1 / laserCovariance, Optimizer.cpp:232-249, no kernel):
+    // all on one pose, so the workgroup reduces J^T Omega J (upper triangle) and -J^T Omega e into slot Ne of odo_blk.
+    if (g.Nz > 0) {
+        __shared__ double redz[4 * 27];
+        const double il = g.inv_laser_cov;
+        const double* tq = pose + POSE_STRIDE * g.laser_pose;
+        double acc[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+        for (int z = tid; z < g.Nz; z += 256) {
+            const Vec3 P{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] };
+            const double e = laser_error(tq, g.Tcr, P, g.grid);
+            double J[6];
+            laser_jacobian(tq, g.Tcr, P, g.grid, J);
+            chi_acc += e * (il * e);
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = r; cc < 6; ++cc, ++q) acc[q] += J[r] * il * J[cc];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[21 + r] -= J[r] * il * e;
+        }
+        const int wave = tid >> 6, lane = tid & 63;
+        int off = 0, len = 27;
+        ReduceScatter<27, 32>::run(acc, lane, off, len);
+        if (len >= 1) redz[wave * 27 + off] = acc[0];
+        __syncthreads();
+        if (tid < 27) {
+            const double v = redz[tid] + redz[27 + tid] + redz[54 + tid] + redz[81 + tid];
+            double* o = g.odo_blk + 120 * (size_t)g.Ne;
+            if (tid < 21) {
+                int r = 0, base = 0;
+                while (tid >= base + (6 - r)) { base += 6 - r; ++r; }
+                const int cc = r + (tid - base);
+                o[r * 6 + cc] = v; o[cc * 6 + r] = v;
+            } else o[108 + (tid - 21)] = v;
+        }
+    }
     const double chi_tot = block_sum_256(chi_acc, red);
     if (tid == 0) { g.lin_part[2 * g.n_lin_a] = chi_tot; g.lin_part[2 * g.n_lin_a + 1] = 0.0; }
 }
@@ -835,7 +874,9 @@ __global__ __launch_bounds__(256) void k_dense_assemble(const DeviceGraph g) {
         const int i = g.blk_i[b], j = g.blk_j[b];
         const double v = g.S[t];
         g.dense[(size_t)(6 * i + r) * NP + 6 * j + c] = v;
-        g.dense[(size_t)(6 * j + c) * NP + 6 * i + r] = v;
+        // mirror only off-diagonal blocks: on a diagonal block (r,c) and (c,r) would both write each entry, and the two
+        // values may differ in the last bit — a write race that made the direct solver non-repeatable
+        if (i != j) g.dense[(size_t)(6 * j + c) * NP + 6 * i + r] = v;
     }
     for (int t = n6 + gid; t < NP; t += stride) g.dense[(size_t)t * NP + t] = 1.0;       // identity tail of the padding
 }
@@ -1056,6 +1097,10 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
 #pragma unroll
             for (int d = 0; d < 6; ++d) chi_acc += e[d] * (ic * e[d]);
         }
+        for (int z = tid; z < g.Nz; z += 256) {       // laser edges at the trial pose
+            const double e = laser_error(pose_t + POSE_STRIDE * g.laser_pose, g.Tcr, Vec3{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] }, g.grid);
+            chi_acc += e * (g.inv_laser_cov * e);
+        }
         const double chi_tot = block_sum_256(chi_acc, red);
         if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; }
         return;
@@ -1225,6 +1270,10 @@ __global__ __launch_bounds__(256) void k_eval(const DeviceGraph g, const int mar
 #pragma unroll
             for (int d = 0; d < 6; ++d) chi_acc += e[d] * (ic * e[d]);
         }
+        for (int z = tid; z < g.Nz; z += 256) {
+            const double e = laser_error(pose + POSE_STRIDE * g.laser_pose, g.Tcr, Vec3{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] }, g.grid);
+            chi_acc += e * (g.inv_laser_cov * e);
+        }
     } else {
         const int k = bid * 256 + tid;
         if (k < g.No) {
@@ -1329,7 +1378,7 @@ void launch_linearize(const DeviceGraph& g, hipStream_t s) {
         case 32: launch_lin_t<32>(g, s); break;
         default: launch_lin_t<64>(g, s); break;
     }
-    if (g.Ne > 0) hipLaunchKernelGGL(k_odo_linearize, dim3(1), dim3(256), 0, s, g);     // lin_part[n_lin_a] stays 0 otherwise
+    if (g.Ne > 0 || g.Nz > 0) hipLaunchKernelGGL(k_odo_linearize, dim3(1), dim3(256), 0, s, g);     // lin_part[n_lin_a] stays 0 otherwise
 }
 
 void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) {

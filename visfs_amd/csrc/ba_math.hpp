@@ -340,4 +340,84 @@ BA_HD void iso_to_tq(const double* T, double* tq) {   // CameraPose(R,t) / g2o::
     tq[3] = q.x; tq[4] = q.y; tq[5] = q.z; tq[6] = q.w;
 }
 
+// ---- laser occupied-space factor: EdgeOccupiedObservation (TypeOccupiedSpace2D.h:75-185) ----
+// The probability grid as the edge reads it through GridArrayAdapter (TypeOccupiedSpace2D.h:22-48).
+struct GridView {
+    const float* cost;          // [ny][nx] Grid2D::getCorrespondenceCost(Array2i(x, y)), flat nx * y + x (Grid2d.h:93-95)
+    int nx, ny;
+    double resolution, max_x, max_y;
+};
+constexpr int kGridPadding = 2147483647 / 4;        // kPadding = INT_MAX / 4 (TypeOccupiedSpace2D.h:20)
+constexpr double kMaxCorrespondenceCost = 1.0 - 0.1; // Map::kMaxCorrespondenceCost (ProbabilityValues.h:41-44)
+
+// GridArrayAdapter::GetValue: outside the padded window the constant, inside the float cost widened to double.
+BA_HD double grid_value(const GridView& g, int row, int col) {
+    const int y = row - kGridPadding, x = col - kGridPadding;
+    if (y < 0 || x < 0 || y >= g.ny || x >= g.nx) return kMaxCorrespondenceCost;
+    return static_cast<double>(g.cost[g.nx * y + x]);
+}
+// [ceres-upstream] CubicHermiteSpline<1>: Catmull-Rom spline through p1..p2, Horner form.
+BA_HD void cubic_hermite(double p0, double p1, double p2, double p3, double x, double& f, double& dfdx) {
+    const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
+    const double b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
+    const double c = 0.5 * (-p0 + p2);
+    f = p1 + x * (c + x * (b + x * a));
+    dfdx = c + x * (2.0 * b + 3.0 * a * x);
+}
+// [ceres-upstream] BiCubicInterpolator::Evaluate(r, c, f, dfdr, dfdc): four row splines, then the column spline.
+BA_HD void bicubic(const GridView& g, double r, double c, double& f, double& dfdr, double& dfdc) {
+    const int row = static_cast<int>(floor(r)), col = static_cast<int>(floor(c));
+    double fr[4], dfr[4];
+    for (int i = 0; i < 4; ++i)
+        cubic_hermite(grid_value(g, row - 1 + i, col - 1), grid_value(g, row - 1 + i, col), grid_value(g, row - 1 + i, col + 1),
+                      grid_value(g, row - 1 + i, col + 2), c - col, fr[i], dfr[i]);
+    double unused;
+    cubic_hermite(fr[0], fr[1], fr[2], fr[3], r - row, f, dfdr);
+    cubic_hermite(dfr[0], dfr[1], dfr[2], dfr[3], r - row, dfdc, unused);
+}
+// The functor (TypeOccupiedSpace2D.h:97-124) for quaternion (x, y, z, w) taken WITHOUT normalisation, as Eigen's
+// toRotationMatrix does: Twc = [R | t]^-1 * Tcr (Isometry inverse: R^T, -R^T t), Po = Twc * P, grid coordinates
+// (max - Po) / resolution - 0.5 + kPadding.  Also returns m = Rcr P + tcr - t and R for the Jacobian.
+BA_HD void laser_grid_coords(const double* tq, double w, const double* Tcr, const Vec3& P, const GridView& g,
+                             double& r, double& c, Mat3& R, Vec3& m) {
+    R = quat_to_R(Quat{ tq[3], tq[4], tq[5], w });
+    // inverse translation -(R^T t)
+    const Vec3 ti{ -(R.m00 * tq[0] + R.m10 * tq[1] + R.m20 * tq[2]), -(R.m01 * tq[0] + R.m11 * tq[1] + R.m21 * tq[2]),
+                   -(R.m02 * tq[0] + R.m12 * tq[1] + R.m22 * tq[2]) };
+    // Twc = inverse * Tcr: only rows 0 and 1 are needed
+    const double L00 = R.m00 * Tcr[0] + R.m10 * Tcr[4] + R.m20 * Tcr[8], L01 = R.m00 * Tcr[1] + R.m10 * Tcr[5] + R.m20 * Tcr[9],
+                 L02 = R.m00 * Tcr[2] + R.m10 * Tcr[6] + R.m20 * Tcr[10], T0 = R.m00 * Tcr[3] + R.m10 * Tcr[7] + R.m20 * Tcr[11] + ti.x;
+    const double L10 = R.m01 * Tcr[0] + R.m11 * Tcr[4] + R.m21 * Tcr[8], L11 = R.m01 * Tcr[1] + R.m11 * Tcr[5] + R.m21 * Tcr[9],
+                 L12 = R.m01 * Tcr[2] + R.m11 * Tcr[6] + R.m21 * Tcr[10], T1 = R.m01 * Tcr[3] + R.m11 * Tcr[7] + R.m21 * Tcr[11] + ti.y;
+    const double Po0 = L00 * P.x + L01 * P.y + L02 * P.z + T0;
+    const double Po1 = L10 * P.x + L11 * P.y + L12 * P.z + T1;
+    r = (g.max_x - Po0) / g.resolution - 0.5 + static_cast<double>(kGridPadding);
+    c = (g.max_y - Po1) / g.resolution - 0.5 + static_cast<double>(kGridPadding);
+    m = Vec3{ Tcr[0] * P.x + Tcr[1] * P.y + Tcr[2] * P.z + Tcr[3] - tq[0], Tcr[4] * P.x + Tcr[5] * P.y + Tcr[6] * P.z + Tcr[7] - tq[1],
+              Tcr[8] * P.x + Tcr[9] * P.y + Tcr[10] * P.z + Tcr[11] - tq[2] };
+}
+// computeError (TypeOccupiedSpace2D.h:126-131).
+BA_HD double laser_error(const double* tq, const double* Tcr, const Vec3& P, const GridView& g) {
+    double r, c, f, dr, dc; Mat3 R; Vec3 m;
+    laser_grid_coords(tq, tq[6], Tcr, P, g, r, c, R, m);
+    bicubic(g, r, c, f, dr, dc);
+    return f;
+}
+// linearizeOplus (TypeOccupiedSpace2D.h:145-179).  The reference runs ceres autodiff over StaticParameterDims<6, 3>:
+// the pose block carries six jets (t, qx, qy, qz), so the functor's pose[6] aliases the first coordinate of the range
+// point.  Its Jacobian is therefore that of the functor with q.w := P.x, w.r.t. (t1 t2 t3 qx qy qz), evaluated at the
+// grid position that aliased pose maps to.  Reproduced analytically: Po = R^T m, dPo/dt = -R^T, dPo/dq = (dR^T/dq) m.
+BA_HD void laser_jacobian(const double* tq, const double* Tcr, const Vec3& P, const GridView& g, double J[6]) {
+    double r, c, f, dfdr, dfdc; Mat3 R; Vec3 m;
+    const double w = P.x;
+    laser_grid_coords(tq, w, Tcr, P, g, r, c, R, m);
+    bicubic(g, r, c, f, dfdr, dfdc);
+    const double x = tq[3], y = tq[4], z = tq[5];
+    const double d0[6] = { -R.m00, -R.m10, -R.m20,
+                           2.0 * y * m.y + 2.0 * z * m.z, -4.0 * y * m.x + 2.0 * x * m.y - 2.0 * w * m.z, -4.0 * z * m.x + 2.0 * w * m.y + 2.0 * x * m.z };
+    const double d1[6] = { -R.m01, -R.m11, -R.m21,
+                           2.0 * y * m.x - 4.0 * x * m.y + 2.0 * w * m.z, 2.0 * x * m.x + 2.0 * z * m.z, -2.0 * w * m.x - 4.0 * z * m.y + 2.0 * y * m.z };
+    for (int i = 0; i < 6; ++i) J[i] = dfdr * (-d0[i] / g.resolution) + dfdc * (-d1[i] / g.resolution);
+}
+
 }  // namespace visfs_ba

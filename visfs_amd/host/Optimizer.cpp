@@ -101,9 +101,26 @@ std::map<std::size_t, Eigen::Isometry3d> Optimizer::localOptimize(
             refFeature.push_back(it->first); refPose.push_back(jt->first);
             refU.push_back(jt->second.kpt.pt.x); refV.push_back(jt->second.kpt.pt.y); refDepth.push_back(jt->second.depth);
         }
-    int nLaser = 0;
-    if (!_pointClouds.empty() && _submap != nullptr)          // Optimizer.cpp:226: the laser factor would be built
-        for (const auto& pc : _pointClouds) nLaser += static_cast<int>(pc.points().size());
+    // laser occupied-space factor (Optimizer.cpp:225-258): every point of every cloud, and the sub-map's grid as the
+    // edge reads it — limits + getCorrespondenceCost(Array2i(x, y)) per cell (TypeOccupiedSpace2D.h:28-37)
+    std::vector<double> laserXyz;
+    std::vector<float> gridCost;
+    visfs_ba_grid grid;
+    std::memset(&grid, 0, sizeof(grid));
+    const bool withLaser = !_pointClouds.empty() && _submap != nullptr && _submap->getGrid() != nullptr;
+    if (withLaser) {
+        for (const auto& pc : _pointClouds)
+            for (const auto& pt : pc.points()) { laserXyz.push_back(pt.position[0]); laserXyz.push_back(pt.position[1]); laserXyz.push_back(pt.position[2]); }
+        const auto* g2 = _submap->getGrid();
+        const auto& lim = g2->limits();
+        grid.resolution = lim.resolution(); grid.max_x = lim.max().x(); grid.max_y = lim.max().y();
+        grid.num_x_cells = lim.cellLimits().numXcells; grid.num_y_cells = lim.cellLimits().numYcells;
+        gridCost.resize(static_cast<std::size_t>(grid.num_x_cells) * grid.num_y_cells);
+        for (int y = 0; y < grid.num_y_cells; ++y)
+            for (int x = 0; x < grid.num_x_cells; ++x)
+                gridCost[static_cast<std::size_t>(grid.num_x_cells) * y + x] = g2->getCorrespondenceCost(Eigen::Array2i(x, y));
+        grid.correspondence_cost = gridCost.data();
+    }
 
     const GeometricCamera& cam = *_cameraModels.front();
     const Eigen::Matrix3d K = cam.eigenKdouble();
@@ -119,7 +136,7 @@ std::map<std::size_t, Eigen::Isometry3d> Optimizer::localOptimize(
     w.n_points = static_cast<int32_t>(pointIds.size()); w.point_ids = pointIds.data(); w.point_xyz = pointXyz.data(); w.point_fixed = pointFixed.data();
     w.n_refs = static_cast<int32_t>(refFeature.size()); w.ref_feature = refFeature.data(); w.ref_pose = refPose.data();
     w.ref_u = refU.data(); w.ref_v = refV.data(); w.ref_depth = refDepth.data();
-    w.n_laser_points = nLaser;
+    if (withLaser && !laserXyz.empty()) { w.n_laser_points = static_cast<int32_t>(laserXyz.size() / 3); w.laser_xyz = laserXyz.data(); w.grid = &grid; }
 
     std::vector<uint64_t> outIds(poseIds.size() + 1), outFeat(refFeature.size() + 1), outPose(refFeature.size() + 1);
     std::vector<double> outTwr((poseIds.size() + 1) * 12);

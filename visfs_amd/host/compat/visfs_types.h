@@ -21,6 +21,20 @@ struct Vector3d {
     double& operator[](int i) { return v[i]; }
     const double& operator[](int i) const { return v[i]; }
 };
+struct Vector2d {
+    double v[2];
+    Vector2d() : v{ 0, 0 } {}
+    Vector2d(double x, double y) : v{ x, y } {}
+    double x() const { return v[0]; }
+    double y() const { return v[1]; }
+};
+struct Array2i {
+    int v[2];
+    Array2i() : v{ 0, 0 } {}
+    Array2i(int x, int y) : v{ x, y } {}
+    int x() const { return v[0]; }
+    int y() const { return v[1]; }
+};
 struct Matrix3d {
     double m[3][3];
     Matrix3d() : m{ { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } } {}
@@ -73,11 +87,47 @@ private:
 
 namespace Sensor {
 struct RangefinderPoint { Eigen::Vector3d position; };
-class PointCloud {   // corelib/include/Sensor/PointCloud.h — only emptiness / size is inspected by the shim
+class PointCloud {   // corelib/include/Sensor/PointCloud.h — points() is what the laser factor iterates (Optimizer.cpp:235-236)
 public:
     const std::vector<RangefinderPoint>& points() const { return pts_; }
     std::vector<RangefinderPoint> pts_;
 };
 }  // namespace Sensor
-namespace Map { class Submap2D {}; }
+namespace Map {
+// corelib/include/Map/2d/{xyIndex,MapLimits,Grid2d,Submap2D}.h — the accessors the laser factor reads through
+// GridArrayAdapter (TypeOccupiedSpace2D.h:22-48) and Optimizer.cpp:229-231.
+struct CellLimits { int numXcells = 0; int numYcells = 0; };
+class MapLimits {
+public:
+    MapLimits() {}
+    MapLimits(double resolution, const Eigen::Vector2d& max, const CellLimits& cells) : resolution_(resolution), max_(max), cells_(cells) {}
+    double resolution() const { return resolution_; }
+    const Eigen::Vector2d& max() const { return max_; }
+    const CellLimits& cellLimits() const { return cells_; }
+private:
+    double resolution_ = 0.05;
+    Eigen::Vector2d max_;
+    CellLimits cells_;
+};
+class Grid2D {
+public:
+    Grid2D(const MapLimits& limits, std::vector<float> cost) : limits_(limits), cost_(std::move(cost)) {}
+    const MapLimits& limits() const { return limits_; }
+    float getCorrespondenceCost(const Eigen::Array2i& c) const {       // Grid2d.h:33-36 (the stand-in stores the floats)
+        if (c.x() < 0 || c.y() < 0 || c.x() >= limits_.cellLimits().numXcells || c.y() >= limits_.cellLimits().numYcells) return 0.9f;
+        return cost_[static_cast<std::size_t>(limits_.cellLimits().numXcells) * c.y() + c.x()];
+    }
+private:
+    MapLimits limits_;
+    std::vector<float> cost_;
+};
+class Submap2D {
+public:
+    Submap2D() {}
+    explicit Submap2D(std::shared_ptr<Grid2D> grid) : grid_(std::move(grid)) {}
+    const Grid2D* getGrid() const { return grid_.get(); }
+private:
+    std::shared_ptr<Grid2D> grid_;
+};
+}  // namespace Map
 }  // namespace VISFS

@@ -200,7 +200,7 @@ def make_window(config="C2", window_index=0, n_kf=None, n_lm=None, n_obs=None, o
              n_cameras=2, fx=FX, fy=FY, cx=CX, cy=CY, baseline=float(BASELINE_F), Trc=TRC.reshape(12),
              point_ids=np.arange(Nl, dtype=np.uint64), point_xyz=P0, point_fixed=fixed.astype(np.uint8),
              ref_feature=obs_lm.astype(np.uint64), ref_pose=pose_ids[obs_kf], ref_u=ref_u, ref_v=ref_v,
-             ref_depth=ref_depth, n_laser_points=0,
+             ref_depth=ref_depth, n_laser_points=0, laser_xyz=np.zeros((0, 3)), grid=None,
              truth_Twr=Twr_true.reshape(Np, 12), truth_points=P, gross=gross)
     if cfg["odo"]:
         # LocalMap.cpp:238-272: consecutive pairs, T_r1r2 = from^-1 * to, + first-order noise N(0, 5e-5) per dof
@@ -216,6 +216,58 @@ def make_window(config="C2", window_index=0, n_kf=None, n_lm=None, n_obs=None, o
         w["link_from"] = np.zeros(0, np.uint64)
         w["link_to"] = np.zeros(0, np.uint64)
         w["link_T"] = np.zeros((0, 12))
+    return w
+
+
+def make_grid(num_x=240, num_y=200, resolution=0.05, max_x=9.0, max_y=5.0, seed=7):
+    """A probability grid as the laser factor reads it (Map::Grid2D through GridArrayAdapter): float correspondence costs
+    in [0.1, 0.9], low on the walls of a rectangular room with a pillar, rising with the distance to them; a band of
+    unknown cells (float(0.9)) on one side.  Cell (x, y) has its centre at (max_x - res (y + .5), max_y - res (x + .5))
+    (MapLimits::getCellCenter, MapLimits.h:75-79)."""
+    rng = SplitMix64(BASE_SEED + 777 + seed)
+    xi, yi = np.meshgrid(np.arange(num_x), np.arange(num_y))          # arrays [num_y][num_x]
+    wx = max_x - resolution * (yi + 0.5)
+    wy = max_y - resolution * (xi + 0.5)
+    x0, x1, y0, y1 = max_x - num_y * resolution + 0.6, max_x - 0.6, max_y - num_x * resolution + 0.8, max_y - 0.8
+    d_wall = np.minimum.reduce([np.abs(wx - x0), np.abs(wx - x1), np.abs(wy - y0), np.abs(wy - y1)])
+    d_pillar = np.abs(np.hypot(wx - (x0 + 2.0), wy - (y0 + 3.0)) - 0.4)
+    d = np.minimum(d_wall, d_pillar)
+    cost = np.clip(0.1 + 0.9 * d + 0.01 * rng.normal(num_x * num_y).reshape(num_y, num_x), 0.1, 0.9).astype(np.float32)
+    cost[:, :6] = np.float32(0.9)                                      # unknown band
+    return dict(resolution=resolution, max_x=max_x, max_y=max_y, cost=cost, room=(x0, x1, y0, y1))
+
+
+def make_laser_window(n_kf=6, n_points=720, with_visual=False, seed=0, pose_noise_t=0.03, pose_noise_r=0.01):
+    """Sensor strategy 4/5 (Estimator.cpp:243-250): poses + wheel-odometry links + one laser scan against the matching
+    submap, no landmarks (with_visual=True keeps the stereo part of a small window as well)."""
+    w = make_window("PROD", n_kf=n_kf, odo=True, seed=BASE_SEED + 4242 + seed, pose_noise_t=pose_noise_t, pose_noise_r=pose_noise_r)
+    if not with_visual:
+        for k, dt in (("point_ids", np.uint64), ("point_fixed", np.uint8), ("ref_feature", np.uint64), ("ref_pose", np.uint64),
+                      ("ref_u", np.float32), ("ref_v", np.float32), ("ref_depth", np.float32)):
+            w[k] = np.zeros(0, dt)
+        w["point_xyz"] = np.zeros((0, 3))
+    rng = SplitMix64(BASE_SEED + 999 + seed)
+    g = make_grid(seed=seed)
+    x0, x1, y0, y1 = g["room"]
+    # the trajectory of make_window starts at the world origin: shift the room so that it lies inside
+    off = np.array([x0 + 1.0, y0 + 2.0, 0.0])
+    Ttrue = w["truth_Twr"].reshape(-1, 3, 4).copy(); Ttrue[:, :, 3] += off
+    T0 = w["pose_Twr"].reshape(-1, 3, 4).copy(); T0[:, :, 3] += off
+    w["truth_Twr"] = Ttrue.reshape(-1, 12); w["pose_Twr"] = T0.reshape(-1, 12)
+    if with_visual:
+        w["point_xyz"] = w["point_xyz"] + off; w["truth_points"] = w["truth_points"] + off
+    # one scan from the newest (true) pose: rays to the room walls, hits expressed in that robot frame
+    R, t = Ttrue[-1][:, :3], Ttrue[-1][:, 3]
+    ang = 2 * np.pi * (np.arange(n_points) + 0.5) / n_points
+    dirs = np.stack([np.cos(ang), np.sin(ang)], -1)
+    with np.errstate(divide="ignore"):
+        tx = np.where(dirs[:, 0] > 0, (x1 - t[0]) / dirs[:, 0], (x0 - t[0]) / dirs[:, 0])
+        ty = np.where(dirs[:, 1] > 0, (y1 - t[1]) / dirs[:, 1], (y0 - t[1]) / dirs[:, 1])
+    rng_len = np.minimum(tx, ty) + 0.01 * rng.normal(n_points)
+    hits_w = np.stack([t[0] + rng_len * dirs[:, 0], t[1] + rng_len * dirs[:, 1], np.full(n_points, t[2])], -1)
+    w["laser_xyz"] = (hits_w - t) @ R                      # R^T (p - t)
+    w["n_laser_points"] = n_points
+    w["grid"] = g
     return w
 
 
