@@ -254,13 +254,15 @@ typedef struct visfs_ba_graph_info {
     int32_t lanes_per_landmark;   /* wavefront sub-group size of the landmark-major kernels */
     int32_t n_schur_chunks;       /* wavefronts of the Schur gather (<= 64 pairs each) */
     int64_t device_bytes;         /* HBM footprint of the window */
+    int32_t fused_path;           /* 1: the window runs on the fused single-workgroup kernel (small windows, opt-in with VISFS_BA_FUSED=1) */
+    int32_t reserved;
 } visfs_ba_graph_info;
 int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out);
 
 enum {
     VISFS_BA_K_LINEARIZE = 0, VISFS_BA_K_LIN_FINALIZE = 1, VISFS_BA_K_SCHUR = 2, VISFS_BA_K_SCHUR_FINALIZE = 3,
     VISFS_BA_K_PCG = 4, VISFS_BA_K_DIRECT = 5, VISFS_BA_K_BACKSUB = 6, VISFS_BA_K_DECIDE = 7,
-    VISFS_BA_K_PHASE_END = 8, VISFS_BA_K_RESET = 9, VISFS_BA_K_COUNT = 10
+    VISFS_BA_K_PHASE_END = 8, VISFS_BA_K_RESET = 9, VISFS_BA_K_SMALL = 10, VISFS_BA_K_COUNT = 11
 };
 typedef struct visfs_ba_profile {
     double  total_ms[VISFS_BA_K_COUNT];        /* sum of hipEventElapsedTime over all launches of the class */

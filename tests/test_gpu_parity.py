@@ -290,6 +290,52 @@ def test_solve_window_error_convention(olib):
     s.close(); s0.close()
 
 
+# ---------------------------------------------------------------- small windows: k_small_solve / fused single-workgroup kernel
+def _solve_in_mode(monkeypatch, w, env, **prm_kw):
+    from visfs_amd import backend
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    prm = abi.default_params(**prm_kw)
+    s = backend.Solver(prm)
+    gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s.upload(gb)
+    info = s.describe()
+    rc, st = s.optimize()
+    out = s.download()
+    s.close()
+    return info, rc, st, out
+
+
+@pytest.mark.parametrize("solver", [0, 2])
+@pytest.mark.parametrize("cfg", ["PROD", "C1", "LASER"])
+def test_small_window_paths_agree(olib, monkeypatch, cfg, solver):
+    """<= 10 free poses: the reduced system is finalised and solved by one workgroup (k_small_solve, default) instead of
+    k_schur_finalize + k_pcg / the blocked Cholesky; VISFS_BA_FUSED=1 runs the whole optimisation in one launch of one
+    workgroup.  All three orders of summation must give the same LM trajectory, outliers and poses (to rounding)."""
+    w = synth.make_laser_window(with_visual=True, n_points=300) if cfg == "LASER" else synth.make_window(cfg)
+    kw = dict(iterations=10, solver=solver)
+    gi, grc, gst, gout = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SMALL_SOLVE="0", VISFS_BA_FUSED="0"), **kw)
+    assert gi["fused_path"] == 0 and grc == abi.OK
+    for env in (dict(VISFS_BA_SMALL_SOLVE="1", VISFS_BA_FUSED="0"), dict(VISFS_BA_SMALL_SOLVE="1", VISFS_BA_FUSED="1")):
+        info, rc, st, out = _solve_in_mode(monkeypatch, w, env, **kw)
+        assert info["fused_path"] == int(env["VISFS_BA_FUSED"]) and rc == abi.OK
+        assert list(st.iterations_run) == list(gst.iterations_run) and list(st.trials_run) == list(gst.trials_run)
+        assert st.pcg_iterations == gst.pcg_iterations and st.n_outliers == gst.n_outliers
+        assert abs(st.chi2_final - gst.chi2_final) <= 1e-10 * gst.chi2_final
+        assert np.abs(out[0] - gout[0]).max() < 1e-12 and rel_err(out[1], gout[1]) < 1e-11
+        assert np.array_equal(out[2], gout[2])
+
+
+def test_fused_path_matches_oracle_with_rejected_steps(olib, monkeypatch):
+    # a hard start on a 9-free-pose window: rejected trials, lambda growth — through the fused kernel's own LM loop
+    monkeypatch.setenv("VISFS_BA_FUSED", "1")
+    w = synth.make_window("custom", n_kf=10, n_lm=300, n_obs=2400, seed=5, point_noise=1.0, fixed_frac=0.0)
+    o, s, gb = make_pair(olib, w, iterations=20, solver=0)
+    assert s.describe()["fused_path"] == 1
+    check_optimize(o, s, pose_tol=1e-6)
+    s.close(); o.close()
+
+
 # ---------------------------------------------------------------- laser occupied-space factor (SURVEY §8f-3)
 @pytest.mark.parametrize("visual,solver", [(False, 2), (False, 0), (True, 2)])
 def test_laser_factor_stages_and_optimize(olib, visual, solver):

@@ -27,7 +27,7 @@ def build_hip(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs + ["-lpthread"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)     # a normal build takes ~30 s
     if verbose or res.returncode != 0:
         print(" ".join(cmd)); print(res.stdout); print(res.stderr)
     if res.returncode != 0:

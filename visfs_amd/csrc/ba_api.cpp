@@ -43,6 +43,8 @@ struct Workspace {
     LmState* h_state = nullptr;                    // pinned
     DeviceGraph g{};
     bool loaded = false;
+    bool fused = false;                            // the resident window runs on k_small_optimize
+    bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
     int64_t n_pairs = 0;
@@ -479,6 +481,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.debug = 0;
     { const char* e = std::getenv("VISFS_BA_STAMP_WG"); dg.stamp_wg = e ? std::atoi(e) : 0; }
     w.g = dg;
+    // opt-in (VISFS_BA_FUSED=1): one CU's fp64 rate makes the fused kernel slower than the multi-kernel path per window
+    // (DESIGN.md §4); it pays only when many small windows run side by side
+    { const char* e = std::getenv("VISFS_BA_SMALL_SOLVE"); w.small_solve = small_solve_fits(dg) && !(e && e[0] == '0'); }
+    { const char* e = std::getenv("VISFS_BA_FUSED"); w.fused = small_path_fits(dg) && e && e[0] == '1'; }
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
@@ -505,9 +511,12 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize(w.g, w.stream); }
     if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE); launch_lin_finalize(w.g, 0, w.stream); }
     { ProfScope p(w, VISFS_BA_K_SCHUR); launch_schur_partial(w.g, w.stream); }
-    { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE); launch_schur_finalize(w.g, w.stream); }
-    if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG); launch_pcg(w.g, w.stream); }
-    else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
+    if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT); launch_small_solve(w.g, h->prm.solver, w.stream); }
+    else {
+        { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE); launch_schur_finalize(w.g, w.stream); }
+        if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG); launch_pcg(w.g, w.stream); }
+        else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
+    }
     { ProfScope p(w, VISFS_BA_K_BACKSUB); launch_backsub(w.g, w.stream); }
     { ProfScope p(w, VISFS_BA_K_DECIDE); launch_decide(w.g, w.stream); }
 }
@@ -550,6 +559,17 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     const int half = h->prm.iterations / 2;
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
     { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
+    if (w.fused) {
+        // small window: both phases, the outlier pass and the final evaluation in one launch of one workgroup
+        { ProfScope p(w, VISFS_BA_K_SMALL); launch_small_optimize(w.g, h->prm.solver, half, w.stream); }
+        HIP_TRY(h, hipGetLastError());
+        int rcs = ws_read_state(h, w);
+        if (rcs != VISFS_BA_OK) return rcs;
+        if (w.h_state->status == VISFS_BA_ERR_DEVICE) { h->err = "fused LM loop did not terminate"; return VISFS_BA_ERR_DEVICE; }
+        if (stats) fill_stats(*w.h_state, stats);
+        if (w.prof_mask) { w.active[VISFS_BA_K_SMALL] += 1; w.active[VISFS_BA_K_RESET] += 1; }
+        return w.h_state->status;
+    }
     int rc = run_phase(h, w, half);                               // :265
     if (rc != VISFS_BA_OK) return rc;
     { ProfScope p(w, VISFS_BA_K_PHASE_END); launch_phase_end(w.g, 0, 1, half, w.stream); }   // :270-303
@@ -865,6 +885,7 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     out->n_poses = w.g.Np; out->n_free_poses = w.g.Npf; out->n_points = w.g.Nl; out->n_obs = w.g.No; out->n_odo = w.g.Ne;
     out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->n_schur_chunks = w.g.n_sch;
     out->device_bytes = (int64_t)w.device_bytes;
+    out->fused_path = w.fused ? 1 : 0; out->reserved = 0;
     return VISFS_BA_OK;
 }
 
@@ -922,8 +943,11 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
     const double chi0 = w.h_state->current_chi;
     launch_stage_arm(w.g, lambda, MODE_TRIAL, w.stream);
     launch_schur_partial(w.g, w.stream);
-    launch_schur_finalize(w.g, w.stream);
-    if (h->prm.solver == 2) launch_pcg(w.g, w.stream); else launch_direct(w.g, w.stream);
+    if (w.small_solve) launch_small_solve(w.g, h->prm.solver, w.stream);
+    else {
+        launch_schur_finalize(w.g, w.stream);
+        if (h->prm.solver == 2) launch_pcg(w.g, w.stream); else launch_direct(w.g, w.stream);
+    }
     launch_backsub(w.g, w.stream);
     HIP_TRY(h, hipGetLastError());
     rc = ws_read_state(h, w);

@@ -23,6 +23,12 @@ constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byt
 constexpr int MAX_STAGED_POSES = 640; // 12 doubles each in LDS (60 KiB)
 constexpr int MAX_PCG_FREE_POSES = 256; // persistent PCG: one workgroup per block row, all co-resident (256 CUs, >= 1 workgroup each)
 constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront
+// fused single-workgroup path (k_small_optimize): limits of a "small" window
+constexpr int SM_MAX_POSES = 16;      // R|t of every pose twice in LDS
+constexpr int SM_MAX_N6 = 64;         // <= 10 free poses: the reduced camera system is solved in LDS
+constexpr int SM_MAX_WCHUNKS = 192;   // 64-observation wave chunks of the pose-major pass (4 per LIN_CHUNK)
+constexpr int SM_MAX_OBS = 8192;      // beyond this one CU's arithmetic costs more than the launches it saves
+constexpr int SM_MAX_SCH = 1024;      // Schur chunks (<= 64 k co-observation pairs)
 
 // LM / phase state machine, resident in HBM; every kernel of a "unit" reads its gate from here.
 // Unit gate bits (LmState::mode).  Written ONLY by single-workgroup kernels (k_reset, k_decide, k_phase_end,

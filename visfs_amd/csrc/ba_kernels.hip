@@ -164,6 +164,114 @@ __device__ __forceinline__ double hpp_entry(const DeviceGraph& g, int a, int q) 
     return hpp_entry_r(g, q, g.pose_chunk_ptr[a], g.pose_chunk_ptr[a + 1], g.pose_odo_ptr[a], g.pose_odo_ptr[a + 1]);
 }
 
+// Role B, one observation of a free pose: upper triangle of Jx^T (rho' Omega) Jx and -Jx^T (rho' Omega) e into acc[27]
+// (left untouched for an inactive edge).  Shared by k_linearize and the fused small-window kernel.
+__device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k, const Rt& T, const double* __restrict__ pt,
+                                               const Intrinsics& K, const double iv, const double delta, double acc[27]) {
+    const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
+    if (!active) return;
+    const int l = g.obs_pt[k];
+    const Vec3 pw{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
+    Vec3 pc;
+    const Vec3 e = stereo_error(T, pw, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
+    const double c2 = chi2_of(e, iv);
+    double rho0 = c2, rho1 = 1.0;
+    if (delta > 0.0) huber(c2, delta, rho0, rho1);
+    const double wo = rho1 * iv;
+    double Jx[18];
+    stereo_jacobian_pose(pc, K, Jx);
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = r; cc < 6; ++cc, ++q)
+            acc[q] = Jx[r] * wo * Jx[cc] + Jx[6 + r] * wo * Jx[6 + cc] + Jx[12 + r] * wo * Jx[12 + cc];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] = -(Jx[r] * wo * e.x + Jx[6 + r] * wo * e.y + Jx[12 + r] * wo * e.z);
+}
+
+// Role A for one landmark handled by G lanes (sub = lane within the group): weights, chi2, tile seeds, Hll, b_l.
+// Shared by k_linearize<G> and the fused small-window kernel (G = 1: one thread per landmark).
+template <int G>
+__device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const int l, const bool lvalid, const int sub, const double* sRt,
+                                             const double* __restrict__ pt, const Intrinsics& K, const double iv, const double delta,
+                                             double& chi_acc, double& md) {
+    int k0 = 0, k1 = 0;
+    Vec3 pw{ 0, 0, 0 };
+    bool lfree = false;
+    if (lvalid) {
+        k0 = g.lm_ptr[l]; k1 = g.lm_ptr[l + 1];
+        pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
+        lfree = !g.pt_fixed[l];
+    }
+    double hb[9];                          // Hll (xx xy xz yy yz zz) then b_l
+#pragma unroll
+    for (int q = 0; q < 9; ++q) hb[q] = 0.0;
+    for (int k = k0 + sub; k < k1; k += G) {
+        const int ip = g.obs_pose[k];
+        const Rt T = load_Rt(sRt, ip);
+        const double u = g.obs_uvr[3 * k], v = g.obs_uvr[3 * k + 1], ur = g.obs_uvr[3 * k + 2];
+        Vec3 pc;
+        const Vec3 e = stereo_error(T, pw, u, v, ur, K, pc);
+        const double c2 = chi2_of(e, iv);
+        const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
+        double rho0 = c2, rho1 = 1.0;
+        if (delta > 0.0) huber(c2, delta, rho0, rho1);
+        g.obs_w[k] = active ? rho1 : 0.0;
+        g.obs_chi2[k] = active ? c2 : 0.0;
+        if (g.debug) { g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
+        const bool pfree = g.pose_free[ip] >= 0;
+        double wo_tile = 0.0;
+        if (active) {
+            chi_acc += rho0;
+            const double wo = rho1 * iv;        // weightedOmega = rho' * Omega
+            double Jp[9], Jx[18];
+            stereo_jacobians(T, pc, K, Jp, Jx);
+            if (lfree) {
+                hb[0] += Jp[0] * wo * Jp[0] + Jp[3] * wo * Jp[3] + Jp[6] * wo * Jp[6];
+                hb[1] += Jp[0] * wo * Jp[1] + Jp[3] * wo * Jp[4] + Jp[6] * wo * Jp[7];
+                hb[2] += Jp[0] * wo * Jp[2] + Jp[3] * wo * Jp[5] + Jp[6] * wo * Jp[8];
+                hb[3] += Jp[1] * wo * Jp[1] + Jp[4] * wo * Jp[4] + Jp[7] * wo * Jp[7];
+                hb[4] += Jp[1] * wo * Jp[2] + Jp[4] * wo * Jp[5] + Jp[7] * wo * Jp[8];
+                hb[5] += Jp[2] * wo * Jp[2] + Jp[5] * wo * Jp[5] + Jp[8] * wo * Jp[8];
+                hb[6] -= Jp[0] * wo * e.x + Jp[3] * wo * e.y + Jp[6] * wo * e.z;
+                hb[7] -= Jp[1] * wo * e.x + Jp[4] * wo * e.y + Jp[7] * wo * e.z;
+                hb[8] -= Jp[2] * wo * e.x + Jp[5] * wo * e.y + Jp[8] * wo * e.z;
+            }
+            if (pfree && lfree) wo_tile = wo;
+        }
+        // the 32-byte tile seed (Hpl is rebuilt from it where it is consumed)
+        double2* seed = reinterpret_cast<double2*>(g.obs_pcw + 4 * (size_t)k);
+        seed[0] = make_double2(pc.x, pc.y);
+        seed[1] = make_double2(pc.z, wo_tile);
+        if (g.debug) {
+            double Wv[18];
+            hpl_tile(T, pc, wo_tile, K, Wv);
+            double2* Wk = reinterpret_cast<double2*>(g.W + 18 * (size_t)k);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Wk[q] = make_double2(Wv[2 * q], Wv[2 * q + 1]);
+        }
+    }
+    // 9 sums over the G lanes of the landmark; each lane ends up owning rs_slots(9,G) of them
+    int off = 0, len = 9;
+    ReduceScatter<9, G / 2>::run(hb, sub, off, len);
+    constexpr int SL = rs_slots(9, G);
+    if (lvalid) {
+#pragma unroll
+        for (int j = 0; j < SL; ++j) {
+            const int idx = off + j;
+            if (j < len) {
+                if (idx < 6) {
+                    g.Hll[6 * (size_t)l + idx] = hb[j];
+                    if (lfree && (idx == 0 || idx == 3 || idx == 5)) md = fmax(md, fabs(hb[j]));
+                } else {
+                    g.bl[3 * (size_t)l + (idx - 6)] = hb[j];
+                }
+            }
+        }
+    }
+}
+
 // ================================================================= K1/K2/K4: linearise the stereo edges
 template <int G>
 __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
@@ -186,82 +294,8 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
         constexpr int LPW = 256 / G;
         const int l = bid * LPW + tid / G, sub = tid % G;
         const bool lvalid = l < g.Nl;
-        int k0 = 0, k1 = 0;
-        Vec3 pw{ 0, 0, 0 };
-        bool lfree = false;
-        if (lvalid) {
-            k0 = g.lm_ptr[l]; k1 = g.lm_ptr[l + 1];
-            pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
-            lfree = !g.pt_fixed[l];
-        }
-        double hb[9];                          // Hll (xx xy xz yy yz zz) then b_l
-#pragma unroll
-        for (int q = 0; q < 9; ++q) hb[q] = 0.0;
-        double chi_acc = 0.0;
-        for (int k = k0 + sub; k < k1; k += G) {
-            const int ip = g.obs_pose[k];
-            const Rt T = load_Rt(sRt, ip);
-            const double u = g.obs_uvr[3 * k], v = g.obs_uvr[3 * k + 1], ur = g.obs_uvr[3 * k + 2];
-            Vec3 pc;
-            const Vec3 e = stereo_error(T, pw, u, v, ur, K, pc);
-            const double c2 = chi2_of(e, iv);
-            const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
-            double rho0 = c2, rho1 = 1.0;
-            if (delta > 0.0) huber(c2, delta, rho0, rho1);
-            g.obs_w[k] = active ? rho1 : 0.0;
-            g.obs_chi2[k] = active ? c2 : 0.0;
-            if (g.debug) { g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
-            const bool pfree = g.pose_free[ip] >= 0;
-            double wo_tile = 0.0;
-            if (active) {
-                chi_acc += rho0;
-                const double wo = rho1 * iv;        // weightedOmega = rho' * Omega
-                double Jp[9], Jx[18];
-                stereo_jacobians(T, pc, K, Jp, Jx);
-                if (lfree) {
-                    hb[0] += Jp[0] * wo * Jp[0] + Jp[3] * wo * Jp[3] + Jp[6] * wo * Jp[6];
-                    hb[1] += Jp[0] * wo * Jp[1] + Jp[3] * wo * Jp[4] + Jp[6] * wo * Jp[7];
-                    hb[2] += Jp[0] * wo * Jp[2] + Jp[3] * wo * Jp[5] + Jp[6] * wo * Jp[8];
-                    hb[3] += Jp[1] * wo * Jp[1] + Jp[4] * wo * Jp[4] + Jp[7] * wo * Jp[7];
-                    hb[4] += Jp[1] * wo * Jp[2] + Jp[4] * wo * Jp[5] + Jp[7] * wo * Jp[8];
-                    hb[5] += Jp[2] * wo * Jp[2] + Jp[5] * wo * Jp[5] + Jp[8] * wo * Jp[8];
-                    hb[6] -= Jp[0] * wo * e.x + Jp[3] * wo * e.y + Jp[6] * wo * e.z;
-                    hb[7] -= Jp[1] * wo * e.x + Jp[4] * wo * e.y + Jp[7] * wo * e.z;
-                    hb[8] -= Jp[2] * wo * e.x + Jp[5] * wo * e.y + Jp[8] * wo * e.z;
-                }
-                if (pfree && lfree) wo_tile = wo;
-            }
-            // the 32-byte tile seed (Hpl is rebuilt from it where it is consumed)
-            double2* seed = reinterpret_cast<double2*>(g.obs_pcw + 4 * (size_t)k);
-            seed[0] = make_double2(pc.x, pc.y);
-            seed[1] = make_double2(pc.z, wo_tile);
-            if (g.debug) {
-                double Wv[18];
-                hpl_tile(T, pc, wo_tile, K, Wv);
-                double2* Wk = reinterpret_cast<double2*>(g.W + 18 * (size_t)k);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) Wk[q] = make_double2(Wv[2 * q], Wv[2 * q + 1]);
-            }
-        }
-        // 9 sums over the G lanes of the landmark; each lane ends up owning rs_slots(9,G) of them
-        int off = 0, len = 9;
-        ReduceScatter<9, G / 2>::run(hb, sub, off, len);
-        constexpr int SL = rs_slots(9, G);
-        double md = 0.0;
-        if (lvalid) {
-#pragma unroll
-            for (int j = 0; j < SL; ++j) {
-                const int idx = off + j;
-                if (j < len) {
-                    if (idx < 6) {
-                        g.Hll[6 * (size_t)l + idx] = hb[j];
-                        if (lfree && (idx == 0 || idx == 3 || idx == 5)) md = fmax(md, fabs(hb[j]));
-                    } else {
-                        g.bl[3 * (size_t)l + (idx - 6)] = hb[j];
-                    }
-                }
-            }
-        }
+        double chi_acc = 0.0, md = 0.0;
+        lin_landmark<G>(g, l, lvalid, sub, sRt, pt, K, iv, delta, chi_acc, md);
         const double chi_tot = block_sum_256(chi_acc, red);
         const double md_tot = block_max_256(md, red);
         if (tid == 0) { g.lin_part[2 * bid] = chi_tot; g.lin_part[2 * bid + 1] = md_tot; }
@@ -273,32 +307,7 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
         double acc[27];
 #pragma unroll
         for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-        if (begin + tid < end) {
-            const int k = g.pose_obs[begin + tid];
-            const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
-            if (active) {
-                const int ip = g.free_pose[a];
-                const Rt T = load_Rt(sRt, ip);
-                const int l = g.obs_pt[k];
-                const Vec3 pw{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
-                Vec3 pc;
-                const Vec3 e = stereo_error(T, pw, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
-                const double c2 = chi2_of(e, iv);
-                double rho0 = c2, rho1 = 1.0;
-                if (delta > 0.0) huber(c2, delta, rho0, rho1);
-                const double wo = rho1 * iv;
-                double Jx[18];
-                stereo_jacobian_pose(pc, K, Jx);
-                int q = 0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int cc = r; cc < 6; ++cc, ++q)
-                        acc[q] = Jx[r] * wo * Jx[cc] + Jx[6 + r] * wo * Jx[6 + cc] + Jx[12 + r] * wo * Jx[12 + cc];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) acc[21 + r] = -(Jx[r] * wo * e.x + Jx[6 + r] * wo * e.y + Jx[12 + r] * wo * e.z);
-            }
-        }
+        if (begin + tid < end) pose_obs_terms(g, g.pose_obs[begin + tid], load_Rt(sRt, g.free_pose[a]), pt, K, iv, delta, acc);
         const int wave = tid >> 6, lane = tid & 63;
         int off = 0, len = 27;
         ReduceScatter<27, 32>::run(acc, lane, off, len);
@@ -306,6 +315,64 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
         __syncthreads();
         if (tid < 27) g.hpp_part[27 * (size_t)c + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
     }
+}
+
+// One wheel-odometry edge: its five 6x6 / 6x1 contributions into odo_blk[e_] (120 doubles); returns its chi2
+// (0 and zero blocks when both poses are fixed: allVerticesFixed).  Shared with the fused small-window kernel.
+__device__ __forceinline__ double odo_edge_blocks(const DeviceGraph& g, const int e_, const double* __restrict__ pose, const double ic) {
+    const int i = g.odo_i[e_], j = g.odo_j[e_];
+    const bool fi = g.pose_free[i] >= 0, fj = g.pose_free[j] >= 0;
+    double* o = g.odo_blk + 120 * (size_t)e_;
+    if (!fi && !fj) { for (int q = 0; q < 120; ++q) o[q] = 0.0; return 0.0; }
+    double e[6], Ji[36], Jj[36];
+    odo_linearize(pose + POSE_STRIDE * i, pose + POSE_STRIDE * j, g.odo_tq + 7 * e_, e, Ji, Jj);
+    double c2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) c2 += e[d] * (ic * e[d]);
+    for (int r = 0; r < 6; ++r) {
+        for (int cc = 0; cc < 6; ++cc) {
+            double aii = 0, ajj = 0, aij = 0;
+            for (int d = 0; d < 6; ++d) {
+                aii += Ji[d * 6 + r] * ic * Ji[d * 6 + cc];
+                ajj += Jj[d * 6 + r] * ic * Jj[d * 6 + cc];
+                aij += Ji[d * 6 + r] * ic * Jj[d * 6 + cc];
+            }
+            o[r * 6 + cc] = fi ? aii : 0.0;
+            o[36 + r * 6 + cc] = fj ? ajj : 0.0;
+            o[72 + r * 6 + cc] = (fi && fj) ? aij : 0.0;
+        }
+        double bi = 0, bj = 0;
+        for (int d = 0; d < 6; ++d) { bi += Ji[d * 6 + r] * ic * e[d]; bj += Jj[d * 6 + r] * ic * e[d]; }
+        o[108 + r] = fi ? -bi : 0.0;
+        o[114 + r] = fj ? -bj : 0.0;
+    }
+    return c2;
+}
+
+// One range point: J^T Omega J (upper triangle) and -J^T Omega e added to acc[27]; returns its chi2.
+__device__ __forceinline__ double laser_point_terms(const DeviceGraph& g, const double* tq, const int z, const double il, double acc[27]) {
+    const Vec3 P{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] };
+    const double e = laser_error(tq, g.Tcr, P, g.grid);
+    double J[6];
+    laser_jacobian(tq, g.Tcr, P, g.grid, J);
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = r; cc < 6; ++cc, ++q) acc[q] += J[r] * il * J[cc];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] -= J[r] * il * e;
+    return e * (il * e);
+}
+// Entry t (< 27) of the reduced laser sums into the pseudo-edge slot Ne of odo_blk (full symmetric 6x6 + b).
+__device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const int t, const double v) {
+    double* o = g.odo_blk + 120 * (size_t)g.Ne;
+    if (t < 21) {
+        int r = 0, base = 0;
+        while (t >= base + (6 - r)) { base += 6 - r; ++r; }
+        const int cc = r + (t - base);
+        o[r * 6 + cc] = v; o[cc * 6 + r] = v;
+    } else o[108 + (t - 21)] = v;
 }
 
 // ================================================================= K3: wheel-odometry edges
@@ -319,33 +386,7 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const DeviceGraph g) {
     const int tid = threadIdx.x;
     double chi_acc = 0.0;
     for (int e_ = tid; e_ < g.Ne; e_ += 256) {
-        const int i = g.odo_i[e_], j = g.odo_j[e_];
-        const bool fi = g.pose_free[i] >= 0, fj = g.pose_free[j] >= 0;
-        double* o = g.odo_blk + 120 * (size_t)e_;
-        if (!fi && !fj) { for (int q = 0; q < 120; ++q) o[q] = 0.0; continue; }     // allVerticesFixed
-        double e[6], Ji[36], Jj[36];
-        odo_linearize(pose + POSE_STRIDE * i, pose + POSE_STRIDE * j, g.odo_tq + 7 * e_, e, Ji, Jj);
-        double c2 = 0.0;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) c2 += e[d] * (ic * e[d]);
-        chi_acc += c2;
-        for (int r = 0; r < 6; ++r) {
-            for (int cc = 0; cc < 6; ++cc) {
-                double aii = 0, ajj = 0, aij = 0;
-                for (int d = 0; d < 6; ++d) {
-                    aii += Ji[d * 6 + r] * ic * Ji[d * 6 + cc];
-                    ajj += Jj[d * 6 + r] * ic * Jj[d * 6 + cc];
-                    aij += Ji[d * 6 + r] * ic * Jj[d * 6 + cc];
-                }
-                o[r * 6 + cc] = fi ? aii : 0.0;
-                o[36 + r * 6 + cc] = fj ? ajj : 0.0;
-                o[72 + r * 6 + cc] = (fi && fj) ? aij : 0.0;
-            }
-            double bi = 0, bj = 0;
-            for (int d = 0; d < 6; ++d) { bi += Ji[d * 6 + r] * ic * e[d]; bj += Jj[d * 6 + r] * ic * e[d]; }
-            o[108 + r] = fi ? -bi : 0.0;
-            o[114 + r] = fj ? -bj : 0.0;
-        }
+        chi_acc += odo_edge_blocks(g, e_, pose, ic);
     }
     // laser occupied-space edges (EdgeOccupiedObservation, Omega = 1 / laserCovariance, Optimizer.cpp:232-249, no kernel):
     // all on one pose, so the workgroup reduces J^T Omega J (upper triangle) and -J^T Omega e into slot Ne of odo_blk.
@@ -357,18 +398,7 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const DeviceGraph g) {
 #pragma unroll
         for (int q = 0; q < 27; ++q) acc[q] = 0.0;
         for (int z = tid; z < g.Nz; z += 256) {
-            const Vec3 P{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] };
-            const double e = laser_error(tq, g.Tcr, P, g.grid);
-            double J[6];
-            laser_jacobian(tq, g.Tcr, P, g.grid, J);
-            chi_acc += e * (il * e);
-            int q = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int cc = r; cc < 6; ++cc, ++q) acc[q] += J[r] * il * J[cc];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[21 + r] -= J[r] * il * e;
+            chi_acc += laser_point_terms(g, tq, z, il, acc);
         }
         const int wave = tid >> 6, lane = tid & 63;
         int off = 0, len = 27;
@@ -376,18 +406,22 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const DeviceGraph g) {
         if (len >= 1) redz[wave * 27 + off] = acc[0];
         __syncthreads();
         if (tid < 27) {
-            const double v = redz[tid] + redz[27 + tid] + redz[54 + tid] + redz[81 + tid];
-            double* o = g.odo_blk + 120 * (size_t)g.Ne;
-            if (tid < 21) {
-                int r = 0, base = 0;
-                while (tid >= base + (6 - r)) { base += 6 - r; ++r; }
-                const int cc = r + (tid - base);
-                o[r * 6 + cc] = v; o[cc * 6 + r] = v;
-            } else o[108 + (tid - 21)] = v;
+            laser_store_slot(g, tid, redz[tid] + redz[27 + tid] + redz[54 + tid] + redz[81 + tid]);
         }
     }
     const double chi_tot = block_sum_256(chi_acc, red);
     if (tid == 0) { g.lin_part[2 * g.n_lin_a] = chi_tot; g.lin_part[2 * g.n_lin_a + 1] = 0.0; }
+}
+
+// One thread: chi2 / max|diag H| of a fresh linearisation; computeLambdaInit on the first iteration of a phase ([g2o-upstream] tau = 1e-5).
+__device__ __noinline__ void lin_finalize_update(LmState* st, const double chi_total, const double md_total) {
+    st->current_chi = chi_total;
+    st->max_diag = md_total;
+    if (st->phase_iter == 0) {
+        if (st->phase == 0) st->chi2_initial = chi_total;
+        st->lambda = st->gauss_newton ? 0.0 : 1e-5 * md_total;
+        st->ni = 2.0;
+    }
 }
 
 // Single workgroup, launched in the FIRST unit of a phase (and by the stage hook): sums Hpp/b_p, reduces the
@@ -418,38 +452,19 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g, cons
     __syncthreads();
     for (int s = 512; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
     const double md_total = red[0];
-    if (tid == 0) {
-        st->current_chi = chi_total;
-        st->max_diag = md_total;
-        if (st->phase_iter == 0) {
-            if (st->phase == 0) st->chi2_initial = chi_total;
-            st->lambda = st->gauss_newton ? 0.0 : 1e-5 * md_total;
-            st->ni = 2.0;
-        }
-    }
+    if (tid == 0) lin_finalize_update(st, chi_total, md_total);
 }
 
 // ================================================================= K5: Schur complement (gather form)
 // k_schur_partial: one wavefront per chunk of <= 64 co-observation pairs of ONE block (i <= j) of the reduced
 // camera matrix, one pair per lane:  Hpl_il (Hll_l + lambda I)^-1 Hpl_jl^T  (+ the b_s term on diagonal blocks),
 // reduce-scattered over the wave into 42 partial sums.
-__global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
-    const LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
-    const int lane = threadIdx.x & 63;
-    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
-    // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
-    // instead of eight (speed only; any placement is correct).  gridDim.x is a multiple of 8.
-    const int per_xcd = gridDim.x >> 3;
-    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int ch = wg * 4 + (threadIdx.x >> 6);
-    if (ch >= g.n_sch) return;
-    const double lambda = st->lambda;
+// One wavefront, one chunk (<= 64 co-observation pairs of one block): shared by k_schur_partial and the fused small-window kernel.
+__device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, const int lane, const double lambda, const double* __restrict__ pose) {
     // one descriptor load, then the pair list and the two poses can be fetched together (no dependent index chain)
     const int4 dsc = g.sch_desc[ch];
     const int e = dsc.x + lane, e_end = dsc.y;
     const bool diag = (dsc.z == dsc.w);
-    const double* pose = g.pose[st->sel];
     const Rt Ti = pose_to_Rt(pose + POSE_STRIDE * dsc.z);
     const Rt Tj = pose_to_Rt(pose + POSE_STRIDE * dsc.w);
     double acc[21];
@@ -508,17 +523,27 @@ __global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
     if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
 }
 
+__global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
+    const LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    const int lane = threadIdx.x & 63;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
+    // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
+    // instead of eight (speed only; any placement is correct).  gridDim.x is a multiple of 8.
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int ch = wg * 4 + (threadIdx.x >> 6);
+    if (ch >= g.n_sch) return;
+    schur_chunk(g, ch, lane, st->lambda, g.pose[st->sel]);
+}
+
 // k_schur_finalize: one wavefront per stored block:
 //   S_ij = Hpp_ij (+lambda I on the diagonal) - sum of the chunk partials;  diagonal waves also produce
 //   b_s_i = b_p_i - ..., Hpp_ii / b_p_i (for computeScale) and Minv_i = S_ii^-1 (block-Jacobi preconditioner).
 // Poses without any active edge are outside g2o's active set: their block is pinned to I (dx = 0).
 // It also clears the hand-off words of the persistent PCG that follows (one zeroing per damped solve).
-__global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
-    LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= g.n_blk) return;
+// One wavefront, one stored block of S: shared by k_schur_finalize and the fused small-window kernel.
+__device__ __forceinline__ void schur_block(const DeviceGraph& g, LmState* st, const int b, const int lane) {
     {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
         const int nwords = 4 * 6 * g.Npf;
         for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
@@ -578,6 +603,15 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
         st->n_active[1] += 1;
         if (st->mode & MODE_LIN) st->n_active[0] += 1;
     }
+}
+
+__global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= g.n_blk) return;
+    schur_block(g, st, b, lane);
 }
 
 // ================================================================= K6: block-Jacobi PCG on S, persistent
@@ -1069,6 +1103,70 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
     }
 }
 
+// K7 + trial chi2 for one landmark handled by G lanes: dl = (Hll + lambda I)^-1 (b_l - sum_i Hpl_il^T x_i), the trial point,
+// and the robust chi2 of its edges at the trial state.  sRt = trial poses, sRt0 = poses of the linearisation point.
+template <int G>
+__device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int l, const bool lvalid, const int sub, const double* sRt, const double* sRt0,
+                                                 const double* __restrict__ pt, double* __restrict__ pt_t, const double lambda, const Intrinsics& K,
+                                                 const double iv, const double delta, double& chi_acc, double& scale_acc) {
+    int k0 = 0, k1 = 0;
+    Vec3 pw{ 0, 0, 0 };
+    bool lfree = false;
+    if (lvalid) {
+        k0 = g.lm_ptr[l]; k1 = g.lm_ptr[l + 1];
+        pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
+        lfree = !g.pt_fixed[l];
+    }
+    // c_l = b_l - sum_i Hpl_il^T x_i
+    double t0 = 0, t1 = 0, t2 = 0, any = 0.0;
+    for (int k = k0 + sub; k < k1; k += G) {
+        const double w = g.obs_w[k];
+        if (w == 0.0) continue;
+        any = 1.0;
+        const int ipk = g.obs_pose[k];
+        const int a = g.pose_free[ipk];
+        if (a < 0 || !lfree) continue;
+        const double2* seed = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)k);
+        const double2 s0 = seed[0], s1 = seed[1];
+        double Wv[18];
+        hpl_tile(load_Rt(sRt0, ipk), Vec3{ s0.x, s0.y, s1.x }, s1.y, K, Wv);
+        const double* xp = g.x + 6 * (size_t)a;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { const double xr = xp[r]; t0 += Wv[r * 3] * xr; t1 += Wv[r * 3 + 1] * xr; t2 += Wv[r * 3 + 2] * xr; }
+    }
+    t0 = group_sum<G>(t0); t1 = group_sum<G>(t1); t2 = group_sum<G>(t2);
+    any = group_max<G>(any);
+    double d0 = 0, d1 = 0, d2 = 0;
+    if (lvalid && lfree && any != 0.0) {
+        const double* H = g.Hll + 6 * (size_t)l;
+        const double* B = g.bl + 3 * (size_t)l;
+        const double h[6] = { H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda };
+        double D[6];
+        sym3_inverse(h, D);
+        const double c0 = B[0] - t0, c1 = B[1] - t1, c2 = B[2] - t2;
+        d0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
+        d1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
+        d2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
+        if (sub == 0) scale_acc += d0 * (lambda * d0 + B[0]) + d1 * (lambda * d1 + B[1]) + d2 * (lambda * d2 + B[2]);
+    }
+    const Vec3 pn{ pw.x + d0, pw.y + d1, pw.z + d2 };         // VertexPointXYZ::oplus
+    if (lvalid && sub == 0) {
+        pt_t[3 * l] = pn.x; pt_t[3 * l + 1] = pn.y; pt_t[3 * l + 2] = pn.z;
+        g.dxl[3 * (size_t)l] = d0; g.dxl[3 * (size_t)l + 1] = d1; g.dxl[3 * (size_t)l + 2] = d2;
+    }
+    // computeActiveErrors + activeRobustChi2 at the trial state
+    for (int k = k0 + sub; k < k1; k += G) {
+        if (g.obs_w[k] == 0.0) continue;
+        const Rt T = load_Rt(sRt, g.obs_pose[k]);
+        Vec3 pc;
+        const Vec3 e = stereo_error(T, pn, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
+        const double c2 = chi2_of(e, iv);
+        double rho0 = c2, rho1 = 1.0;
+        if (delta > 0.0) huber(c2, delta, rho0, rho1);
+        chi_acc += rho0;
+    }
+}
+
 // ================================================================= K7/K8 + chi2 at the trial state
 template <int G>
 __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
@@ -1112,63 +1210,8 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
     constexpr int LPW = 256 / G;
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
-    int k0 = 0, k1 = 0;
-    Vec3 pw{ 0, 0, 0 };
-    bool lfree = false;
-    if (lvalid) {
-        k0 = g.lm_ptr[l]; k1 = g.lm_ptr[l + 1];
-        pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
-        lfree = !g.pt_fixed[l];
-    }
-    // c_l = b_l - sum_i Hpl_il^T x_i
-    double t0 = 0, t1 = 0, t2 = 0, any = 0.0;
-    for (int k = k0 + sub; k < k1; k += G) {
-        const double w = g.obs_w[k];
-        if (w == 0.0) continue;
-        any = 1.0;
-        const int ipk = g.obs_pose[k];
-        const int a = g.pose_free[ipk];
-        if (a < 0 || !lfree) continue;
-        const double2* seed = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)k);
-        const double2 s0 = seed[0], s1 = seed[1];
-        double Wv[18];
-        hpl_tile(load_Rt(sRt0, ipk), Vec3{ s0.x, s0.y, s1.x }, s1.y, K, Wv);
-        const double* xp = g.x + 6 * (size_t)a;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { const double xr = xp[r]; t0 += Wv[r * 3] * xr; t1 += Wv[r * 3 + 1] * xr; t2 += Wv[r * 3 + 2] * xr; }
-    }
-    t0 = group_sum<G>(t0); t1 = group_sum<G>(t1); t2 = group_sum<G>(t2);
-    any = group_max<G>(any);
-    double d0 = 0, d1 = 0, d2 = 0, scale_acc = 0.0;
-    if (lvalid && lfree && any != 0.0) {
-        const double* H = g.Hll + 6 * (size_t)l;
-        const double* B = g.bl + 3 * (size_t)l;
-        const double h[6] = { H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda };
-        double D[6];
-        sym3_inverse(h, D);
-        const double c0 = B[0] - t0, c1 = B[1] - t1, c2 = B[2] - t2;
-        d0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
-        d1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
-        d2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
-        if (sub == 0) scale_acc = d0 * (lambda * d0 + B[0]) + d1 * (lambda * d1 + B[1]) + d2 * (lambda * d2 + B[2]);
-    }
-    const Vec3 pn{ pw.x + d0, pw.y + d1, pw.z + d2 };         // VertexPointXYZ::oplus
-    if (lvalid && sub == 0) {
-        pt_t[3 * l] = pn.x; pt_t[3 * l + 1] = pn.y; pt_t[3 * l + 2] = pn.z;
-        g.dxl[3 * (size_t)l] = d0; g.dxl[3 * (size_t)l + 1] = d1; g.dxl[3 * (size_t)l + 2] = d2;
-    }
-    // computeActiveErrors + activeRobustChi2 at the trial state
-    double chi_acc = 0.0;
-    for (int k = k0 + sub; k < k1; k += G) {
-        if (g.obs_w[k] == 0.0) continue;
-        const Rt T = load_Rt(sRt, g.obs_pose[k]);
-        Vec3 pc;
-        const Vec3 e = stereo_error(T, pn, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
-        const double c2 = chi2_of(e, iv);
-        double rho0 = c2, rho1 = 1.0;
-        if (delta > 0.0) huber(c2, delta, rho0, rho1);
-        chi_acc += rho0;
-    }
+    double chi_acc = 0.0, scale_acc = 0.0;
+    backsub_landmark<G>(g, l, lvalid, sub, sRt, sRt0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
     if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; }
@@ -1176,21 +1219,9 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
 
 // ================================================================= K9: Levenberg-Marquardt control
 // [g2o-upstream] OptimizationAlgorithmLevenberg::solve, second half; one workgroup.  Sets the gate of the next unit.
-__global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
-    LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const bool ok = !st->solver_failed && !st->pcg_timeout;
-    const double lambda = st->lambda;
-    double chi = 0.0, sc = 0.0;
-    if (ok) {
-        for (int w = tid; w < g.n_lin_a + 1; w += 256) { chi += g.trial_part[2 * w]; sc += g.trial_part[2 * w + 1]; }
-        for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
-    }
-    chi = block_sum_256(chi, red);
-    sc = block_sum_256(sc, red);
-    if (tid != 0) return;
+// The scalar half of [g2o-upstream] OptimizationAlgorithmLevenberg::solve (and the Gauss-Newton variant): one thread.
+// ok = the linear solve succeeded; chi / sc = robust chi2 at the trial state and computeScale's sum.
+__device__ __noinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc) {
     const int ph = st->phase;
     st->trials_run[ph] += 1;
     st->solver_failed = 0;
@@ -1240,6 +1271,24 @@ __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
     } else {
         st->mode = MODE_TRIAL;                      // same linearisation, larger lambda
     }
+}
+
+__global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const bool ok = !st->solver_failed && !st->pcg_timeout;
+    const double lambda = st->lambda;
+    double chi = 0.0, sc = 0.0;
+    if (ok) {
+        for (int w = tid; w < g.n_lin_a + 1; w += 256) { chi += g.trial_part[2 * w]; sc += g.trial_part[2 * w + 1]; }
+        for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
+    }
+    chi = block_sum_256(chi, red);
+    sc = block_sum_256(sc, red);
+    if (tid != 0) return;
+    lm_decide(st, ok, lambda, chi, sc);
 }
 
 // ================================================================= K10: per-edge chi2, outlier marking
@@ -1299,16 +1348,8 @@ __global__ __launch_bounds__(256) void k_eval(const DeviceGraph g, const int mar
 }
 
 // One workgroup: closes a phase (Optimizer.cpp:271-280 after phase 1, :315-318 after phase 2) and arms the next.
-__global__ __launch_bounds__(256) void k_phase_end(const DeviceGraph g, const int nparts, const int phase_just_done, const int next_max_iter) {
-    LmState* st = g.st;
-    if (st->status != 0) return;
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    double chi = 0.0, nout = 0.0;
-    for (int w = tid; w < nparts; w += 256) { chi += g.trial_part[2 * w]; nout += g.trial_part[2 * w + 1]; }
-    chi = block_sum_256(chi, red);
-    nout = block_sum_256(nout, red);
-    if (tid != 0) return;
+// One thread: closes a phase (Optimizer.cpp:271-280 after phase 1, :315-318 after phase 2) and arms the next.
+__device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st, const double chi, const double nout, const int phase_just_done, const int next_max_iter) {
     if (phase_just_done == 0) {
         st->chi2_phase1 = chi; st->chi2_final = chi;
         if (st->max_iter <= 0) st->chi2_initial = chi;        // optimize(0): nothing linearised
@@ -1324,6 +1365,19 @@ __global__ __launch_bounds__(256) void k_phase_end(const DeviceGraph g, const in
         st->chi2_final = chi;
         if (chi > 1000000000000.0) st->status = 5;                       // VISFS_BA_ERR_HUGE_CHI2_2
     }
+}
+
+__global__ __launch_bounds__(256) void k_phase_end(const DeviceGraph g, const int nparts, const int phase_just_done, const int next_max_iter) {
+    LmState* st = g.st;
+    if (st->status != 0) return;
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double chi = 0.0, nout = 0.0;
+    for (int w = tid; w < nparts; w += 256) { chi += g.trial_part[2 * w]; nout += g.trial_part[2 * w + 1]; }
+    chi = block_sum_256(chi, red);
+    nout = block_sum_256(nout, red);
+    if (tid != 0) return;
+    phase_end_update(g, st, chi, nout, phase_just_done, next_max_iter);
 }
 
 // Arm phase 1 on a fresh graph (all edges level 0, as the reference builds a new optimizer per call);
@@ -1356,6 +1410,381 @@ __global__ void k_stage_arm(const DeviceGraph g, const double lambda, const int 
     LmState* st = g.st;
     st->done = 0; st->mode = mode; st->solver_failed = 0; st->lambda = lambda; st->phase_iter = 1;
     st->max_iter = 1 << 30; st->trial_q = 0; st->gauss_newton = 0;
+}
+
+// ================================================================= fused single-workgroup path (small windows)
+// The production window of VISFS (LocalMap/MapSize = 5: six poses, ~300 landmarks, ~1500 observations) is far too small
+// for one kernel per stage — a stage is a few microseconds of work behind a launch and a dependent-load chain.
+// k_small_optimize runs BOTH optimise phases, the outlier pass and the final evaluation (Optimizer.cpp:261-318) in ONE
+// launch of ONE 1024-thread workgroup: stages are separated by __syncthreads() instead of kernel boundaries, the LM
+// state machine (lm_decide / phase_end_update — the very functions the multi-kernel path runs) is stepped by thread 0
+// and re-read by everyone after the barrier, the reduced camera system (<= 64 x 64) is solved in LDS.  All arithmetic
+// goes through the same device functions as the multi-kernel path (lin_landmark<1>, pose_obs_terms, schur_chunk,
+// schur_block, backsub_landmark<1>, ...); only the reduction trees differ, so the two paths agree to rounding.
+constexpr int SM_T = 512;
+constexpr int SM_WAVES = SM_T / 64;
+constexpr int SM_LD = SM_MAX_N6 + 1;           // padded leading dimension of the dense S in LDS
+
+// Sum `a` and `b` (separately) over the workgroup; every thread gets both.  Fixed order: wave butterfly, waves 0..15.
+__device__ __forceinline__ void sm_block_sum2(double& a, double& b, double* red) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < SM_WAVES; ++w) { sa += red[2 * w]; sb += red[2 * w + 1]; }
+    a = sa; b = sb;
+}
+__device__ __forceinline__ double sm_block_max(double v, double* red) {
+    v = wave_max(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double m = red[0];
+#pragma unroll
+    for (int w = 1; w < SM_WAVES; ++w) m = fmax(m, red[w]);
+    return m;
+}
+__device__ __forceinline__ int ld_state(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// [g2o-upstream] LinearSolverPCG on the dense S in LDS: wave 0, lane r owns scalar row r (n6 <= 64).  Same recurrence,
+// tolerance and residual carry-over as k_pcg.
+__device__ __forceinline__ void sm_pcg(const DeviceGraph& g, LmState* st, const int n6, const double* sA, const double* sb, double* sd, double* sx) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < n6;
+    const int blk0 = 6 * (r / 6);
+    double m[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) m[c] = act ? g.Minv[36 * (size_t)(r / 6) + 6 * (r % 6) + c] : 0.0;
+    double rr = act ? sb[r] : 0.0;
+    auto apply_minv = [&](const double v) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sacc += m[c] * __shfl(v, (blk0 + c) & 63, 64);
+        return sacc;
+    };
+    double d = apply_minv(rr);
+    double dn = wave_sum(rr * d);
+    double d0 = 1e-6 * dn;
+    const double res_in = st->pcg_res_in;
+    if (res_in > 0.0 && res_in > d0) d0 = res_in;
+    double x = 0.0;
+    int iter = 0;
+    while (true) {
+        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
+        if (act) sd[r] = d;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        double q = 0.0;
+        if (act) { const double* Ar = sA + r * SM_LD; for (int c = 0; c < n6; ++c) q += Ar[c] * sd[c]; }
+        const double dq = wave_sum(d * q);
+        const double alpha = dn / dq;
+        x += alpha * d;
+        rr -= alpha * q;
+        const double sv = apply_minv(rr);
+        const double dnn = wave_sum(rr * sv);
+        const double beta = dnn / dn;
+        d = sv + beta * d;
+        dn = dnn;
+        iter += 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (act) sx[r] = x;
+    if (r == 0) {
+        st->pcg_residual = 0.5 * dn;
+        st->pcg_iter = iter;
+        st->pcg_total += iter;
+        if (iter > st->pcg_max) st->pcg_max = iter;
+    }
+}
+
+// Dense Cholesky of S in LDS by ONE wavefront (lane r owns row r, right-looking, lower triangle), then the two triangular
+// solves.  Wave-synchronous: LDS traffic of one wave is ordered, a wave barrier separates the steps.  The eliminated
+// column is first copied to sCol, so the row update reads two arrays and writes one at distinct, provable offsets and
+// its loads can be batched (a register-resident row per lane, as in k_chol_diag, sent the compiler into a >10 min build
+// inside these large kernels).  A non-positive or non-finite pivot sets LmState::solver_failed.
+__device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double* __restrict__ sA, const double* __restrict__ sb,
+                                                double* __restrict__ sx, double* __restrict__ sCol) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < n;
+    bool failed = false;
+    for (int c = 0; c < n; ++c) {
+        const double p = sA[c * SM_LD + c];
+        if (!(p > 0.0) || !(p <= DBL_MAX)) { failed = true; break; }
+        const double piv = sqrt(p), inv = 1.0 / piv;
+        double l = 0.0;
+        if (act && r >= c) { l = (r == c) ? piv : sA[r * SM_LD + c] * inv; sA[r * SM_LD + c] = l; }
+        sCol[r] = l;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (act && r > c) {
+            double* __restrict__ Ar = sA + r * SM_LD;
+            int c2 = c + 1;
+            for (; c2 + 8 <= r + 1; c2 += 8) {
+                double v[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u] = Ar[c2 + u]; w[u] = sCol[c2 + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) Ar[c2 + u] = v[u] - l * w[u];
+            }
+            for (; c2 <= r; ++c2) Ar[c2] -= l * sCol[c2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (failed) { if (r == 0) st->solver_failed = 1; return; }
+    const double inv = act ? 1.0 / sA[r * SM_LD + r] : 1.0;
+    double acc = act ? sb[r] : 0.0;
+    for (int c = 0; c < n; ++c) {                           // L y = b
+        const double yc = __shfl(acc * inv, c, 64);
+        if (act && r > c) acc -= sA[r * SM_LD + c] * yc;
+        if (r == c) acc = yc;
+    }
+    for (int c = n - 1; c >= 0; --c) {                      // L^T x = y
+        const double xc = __shfl(acc * inv, c, 64);
+        if (act && r < c) acc -= sA[c * SM_LD + r] * xc;
+        if (r == c) acc = xc;
+    }
+    if (act) sx[r] = acc;
+}
+__device__ __forceinline__ void sm_solve(const DeviceGraph& g, LmState* st, const int solver, const int n6, double* sA, const double* sb, double* sd, double* sx) {
+    if (solver == 2) sm_pcg(g, st, n6, sA, sb, sd, sx);
+    else sm_cholesky_lds(st, n6, sA, sb, sx, sd);
+}
+
+// Small reduced camera systems (6 Npf <= 64): ONE workgroup does what k_schur_finalize + k_pcg (five cross-workgroup
+// hand-offs per iteration for nothing) or + the four direct-solver launches do on the general path: S / b_s / Minv per
+// stored block, the dense system in LDS, PCG or Cholesky on one wavefront, K8 (pose oplus).
+__global__ __launch_bounds__(512) void k_small_solve(const DeviceGraph g, const int solver) {
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    __shared__ double sA[SM_MAX_N6 * SM_LD];
+    __shared__ double sb[SM_MAX_N6], sx[SM_MAX_N6], sd[SM_MAX_N6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n6 = 6 * g.Npf;
+    for (int b = wave; b < g.n_blk; b += 8) schur_block(g, st, b, lane);
+    for (int t = tid; t < n6 * SM_LD; t += 512) sA[t] = 0.0;
+    __syncthreads();
+    for (int t = tid; t < g.n_blk * 36; t += 512) {
+        const int b = t / 36, q = t - 36 * b, r = q / 6, c = q - 6 * r;
+        const int i = g.blk_i[b], j = g.blk_j[b];
+        const double v = g.S[t];
+        sA[(6 * i + r) * SM_LD + 6 * j + c] = v;
+        if (i != j) sA[(6 * j + c) * SM_LD + 6 * i + r] = v;
+    }
+    for (int t = tid; t < n6; t += 512) sb[t] = g.bs[t];
+    __syncthreads();
+    if (wave == 0) sm_solve(g, st, solver, n6, sA, sb, sd, sx);
+    __syncthreads();
+    if (ld_state(&st->solver_failed) != 0) return;
+    for (int t = tid; t < n6; t += 512) g.x[t] = sx[t];
+    const int sel = st->sel;
+    for (int a = tid; a < g.Npf; a += 512) {
+        const int ip = g.free_pose[a];
+        double dx[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dx[q] = sx[6 * a + q];
+        pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+    }
+}
+
+#ifdef VISFS_BA_STAMPS
+#define SM_STAMP(slot) do { if (tid == 0 && units <= 3) g.stamps[(units - 1) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SM_STAMP(slot) do { } while (0)
+#endif
+__global__ __launch_bounds__(SM_T) void k_small_optimize(const DeviceGraph g, const int solver, const int half) {
+    LmState* st = g.st;
+    __shared__ double sRt[SM_MAX_POSES * 12];              // R|t of the estimate
+    __shared__ double sRtT[SM_MAX_POSES * 12];             // ... of the trial state
+    __shared__ double sA[SM_MAX_N6 * SM_LD];               // dense reduced camera matrix / its Cholesky factor
+    __shared__ double sb[SM_MAX_N6], sx[SM_MAX_N6], sd[SM_MAX_N6];
+    __shared__ double sPart[SM_MAX_WCHUNKS * 27];          // per-wave partials of the pose-major pass, then of the laser sums
+    __shared__ double sRed[2 * SM_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Intrinsics K = intr_of(g);
+    const double iv = g.inv_pixel_var, delta = g.huber_delta, ic = g.inv_odo_cov, il = g.inv_laser_cov;
+    const int n6 = 6 * g.Npf;
+    int units = 0;
+    const int max_units = 32 * (half > 0 ? half : 1) + 32;     // every unit ends an iteration or grows lambda: bounded anyway
+
+    for (int phase = 0; phase < 2; ++phase) {
+        while (true) {
+            __syncthreads();
+            const int mode = ld_state(&st->mode);
+            if (mode == 0) break;
+            if (++units > max_units) { if (tid == 0) { st->status = 8; st->done = 1; st->mode = 0; } break; }
+            const int sel = ld_state(&st->sel);
+            const double* pose = g.pose[sel];
+            const double* pt = g.pt[sel];
+            if (mode & MODE_LIN) {
+                SM_STAMP(0);
+                const bool first = ld_state(&st->phase_iter) == 0;
+                stage_poses(pose, g.Np, sRt);
+                __syncthreads();
+                double chi_acc = 0.0, md = 0.0;
+                for (int l = tid; l < g.Nl; l += SM_T) lin_landmark<1>(g, l, true, 0, sRt, pt, K, iv, delta, chi_acc, md);
+                SM_STAMP(1);
+                // pose-major pass: one wave per 64 observations of a LIN_CHUNK; the four partials of a chunk are added in
+                // role B's order, so hpp_part comes out bit-identical to k_linearize's
+                for (int wc = wave; wc < 4 * g.n_chunks; wc += SM_WAVES) {
+                    const int c = wc >> 2;
+                    const int idx = g.chunk_ptr[c] + 64 * (wc & 3) + lane, end = g.chunk_ptr[c + 1];
+                    double acc[27];
+#pragma unroll
+                    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+                    if (idx < end) pose_obs_terms(g, g.pose_obs[idx], load_Rt(sRt, g.free_pose[g.chunk_pose[c]]), pt, K, iv, delta, acc);
+                    int off = 0, len = 27;
+                    ReduceScatter<27, 32>::run(acc, lane, off, len);
+                    if (len >= 1) sPart[wc * 27 + off] = acc[0];
+                }
+                for (int e_ = tid; e_ < g.Ne; e_ += SM_T) chi_acc += odo_edge_blocks(g, e_, pose, ic);
+                __syncthreads();
+                SM_STAMP(2);
+                for (int t = tid; t < 27 * g.n_chunks; t += SM_T) {
+                    const int c = t / 27, q = t - 27 * c;
+                    const double* pp = sPart + (4 * c) * 27 + q;
+                    g.hpp_part[t] = ((pp[0] + pp[27]) + pp[54]) + pp[81];
+                }
+                if (g.Nz > 0) {                            // laser edges: all on one pose, reduced into the pseudo-edge slot
+                    __syncthreads();                       // sPart is reused
+                    const double* tq = pose + POSE_STRIDE * g.laser_pose;
+                    double acc[27];
+#pragma unroll
+                    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+                    for (int z = tid; z < g.Nz; z += SM_T) chi_acc += laser_point_terms(g, tq, z, il, acc);
+                    int off = 0, len = 27;
+                    ReduceScatter<27, 32>::run(acc, lane, off, len);
+                    if (len >= 1) sPart[wave * 27 + off] = acc[0];
+                    __syncthreads();
+                    if (tid < 27) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int w = 0; w < SM_WAVES; ++w) v += sPart[w * 27 + tid];
+                        laser_store_slot(g, tid, v);
+                    }
+                }
+                __syncthreads();
+                if (first) {                               // computeLambdaInit needs max|diag H| and the chi2 of the linearisation
+                    for (int t = tid; t < g.Npf * 42; t += SM_T) {
+                        const int a = t / 42, q = t % 42;
+                        const double v = hpp_entry(g, a, q);
+                        if (q < 36) { g.Hpp[36 * (size_t)a + q] = v; if (q % 7 == 0) md = fmax(md, fabs(v)); }
+                        else g.bp[6 * (size_t)a + (q - 36)] = v;
+                    }
+                    double zero = 0.0;
+                    sm_block_sum2(chi_acc, zero, sRed);
+                    const double md_total = sm_block_max(md, sRed);
+                    if (tid == 0) lin_finalize_update(st, chi_acc, md_total);
+                }
+            }
+            __syncthreads();
+            const double lambda = st->lambda;
+            SM_STAMP(3);
+            // ---- one damped solve
+            for (int ch = wave; ch < g.n_sch; ch += SM_WAVES) schur_chunk(g, ch, lane, lambda, pose);
+            __syncthreads();
+            SM_STAMP(4);
+            for (int b = wave; b < g.n_blk; b += SM_WAVES) schur_block(g, st, b, lane);
+            for (int t = tid; t < n6 * SM_LD; t += SM_T) sA[t] = 0.0;
+            __syncthreads();
+            SM_STAMP(5);
+            for (int t = tid; t < g.n_blk * 36; t += SM_T) {
+                const int b = t / 36, q = t - 36 * b, r = q / 6, c = q - 6 * r;
+                const int i = g.blk_i[b], j = g.blk_j[b];
+                const double v = g.S[t];
+                sA[(6 * i + r) * SM_LD + 6 * j + c] = v;
+                if (i != j) sA[(6 * j + c) * SM_LD + 6 * i + r] = v;
+            }
+            for (int t = tid; t < n6; t += SM_T) sb[t] = g.bs[t];
+            __syncthreads();
+            SM_STAMP(6);
+            if (wave == 0) sm_solve(g, st, solver, n6, sA, sb, sd, sx);
+            __syncthreads();
+            SM_STAMP(7);
+            const bool ok = ld_state(&st->solver_failed) == 0;
+            double chi_t = 0.0, sc = 0.0;
+            if (ok) {
+                double* pose_t = g.pose[sel ^ 1];
+                double* pt_t = g.pt[sel ^ 1];
+                for (int t = tid; t < n6; t += SM_T) g.x[t] = sx[t];
+                for (int a = tid; a < g.Npf; a += SM_T) {
+                    const int ip = g.free_pose[a];
+                    double dx[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) dx[q] = sx[6 * a + q];
+                    pose_oplus(pose + POSE_STRIDE * ip, dx, pose_t + POSE_STRIDE * ip);
+                }
+                __syncthreads();
+                stage_poses(pose_t, g.Np, sRtT);
+                __syncthreads();
+                SM_STAMP(8);
+                for (int l = tid; l < g.Nl; l += SM_T) backsub_landmark<1>(g, l, true, 0, sRtT, sRt, pt, pt_t, lambda, K, iv, delta, chi_t, sc);
+                SM_STAMP(9);
+                for (int e_ = tid; e_ < g.Ne; e_ += SM_T) {
+                    const int i = g.odo_i[e_], j = g.odo_j[e_];
+                    if (g.pose_free[i] < 0 && g.pose_free[j] < 0) continue;
+                    double e[6];
+                    odo_error(pose_t + POSE_STRIDE * i, pose_t + POSE_STRIDE * j, g.odo_tq + 7 * e_, e);
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) chi_t += e[d] * (ic * e[d]);
+                }
+                for (int z = tid; z < g.Nz; z += SM_T) {
+                    const double e = laser_error(pose_t + POSE_STRIDE * g.laser_pose, g.Tcr, Vec3{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] }, g.grid);
+                    chi_t += e * (il * e);
+                }
+                for (int t = tid; t < n6; t += SM_T) { const double x = sx[t]; sc += x * (lambda * x + g.bp[t]); }
+                sm_block_sum2(chi_t, sc, sRed);
+                SM_STAMP(10);
+            }
+            if (tid == 0) lm_decide(st, ok, lambda, chi_t, sc);
+            SM_STAMP(11);
+        }
+        // ---- close the phase: per-edge chi2 at the estimate, outlier marking after phase 1 (Optimizer.cpp:270-303, :315-318)
+        __syncthreads();
+        if (ld_state(&st->status) == 0) {
+            const int sel = ld_state(&st->sel);
+            const double* pose = g.pose[sel];
+            const double* pt = g.pt[sel];
+            const int mark = (phase == 0);
+            stage_poses(pose, g.Np, sRt);
+            __syncthreads();
+            double chi = 0.0, nout = 0.0;
+            for (int k = tid; k < g.No; k += SM_T) {
+                const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
+                double c2 = 0.0;
+                if (active) {
+                    const int l = g.obs_pt[k];
+                    Vec3 pc;
+                    const Vec3 e = stereo_error(load_Rt(sRt, g.obs_pose[k]), Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] }, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
+                    c2 = chi2_of(e, iv);
+                    double rho0 = c2, rho1 = 1.0;
+                    if (delta > 0.0) huber(c2, delta, rho0, rho1);
+                    chi += rho0;
+                    if (mark && delta > 0.0 && c2 > delta) { g.obs_level[k] = 1; g.obs_outlier[k] = 1; nout += 1.0; }
+                }
+                if (mark) g.obs_chi2_out[k] = c2;
+            }
+            for (int e_ = tid; e_ < g.Ne; e_ += SM_T) {
+                const int i = g.odo_i[e_], j = g.odo_j[e_];
+                if (g.pose_free[i] < 0 && g.pose_free[j] < 0) continue;
+                double e[6];
+                odo_error(pose + POSE_STRIDE * i, pose + POSE_STRIDE * j, g.odo_tq + 7 * e_, e);
+#pragma unroll
+                for (int d = 0; d < 6; ++d) chi += e[d] * (ic * e[d]);
+            }
+            for (int z = tid; z < g.Nz; z += SM_T) {
+                const double e = laser_error(pose + POSE_STRIDE * g.laser_pose, g.Tcr, Vec3{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] }, g.grid);
+                chi += e * (il * e);
+            }
+            sm_block_sum2(chi, nout, sRed);
+            if (tid == 0) phase_end_update(g, st, chi, nout, phase, phase == 0 ? half : 0);
+        }
+        __syncthreads();
+    }
 }
 
 // ================================================================= launchers
@@ -1451,6 +1880,20 @@ void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int rest
 
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s) {
     hipLaunchKernelGGL(k_stage_arm, dim3(1), dim3(1), 0, s, g, lambda, mode);
+}
+
+bool small_path_fits(const DeviceGraph& g) {
+    return g.Np <= SM_MAX_POSES && 6 * g.Npf <= SM_MAX_N6 && g.Npf >= 1 && 4 * g.n_chunks <= SM_MAX_WCHUNKS && g.No <= SM_MAX_OBS && g.n_sch <= SM_MAX_SCH;
+}
+
+bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= SM_MAX_N6; }
+
+void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s) {
+    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(512), 0, s, g, solver);
+}
+
+void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s) {
+    hipLaunchKernelGGL(k_small_optimize, dim3(1), dim3(SM_T), 0, s, g, solver, half);
 }
 
 int configure_kernels(const DeviceGraph& g) {

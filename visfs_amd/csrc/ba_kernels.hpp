@@ -19,6 +19,10 @@ void launch_direct(const DeviceGraph& g, hipStream_t s);             // dense as
 void launch_backsub(const DeviceGraph& g, hipStream_t s);
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
+bool small_solve_fits(const DeviceGraph& g);                         // 6 Npf <= 64: S is finalised and solved by one workgroup
+void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s);   // k_schur_finalize + solver + K8 in one launch
+bool small_path_fits(const DeviceGraph& g);                          // the window qualifies for the fused single-workgroup path
+void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s);   // both phases + outlier pass in one launch
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
 
 }  // namespace visfs_ba
