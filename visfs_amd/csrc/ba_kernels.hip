@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
 // [g2o-upstream] OptimizationAlgorithmLevenberg::solve, second half; one workgroup.  Sets the gate of the next unit.
 // The scalar half of [g2o-upstream] OptimizationAlgorithmLevenberg::solve (and the Gauss-Newton variant): one thread.
 // ok = the linear solve succeeded; chi / sc = robust chi2 at the trial state and computeScale's sum.
-__device__ __noinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc) {
+__device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc) {
     const int ph = st->phase;
     st->trials_run[ph] += 1;
     st->solver_failed = 0;
@@ -1272,6 +1272,8 @@ __device__ __noinline__ void lm_decide(LmState* st, const bool ok, const double 
         st->mode = MODE_TRIAL;                      // same linearisation, larger lambda
     }
 }
+
+__device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc); }
 
 __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
     LmState* st = g.st;
@@ -1740,7 +1742,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const DeviceGraph g, co
                 sm_block_sum2(chi_t, sc, sRed);
                 SM_STAMP(10);
             }
-            if (tid == 0) lm_decide(st, ok, lambda, chi_t, sc);
+            if (tid == 0) lm_decide_call(st, ok, lambda, chi_t, sc);
             SM_STAMP(11);
         }
         // ---- close the phase: per-edge chi2 at the estimate, outlier marking after phase 1 (Optimizer.cpp:270-303, :315-318)
