@@ -109,6 +109,15 @@ namespace {
 
 int bad(visfs_ba_handle* h, const char* msg) { h->err = msg; return VISFS_BA_ERR_BAD_ARGUMENT; }
 
+// No exception may cross the C ABI: host allocations (std::vector, std::string, std::thread) can throw.
+template <typename F>
+int guarded(visfs_ba_handle* h, F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { try { if (h) h->err = "out of host memory"; } catch (...) {} return VISFS_BA_ERR_DEVICE; }
+    catch (const std::exception& e) { try { if (h) h->err = e.what(); } catch (...) {} return VISFS_BA_ERR_DEVICE; }
+    catch (...) { return VISFS_BA_ERR_DEVICE; }
+}
+
 void ws_release(Workspace& w) {
     if (w.d_base) (void)hipFree(w.d_base);
     if (w.h_base) (void)hipHostFree(w.h_base);
@@ -711,12 +720,14 @@ int visfs_ba_create(const visfs_ba_params* params, int device_index, visfs_ba_ha
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) return VISFS_BA_ERR_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VISFS_BA_ERR_DEVICE;     // kernels are built for gfx950 only
-    visfs_ba_handle* h = new visfs_ba_handle();
-    h->prm = *params;
-    h->device = device_index;
-    if (ws_init(h, h->ws) != VISFS_BA_OK) { delete h; return VISFS_BA_ERR_DEVICE; }
-    *out = h;
-    return VISFS_BA_OK;
+    return guarded(nullptr, [&]() {
+        visfs_ba_handle* h = new visfs_ba_handle();
+        h->prm = *params;
+        h->device = device_index;
+        if (ws_init(h, h->ws) != VISFS_BA_OK) { delete h; return (int)VISFS_BA_ERR_DEVICE; }
+        *out = h;
+        return (int)VISFS_BA_OK;
+    });
 }
 
 void visfs_ba_destroy(visfs_ba_handle* h) {
@@ -825,7 +836,7 @@ void visfs_ba_unpack_pose(const double* tq, const double* Trc, double* Twr_out) 
 int visfs_ba_graph_upload(visfs_ba_handle* h, const visfs_ba_graph* g) {
     if (!h || !g) return VISFS_BA_ERR_BAD_ARGUMENT;
     if (h->prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return VISFS_BA_ERR_UNSUPPORTED; }
-    return ws_upload(h, h->ws, g);
+    return guarded(h, [&]() { return ws_upload(h, h->ws, g); });
 }
 
 int visfs_ba_graph_reset(visfs_ba_handle* h) {
@@ -838,44 +849,54 @@ int visfs_ba_graph_reset(visfs_ba_handle* h) {
 
 int visfs_ba_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
-    return ws_optimize(h, h->ws, stats);
+    return guarded(h, [&]() { return ws_optimize(h, h->ws, stats); });
 }
 
 int visfs_ba_graph_download(visfs_ba_handle* h, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
-    return ws_download(h, h->ws, pose_tq, point_xyz, obs_outlier, obs_chi2);
+    return guarded(h, [&]() { return ws_download(h, h->ws, pose_tq, point_xyz, obs_outlier, obs_chi2); });
 }
 
 int visfs_ba_solve_window(visfs_ba_handle* h, const visfs_ba_window* w, visfs_ba_result* r) {
     if (!h || !w || !r) return VISFS_BA_ERR_BAD_ARGUMENT;
-    return solve_window_on(h, h->ws, w, r);
+    return guarded(h, [&]() { return solve_window_on(h, h->ws, w, r); });
 }
 
 int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r) {
     if (!h || n < 0 || (n > 0 && (!w || !r))) return VISFS_BA_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < n; ++i) if (!w[i] || !r[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
     // independent windows: one workspace + stream + host thread per in-flight window
     // the persistent PCG needs all of a window's workgroups resident: keep the sum of the in-flight grids <= 256 CUs
-    int max_poses = 1;
-    for (int i = 0; i < n; ++i) max_poses = std::max(max_poses, (int)w[i]->n_poses);
-    const int lanes = std::max(1, std::min<int>(std::min<int>(n, 8), h->prm.solver == 2 ? 256 / max_poses : 8));
-    while ((int)h->batch.size() < lanes) h->batch.push_back(new Workspace());
-    std::vector<int> rcs(n, VISFS_BA_OK);
-    std::vector<std::string> errs(lanes);
-    std::vector<std::thread> th;
-    for (int t = 0; t < lanes; ++t) {
-        th.emplace_back([&, t]() {
-            (void)hipSetDevice(h->device);
-            visfs_ba_handle local;            // per-thread error string; shares params / device
-            local.prm = h->prm; local.device = h->device;
-            for (int i = t; i < n; i += lanes) rcs[i] = solve_window_on(&local, *h->batch[t], w[i], r[i]);
-            errs[t] = local.err;
-        });
-    }
-    for (auto& x : th) x.join();
-    int worst = VISFS_BA_OK;
-    for (int i = 0; i < n; ++i) if (rcs[i] == VISFS_BA_ERR_DEVICE) worst = VISFS_BA_ERR_DEVICE;
-    for (int t = 0; t < lanes; ++t) if (!errs[t].empty()) h->err = errs[t];
-    return worst;
+    return guarded(h, [&]() -> int {
+        int max_poses = 1;
+        for (int i = 0; i < n; ++i) max_poses = std::max(max_poses, (int)w[i]->n_poses);
+        const int lanes = std::max(1, std::min<int>(std::min<int>(n, 8), h->prm.solver == 2 ? 256 / max_poses : 8));
+        while ((int)h->batch.size() < lanes) h->batch.push_back(new Workspace());
+        std::vector<int> rcs(n, VISFS_BA_OK);
+        std::vector<std::string> errs(lanes);
+        std::vector<std::thread> th;
+        struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{ th };
+        th.reserve(lanes);
+        for (int t = 0; t < lanes; ++t) {
+            th.emplace_back([&, t]() noexcept {
+                int i = t;
+                try {
+                    (void)hipSetDevice(h->device);
+                    visfs_ba_handle local;            // per-thread error string; shares params / device
+                    local.prm = h->prm; local.device = h->device;
+                    for (; i < n; i += lanes) rcs[i] = solve_window_on(&local, *h->batch[t], w[i], r[i]);
+                    errs[t] = local.err;
+                } catch (...) {                       // nothing may escape a thread: mark this lane's remaining windows failed
+                    for (; i < n; i += lanes) { rcs[i] = VISFS_BA_ERR_DEVICE; r[i]->status = VISFS_BA_ERR_DEVICE; r[i]->n_poses_out = 0; }
+                }
+            });
+        }
+        for (auto& x : th) x.join();
+        int worst = VISFS_BA_OK;
+        for (int i = 0; i < n; ++i) if (rcs[i] == VISFS_BA_ERR_DEVICE) worst = VISFS_BA_ERR_DEVICE;
+        for (int t = 0; t < lanes; ++t) if (!errs[t].empty()) h->err = errs[t];
+        return worst;
+    });
 }
 
 int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
@@ -970,8 +991,7 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
     return VISFS_BA_OK;
 }
 
-int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {
-    if (!h || !dst) return VISFS_BA_ERR_BAD_ARGUMENT;
+static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {
     Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     const DeviceGraph& g = w.g;
@@ -1045,6 +1065,11 @@ int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t 
         }
     }
     return VISFS_BA_OK;
+}
+
+int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {
+    if (!h || !dst) return VISFS_BA_ERR_BAD_ARGUMENT;
+    return guarded(h, [&]() { return stage_fetch_impl(h, which, dst, n_doubles); });
 }
 
 }  // extern "C"
