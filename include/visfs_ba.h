@@ -269,6 +269,8 @@ typedef struct visfs_ba_profile {
     int64_t launches[VISFS_BA_K_COUNT];
     double  active_ms[VISFS_BA_K_COUNT];       /* the `active_launches` longest launches (gated-off launches return at once) */
     int64_t active_launches[VISFS_BA_K_COUNT]; /* launches that did work, counted on the device */
+    double  null_pair_ms;                      /* median elapsed time of an EMPTY event pair on the stream: what the event mechanism
+                                                  itself adds to every duration above (rocprofv3 kernel durations do not carry it) */
 } visfs_ba_profile;
 /* mask: bit k enables hipEvent pairs around every launch of kernel class k on the handle's own stream. */
 int visfs_ba_profile_enable(visfs_ba_handle* h, uint32_t mask);

@@ -103,7 +103,7 @@ class GraphInfo(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("total_ms", C.c_double * K_COUNT), ("launches", C.c_int64 * K_COUNT),
-                ("active_ms", C.c_double * K_COUNT), ("active_launches", C.c_int64 * K_COUNT)]
+                ("active_ms", C.c_double * K_COUNT), ("active_launches", C.c_int64 * K_COUNT), ("null_pair_ms", C.c_double)]
 
 
 class Stats(C.Structure):

@@ -158,8 +158,10 @@ class Solver:
     def profile_read(self):
         p = abi.Profile()
         self._check(self.lib.visfs_ba_profile_read(self.h, C.byref(p)), "profile_read")
-        return {abi.K_NAMES[k]: dict(total_ms=p.total_ms[k], launches=p.launches[k], active_ms=p.active_ms[k],
-                                     active_launches=p.active_launches[k]) for k in range(abi.K_COUNT) if p.launches[k]}
+        out = {abi.K_NAMES[k]: dict(total_ms=p.total_ms[k], launches=p.launches[k], active_ms=p.active_ms[k],
+                                    active_launches=p.active_launches[k]) for k in range(abi.K_COUNT) if p.launches[k]}
+        self.null_pair_ms = p.null_pair_ms        # what an empty event pair measures on this stream
+        return out
 
     # ---- stage hooks (parity tests)
     def linearize(self):

@@ -931,6 +931,24 @@ int visfs_ba_profile_read(visfs_ba_handle* h, visfs_ba_profile* out) {
         d.clear();
         w.active[k] = 0;
     }
+    // what an event pair costs by itself: 15 empty pairs back to back, median
+    if (w.stream) {
+        float el[15];
+        int n = 0;
+        w.ev_used = 0;
+        hipEvent_t ea[15], eb[15];
+        for (; n < 15; ++n) {
+            ea[n] = ProfScope::take(w); eb[n] = ProfScope::take(w);
+            if (!ea[n] || !eb[n]) break;
+            if (hipEventRecord(ea[n], w.stream) != hipSuccess || hipEventRecord(eb[n], w.stream) != hipSuccess) break;
+        }
+        if (n > 0 && hipStreamSynchronize(w.stream) == hipSuccess) {
+            int m = 0;
+            for (int i = 0; i < n; ++i) if (hipEventElapsedTime(&el[m], ea[i], eb[i]) == hipSuccess) ++m;
+            if (m > 0) { std::sort(el, el + m); out->null_pair_ms = el[m / 2]; }
+        }
+        w.ev_used = 0;
+    }
     return VISFS_BA_OK;
 }
 
