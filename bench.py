@@ -127,6 +127,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = vdist.reduce_max(t1 - t0, world, red_dev)
     total_iters = vdist.reduce_sum(iters, world, red_dev)
+    vdist.shutdown(world)                  # last collective done
 
     if rank != 0:
         return

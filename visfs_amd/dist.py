@@ -27,6 +27,14 @@ def init_process_group(backend, rank, world_size):
         dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
 
 
+def shutdown(world_size):
+    """Tear the process group down once the last collective is done (avoids the resource-leak warning at exit)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def barrier(world_size, device=None):
     if world_size > 1:
         import torch.distributed as dist
