@@ -23,6 +23,8 @@
 
 #include <float.h>
 
+#include <algorithm>
+
 namespace visfs_ba {
 
 // ---------------------------------------------------------------- wave helpers
@@ -129,6 +131,14 @@ __device__ __forceinline__ Rt load_Rt(const double* sRt, int i) {
 }
 
 __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Intrinsics{ g.fx, g.fy, g.cx, g.cy, g.bf }; }
+
+// Where a kernel finds its window.  One: the DeviceGraph travels by value in the kernel arguments (single window).
+// Many: independent windows solved side by side — blockIdx.y selects the window from an array in HBM,
+// every window is gated by its own LmState, so the same launch serves windows at different points of their LM loops.
+struct One { DeviceGraph g; };
+struct Many { const DeviceGraph* gs; };
+__device__ __forceinline__ const DeviceGraph& graph_of(const One& s) { return s.g; }
+__device__ __forceinline__ const DeviceGraph& graph_of(const Many& s) { return s.gs[blockIdx.y]; }
 
 // chi2() = e . (Omega e), Omega = I3 / pixelVariance (Optimizer.cpp:153)
 __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x * (iv * e.x) + e.y * (iv * e.y) + e.z * (iv * e.z); }
@@ -273,8 +283,9 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const int l, 
 }
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
-template <int G>
-__global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
+template <int G, class Src>
+__global__ __launch_bounds__(256) void k_linearize(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_LIN)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(256) void k_linearize(const DeviceGraph g) {
     } else {
         // ---- role B: pose-major chunk: upper triangle of Jx^T (rho' Omega) Jx and -Jx^T (rho' Omega) e
         const int c = bid - g.n_lin_a;
+        if (c >= g.n_chunks) return;                 // a batched launch is sized for the largest window
         const int a = g.chunk_pose[c];
         const int begin = g.chunk_ptr[c], end = g.chunk_ptr[c + 1];
         double acc[27];
@@ -377,7 +389,9 @@ __device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const int
 
 // ================================================================= K3: wheel-odometry edges
 // EdgePoseConstraint, Omega = I6 / odometryCovariance (Optimizer.cpp:117-121), no robust kernel.  One workgroup.
-__global__ __launch_bounds__(256) void k_odo_linearize(const DeviceGraph g) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_odo_linearize(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_LIN)) return;
     __shared__ double red[4];
@@ -427,7 +441,9 @@ __device__ __noinline__ void lin_finalize_update(LmState* st, const double chi_t
 // Single workgroup, launched in the FIRST unit of a phase (and by the stage hook): sums Hpp/b_p, reduces the
 // robust chi2 and max|diag H| of the linearisation and does computeLambdaInit ([g2o-upstream] tau = 1e-5).
 // Later units take current_chi from the accepted trial and lambda from k_decide.
-__global__ __launch_bounds__(1024) void k_lin_finalize(const DeviceGraph g, const int force) {
+template <class Src>
+__global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int force) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_LIN)) return;
     if (!force && st->phase_iter != 0) return;
@@ -523,14 +539,18 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
     if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
 }
 
-__global__ __launch_bounds__(256, 4) void k_schur_partial(const DeviceGraph g) {
+template <class Src>
+__global__ __launch_bounds__(256, 4) void k_schur_partial(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
     const int lane = threadIdx.x & 63;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
     // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
     // instead of eight (speed only; any placement is correct).  gridDim.x is a multiple of 8.
-    const int per_xcd = gridDim.x >> 3;
+    const int nwg = (((g.n_sch + 3) / 4) + 7) / 8 * 8;        // this window's share of the launch (== gridDim.x for a single window)
+    if ((int)blockIdx.x >= nwg) return;
+    const int per_xcd = nwg >> 3;
     const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int ch = wg * 4 + (threadIdx.x >> 6);
     if (ch >= g.n_sch) return;
@@ -605,7 +625,9 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, LmState* st, c
     }
 }
 
-__global__ __launch_bounds__(256) void k_schur_finalize(const DeviceGraph g) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
     const int lane = threadIdx.x & 63;
@@ -635,10 +657,12 @@ __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long 
 }
 
 // BPL = 6-blocks owned by each lane of wave 0 (ceil(Npf / 64)); MREG: the lane keeps its Minv block in registers (BPL == 1).
-template <int BPL, bool MREG>
-__global__ __launch_bounds__(256) void k_pcg(const DeviceGraph g) {
+template <int BPL, bool MREG, class Src>
+__global__ __launch_bounds__(256) void k_pcg(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
+    if ((int)blockIdx.x >= g.Npf) return;             // a batched launch is sized for the largest window
 #ifdef VISFS_BA_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == (unsigned)g.stamp_wg) g.stamps[127] = wall_clock64();
 #endif
@@ -1168,8 +1192,9 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int
 }
 
 // ================================================================= K7/K8 + chi2 at the trial state
-template <int G>
-__global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
+template <int G, class Src>
+__global__ __launch_bounds__(256) void k_backsub(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL) || st->solver_failed || st->pcg_timeout) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1183,6 +1208,7 @@ __global__ __launch_bounds__(256) void k_backsub(const DeviceGraph g) {
     const Intrinsics K = intr_of(g);
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
     const int bid = blockIdx.x, tid = threadIdx.x;
+    if (bid > g.n_lin_a) return;
     if (bid == g.n_lin_a) {
         // odometry chi2 at the trial state (the pose part of computeScale is done in k_decide)
         const double ic = g.inv_odo_cov;
@@ -1275,7 +1301,9 @@ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const doub
 
 __device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc); }
 
-__global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_decide(const Src src) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
     __shared__ double red[4];
@@ -1295,7 +1323,9 @@ __global__ __launch_bounds__(256) void k_decide(const DeviceGraph g) {
 
 // ================================================================= K10: per-edge chi2, outlier marking
 // Optimizer.cpp:270-303: computeActiveErrors; edges with chi2() > kernel->delta() (UNSQUARED) go to level 1.
-__global__ __launch_bounds__(256) void k_eval(const DeviceGraph g, const int mark) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_eval(const Src src, const int mark) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (st->status != 0) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1308,9 +1338,11 @@ __global__ __launch_bounds__(256) void k_eval(const DeviceGraph g, const int mar
     const Intrinsics K = intr_of(g);
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
     const int tid = threadIdx.x, bid = blockIdx.x;
+    const int nb = (g.No + 255) / 256 + 1;                 // this window's blocks (== gridDim.x for a single window)
+    if (bid >= nb) return;
     double chi_acc = 0.0;
     int n_out = 0;
-    if (bid == gridDim.x - 1) {
+    if (bid == nb - 1) {
         const double ic = g.inv_odo_cov;
         const double* pose = g.pose[sel];
         for (int e_ = tid; e_ < g.Ne; e_ += 256) {
@@ -1369,7 +1401,10 @@ __device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st,
     }
 }
 
-__global__ __launch_bounds__(256) void k_phase_end(const DeviceGraph g, const int nparts, const int phase_just_done, const int next_max_iter) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_phase_end(const Src src, const int phase_just_done, const int next_max_iter) {
+    const DeviceGraph& g = graph_of(src);
+    const int nparts = (g.No + 255) / 256 + 1;          // partials written by k_eval
     LmState* st = g.st;
     if (st->status != 0) return;
     __shared__ double red[4];
@@ -1384,7 +1419,9 @@ __global__ __launch_bounds__(256) void k_phase_end(const DeviceGraph g, const in
 
 // Arm phase 1 on a fresh graph (all edges level 0, as the reference builds a new optimizer per call);
 // restore != 0 also rewinds the estimates to the uploaded ones.
-__global__ __launch_bounds__(256) void k_reset(const DeviceGraph g, const int max_iter, const int gauss_newton, const int restore) {
+template <class Src>
+__global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter, const int gauss_newton, const int restore) {
+    const DeviceGraph& g = graph_of(src);
     const int gid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     if (restore) {
         for (int t = gid; t < g.Np * POSE_STRIDE; t += stride) { const double v = g.pose0[t]; g.pose[0][t] = v; g.pose[1][t] = v; }
@@ -1560,7 +1597,9 @@ __device__ __forceinline__ void sm_solve(const DeviceGraph& g, LmState* st, cons
 // Small reduced camera systems (6 Npf <= 64): ONE workgroup does what k_schur_finalize + k_pcg (five cross-workgroup
 // hand-offs per iteration for nothing) or + the four direct-solver launches do on the general path: S / b_s / Minv per
 // stored block, the dense system in LDS, PCG or Cholesky on one wavefront, K8 (pose oplus).
-__global__ __launch_bounds__(512) void k_small_solve(const DeviceGraph g, const int solver) {
+template <class Src>
+__global__ __launch_bounds__(512) void k_small_solve(const Src src, const int solver) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
     __shared__ double sA[SM_MAX_N6 * SM_LD];
@@ -1598,7 +1637,9 @@ __global__ __launch_bounds__(512) void k_small_solve(const DeviceGraph g, const 
 #else
 #define SM_STAMP(slot) do { } while (0)
 #endif
-__global__ __launch_bounds__(SM_T) void k_small_optimize(const DeviceGraph g, const int solver, const int half) {
+template <class Src>
+__global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const int solver, const int half) {
+    const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     __shared__ double sRt[SM_MAX_POSES * 12];              // R|t of the estimate
     __shared__ double sRtT[SM_MAX_POSES * 12];             // ... of the trial state
@@ -1790,49 +1831,106 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const DeviceGraph g, co
 }
 
 // ================================================================= launchers
-static inline size_t lds_poses(const DeviceGraph& g, int extra) { return (size_t)(12 * g.Np + extra) * sizeof(double); }
-
-template <int G>
-static void launch_lin_t(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize<G>, dim3(g.n_lin_a + g.n_chunks), dim3(256), lds_poses(g, 4 * 27), s, g);
+// Every launcher exists once, templated on the graph source: One{g} for a single window (grid.y = 1), Many{gs} for a batch
+// of independent windows (grid.y = number of windows, grid.x sized for the largest one; smaller windows' surplus
+// workgroups return at once).
+LaunchDims dims_of(const DeviceGraph& g) {
+    LaunchDims d;
+    d.group = g.group;
+    d.np = g.Np;
+    d.lin_blocks = g.n_lin_a + g.n_chunks;
+    d.backsub_blocks = g.n_lin_a + 1;
+    d.sch_wgs = g.n_sch > 0 ? (((g.n_sch + 3) / 4) + 7) / 8 * 8 : 0;
+    d.fin_wgs = (g.n_blk + 3) / 4;
+    d.pcg_rows = g.Npf;
+    d.pcg_lds = g.pcg_lds_bytes;
+    d.eval_blocks = (g.No + 255) / 256 + 1;
+    d.reset_blocks = std::min(std::max((g.No + 255) / 256, 1), 1024);
+    d.has_odo = (g.Ne > 0 || g.Nz > 0) ? 1 : 0;
+    return d;
 }
-template <int G>
-static void launch_backsub_t(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_backsub<G>, dim3(g.n_lin_a + 1), dim3(256), (size_t)(24 * g.Np + 8) * sizeof(double), s, g);
+LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
+    LaunchDims d = a;
+    d.np = std::max(a.np, b.np); d.lin_blocks = std::max(a.lin_blocks, b.lin_blocks); d.backsub_blocks = std::max(a.backsub_blocks, b.backsub_blocks);
+    d.sch_wgs = std::max(a.sch_wgs, b.sch_wgs); d.fin_wgs = std::max(a.fin_wgs, b.fin_wgs); d.pcg_rows = std::max(a.pcg_rows, b.pcg_rows);
+    d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
+    d.has_odo = a.has_odo | b.has_odo;
+    return d;
 }
+static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)(12 * d.np + extra) * sizeof(double); }
 
-void launch_linearize(const DeviceGraph& g, hipStream_t s) {
-    switch (g.group) {
-        case 4: launch_lin_t<4>(g, s); break;
-        case 8: launch_lin_t<8>(g, s); break;
-        case 16: launch_lin_t<16>(g, s); break;
-        case 32: launch_lin_t<32>(g, s); break;
-        default: launch_lin_t<64>(g, s); break;
+template <int G, class Src>
+static void launch_lin_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    hipLaunchKernelGGL((k_linearize<G, Src>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
+}
+template <int G, class Src>
+static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    hipLaunchKernelGGL((k_backsub<G, Src>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
+}
+template <class Src>
+static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    switch (d.group) {
+        case 4: launch_lin_t<4>(src, d, B, s); break;
+        case 8: launch_lin_t<8>(src, d, B, s); break;
+        case 16: launch_lin_t<16>(src, d, B, s); break;
+        case 32: launch_lin_t<32>(src, d, B, s); break;
+        default: launch_lin_t<64>(src, d, B, s); break;
     }
-    if (g.Ne > 0 || g.Nz > 0) hipLaunchKernelGGL(k_odo_linearize, dim3(1), dim3(256), 0, s, g);     // lin_part[n_lin_a] stays 0 otherwise
+    if (d.has_odo) hipLaunchKernelGGL((k_odo_linearize<Src>), dim3(1, B), dim3(256), 0, s, src);     // lin_part[n_lin_a] stays 0 otherwise
+}
+template <class Src>
+static void launch_lin_finalize_src(const Src& src, int force, int B, hipStream_t s) {
+    hipLaunchKernelGGL((k_lin_finalize<Src>), dim3(1, B), dim3(1024), 0, s, src, force);
+}
+template <class Src>
+static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    if (d.sch_wgs > 0) hipLaunchKernelGGL((k_schur_partial<Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
+}
+template <class Src>
+static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    hipLaunchKernelGGL((k_schur_finalize<Src>), dim3(d.fin_wgs, B), dim3(256), 0, s, src);
+}
+template <class Src>
+static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    if (d.pcg_rows <= 64) hipLaunchKernelGGL((k_pcg<1, true, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    else if (d.pcg_rows <= 128) hipLaunchKernelGGL((k_pcg<2, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    else hipLaunchKernelGGL((k_pcg<4, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
+}
+template <class Src>
+static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    switch (d.group) {
+        case 4: launch_backsub_t<4>(src, d, B, s); break;
+        case 8: launch_backsub_t<8>(src, d, B, s); break;
+        case 16: launch_backsub_t<16>(src, d, B, s); break;
+        case 32: launch_backsub_t<32>(src, d, B, s); break;
+        default: launch_backsub_t<64>(src, d, B, s); break;
+    }
+}
+template <class Src>
+static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
+    hipLaunchKernelGGL((k_eval<Src>), dim3(d.eval_blocks, B), dim3(256), lds_poses(d, 8), s, src, mark);
+    hipLaunchKernelGGL((k_phase_end<Src>), dim3(1, B), dim3(256), 0, s, src, phase_just_done, next_max_iter);
 }
 
-void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) {
-    hipLaunchKernelGGL(k_lin_finalize, dim3(1), dim3(1024), 0, s, g, force);
+// ---- single window
+void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, s); }
+void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) { launch_lin_finalize_src(One{ g }, force, 1, s); }
+void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_src(One{ g }, dims_of(g), 1, s); }
+void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) { launch_schur_finalize_src(One{ g }, dims_of(g), 1, s); }
+void launch_pcg(const DeviceGraph& g, hipStream_t s) { launch_pcg_src(One{ g }, dims_of(g), 1, s); }
+void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, s); }
+void launch_decide(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
+void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
+    launch_phase_end_src(One{ g }, dims_of(g), 1, phase_just_done, mark, next_max_iter, s);
 }
-
-void launch_schur_partial(const DeviceGraph& g, hipStream_t s) {
-    if (g.n_sch > 0) hipLaunchKernelGGL(k_schur_partial, dim3((((g.n_sch + 3) / 4) + 7) / 8 * 8), dim3(256), 0, s, g);
+void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s) {
+    hipLaunchKernelGGL((k_reset<One>), dim3(dims_of(g).reset_blocks), dim3(256), 0, s, One{ g }, max_iter, gauss_newton, restore);
 }
-
-void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_schur_finalize, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
+void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s) {
+    hipLaunchKernelGGL((k_small_solve<One>), dim3(1), dim3(512), 0, s, One{ g }, solver);
 }
-
-template <int BPL, bool MREG>
-static void launch_pcg_t(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL((k_pcg<BPL, MREG>), dim3(g.Npf), dim3(256), (size_t)g.pcg_lds_bytes, s, g);
-}
-
-void launch_pcg(const DeviceGraph& g, hipStream_t s) {
-    if (g.Npf <= 64) launch_pcg_t<1, true>(g, s);
-    else if (g.Npf <= 128) launch_pcg_t<2, false>(g, s);
-    else launch_pcg_t<4, false>(g, s);                          // Npf <= MAX_PCG_FREE_POSES = 256
+void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s) {
+    hipLaunchKernelGGL((k_small_optimize<One>), dim3(1), dim3(SM_T), 0, s, One{ g }, solver, half);
 }
 
 void launch_direct(const DeviceGraph& g, hipStream_t s) {
@@ -1853,35 +1951,40 @@ void launch_direct(const DeviceGraph& g, hipStream_t s) {
     hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, s, g);
 }
 
-void launch_backsub(const DeviceGraph& g, hipStream_t s) {
-    switch (g.group) {
-        case 4: launch_backsub_t<4>(g, s); break;
-        case 8: launch_backsub_t<8>(g, s); break;
-        case 16: launch_backsub_t<16>(g, s); break;
-        case 32: launch_backsub_t<32>(g, s); break;
-        default: launch_backsub_t<64>(g, s); break;
-    }
-}
-
-void launch_decide(const DeviceGraph& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, g);
-}
-
-void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
-    const int nb = (g.No + 255) / 256 + 1;
-    hipLaunchKernelGGL(k_eval, dim3(nb), dim3(256), lds_poses(g, 8), s, g, mark);
-    hipLaunchKernelGGL(k_phase_end, dim3(1), dim3(256), 0, s, g, nb, phase_just_done, next_max_iter);
-}
-
-void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s) {
-    int grid = (g.No + 255) / 256;
-    if (grid < 1) grid = 1;
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, s, g, max_iter, gauss_newton, restore);
-}
-
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s) {
     hipLaunchKernelGGL(k_stage_arm, dim3(1), dim3(1), 0, s, g, lambda, mode);
+}
+
+// ---- a batch of independent windows (gs: B DeviceGraphs in HBM; d: element-wise maximum of their launch geometry)
+void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int max_iter, int gauss_newton, int restore, hipStream_t s) {
+    hipLaunchKernelGGL((k_reset<Many>), dim3(d.reset_blocks, B), dim3(256), 0, s, Many{ gs }, max_iter, gauss_newton, restore);
+}
+// One unit of the LM state machine for every window of the batch (PCG or, for reduced systems <= 64 x 64, k_small_solve).
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s) {
+    const Many src{ gs };
+    launch_linearize_src(src, d, B, s);
+    if (first) launch_lin_finalize_src(src, 0, B, s);
+    launch_schur_partial_src(src, d, B, s);
+    if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
+    else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
+    launch_backsub_src(src, d, B, s);
+    hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
+}
+void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
+    launch_phase_end_src(Many{ gs }, d, B, phase_just_done, mark, next_max_iter, s);
+}
+void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s) {
+    hipLaunchKernelGGL((k_small_optimize<Many>), dim3(1, B), dim3(SM_T), 0, s, Many{ gs }, solver, half);
+}
+// The words the host needs to drive a batch: (done, status, phase_iter, mode) of every window, contiguous.
+__global__ void k_gather_state(const DeviceGraph* gs, int B, int* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const LmState* st = gs[b].st;
+    out[4 * b] = st->done; out[4 * b + 1] = st->status; out[4 * b + 2] = st->phase_iter; out[4 * b + 3] = st->mode;
+}
+void launch_gather_state(const DeviceGraph* gs, int B, int* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_state, dim3((B + 63) / 64), dim3(64), 0, s, gs, B, out);
 }
 
 bool small_path_fits(const DeviceGraph& g) {
@@ -1890,19 +1993,11 @@ bool small_path_fits(const DeviceGraph& g) {
 
 bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= SM_MAX_N6; }
 
-void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s) {
-    hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(512), 0, s, g, solver);
-}
-
-void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s) {
-    hipLaunchKernelGGL(k_small_optimize, dim3(1), dim3(SM_T), 0, s, g, solver, half);
-}
-
 int configure_kernels(const DeviceGraph& g) {
     // dynamic LDS above 64 KiB needs an explicit opt-in (never the case with the limits in ba_device.hpp, kept for safety)
     if (g.pcg_lds_bytes > 64 * 1024) {
-        const void* f = g.Npf <= 64 ? reinterpret_cast<const void*>(k_pcg<1, true>) : g.Npf <= 128 ? reinterpret_cast<const void*>(k_pcg<2, false>)
-                      : reinterpret_cast<const void*>(k_pcg<4, false>);
+        const void* f = g.Npf <= 64 ? reinterpret_cast<const void*>(k_pcg<1, true, One>) : g.Npf <= 128 ? reinterpret_cast<const void*>(k_pcg<2, false, One>)
+                      : reinterpret_cast<const void*>(k_pcg<4, false, One>);
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, g.pcg_lds_bytes) != hipSuccess) return -1;
     }
     return 0;

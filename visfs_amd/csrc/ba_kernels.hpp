@@ -8,6 +8,11 @@
 
 namespace visfs_ba {
 
+// Launch geometry of one window, or the element-wise maximum over a batch of windows (same lanes-per-landmark group).
+struct LaunchDims { int group, np, lin_blocks, backsub_blocks, sch_wgs, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo; };
+LaunchDims dims_of(const DeviceGraph& g);
+LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b);
+
 int configure_kernels(const DeviceGraph& g);
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s);
 void launch_linearize(const DeviceGraph& g, hipStream_t s);          // k_linearize (+ k_odo_linearize when the window has odometry edges)
@@ -23,6 +28,12 @@ bool small_solve_fits(const DeviceGraph& g);                         // 6 Npf <=
 void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s);   // k_schur_finalize + solver + K8 in one launch
 bool small_path_fits(const DeviceGraph& g);                          // the window qualifies for the fused single-workgroup path
 void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s);   // both phases + outlier pass in one launch
+// batches of independent windows: gs = B DeviceGraphs in HBM, blockIdx.y = window
+void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int max_iter, int gauss_newton, int restore, hipStream_t s);
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s);
+void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
+void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
+void launch_gather_state(const DeviceGraph* gs, int B, int* out, hipStream_t s);
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
 
 }  // namespace visfs_ba
