@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--windows-per-gpu", type=int, default=1)
     ap.add_argument("--solver", type=int, default=2, help="Optimizer/Solver: 2 = PCG (headline), 0 = direct Cholesky")
     ap.add_argument("--iterations", type=int, default=20, help="Optimizer/Iterations (10+10, as the shipped launch files)")
+    ap.add_argument("--batch-mode", default="launch", choices=("launch", "streams"),
+                    help="--windows-per-gpu > 1: 'launch' = one sequence of batched launches for all resident windows "
+                         "(blockIdx.y = window), 'streams' = one host thread + HIP stream per window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -69,18 +72,23 @@ def main():
     prm = abi.default_params(iterations=args.iterations, solver=args.solver)
     lib = backend.load_library()
     B = args.windows_per_gpu
-    solvers, descs = [], []
+    solvers, descs, gbs = [], [], []
+    batched = B > 1 and args.batch_mode == "launch"
     for b in range(B):
         w = synth.make_window(args.config, window_index=rank * B + b)
         wb = abi.WindowBuffers(w)
         gb, used, oref, mono = abi.pack_window_with(lib.visfs_ba_pack_window, prm, wb)    # host graph build (product code)
-        s = backend.Solver(prm, device=dev)
-        s.upload(gb)                                                                      # inputs resident in HBM
-        solvers.append(s)
-        descs.append(s.describe())
+        gbs.append(gb)
+        if not batched or b == 0:
+            s = backend.Solver(prm, device=dev)
+            s.upload(gb)                                                                  # inputs resident in HBM
+            solvers.append(s)
+            descs.append(s.describe())
+    if batched:
+        solvers[0].batch_upload(gbs)                                                      # all windows resident side by side
 
     pool = None
-    if B > 1:
+    if B > 1 and not batched:
         # independent windows: one host thread per resident window, each on its own HIP stream (ctypes drops the GIL),
         # so their kernels overlap on the device — BASELINE config 5 puts 8 windows on every GPU
         from concurrent.futures import ThreadPoolExecutor
@@ -95,6 +103,11 @@ def main():
     def step():
         if B == 1:
             return solve_one(solvers[0])
+        if batched:
+            solvers[0].batch_reset()
+            rc, stats = solvers[0].batch_optimize()
+            assert rc == abi.OK, rc
+            return sum(st.iterations_run[0] + st.iterations_run[1] for st in stats), stats[0]
         res = list(pool.map(solve_one, solvers))
         return sum(r[0] for r in res), res[0][1]
 
@@ -162,7 +175,8 @@ def main():
                                f"Iterations={args.iterations} ({args.iterations // 2}+{args.iterations // 2}), {B} window(s) per GPU",
                    "windows_per_gpu": B, "solver": args.solver, "iterations_per_solve": int(total_iters / (args.steps * world * B)),
                    "pcg_iterations_per_solve": int(last.pcg_iterations) if last is not None else 0,
-                   "parallelism": f"{world} rank(s) x {B} independent window(s), no data-path collective"},
+                   "parallelism": f"{world} rank(s) x {B} independent window(s), no data-path collective"
+                                  + (f"; windows of a rank share every launch (blockIdx.y = window)" if batched else "")},
         "roofline": roofline,
         "roofline_other_kernels": roofline_kernels,
         "kernel_us_per_step_calibration": {k: round(1e3 * v["total_ms"] / 3, 2) for k, v in calib.items()},

@@ -257,6 +257,14 @@ typedef struct visfs_ba_graph_info {
     int32_t fused_path;           /* 1: the window runs on the fused single-workgroup kernel (small windows, opt-in with VISFS_BA_FUSED=1) */
     int32_t reserved;
 } visfs_ba_graph_info;
+/* GRAPH layer for a batch of independent windows (BASELINE config 5): n graphs resident side by side; one optimise call runs
+ * them through ONE sequence of launches (blockIdx.y = window, each window gated by its own LM state).  Needs
+ * Optimizer/Solver = 2 or reduced systems <= 64 x 64.  stats: caller-allocated [n] or NULL. */
+int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* const* graphs);
+int visfs_ba_batch_reset(visfs_ba_handle* h);
+int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats);
+int visfs_ba_batch_download(visfs_ba_handle* h, int32_t index, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2);
+
 int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out);
 
 enum {

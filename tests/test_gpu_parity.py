@@ -394,6 +394,72 @@ def test_solve_batch_equals_individual_solves(olib):
     s.close()
 
 
+def test_batched_launches_match_single_window_solves(olib):
+    """independent windows as ONE sequence of launches (blockIdx.y = window, each window gated by its own LM
+    state).  Mixed shapes: two launch-geometry groups, a window that needs more damped solves than the others, one that is
+    refused — every result must equal the single-window solve bit for bit."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("C1", window_index=i) for i in range(3)]
+    ws += [synth.make_window("PROD", window_index=i) for i in range(3)]
+    ws.append(hard_window())                                                   # rejected trials: runs longer than its neighbours
+    ws.append(synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11))   # > 10 free poses: general PCG path
+    bad = dict(ws[0]); bad["pose_ids"] = np.arange(0, 10, dtype=np.uint64)     # first id 0: refused (Optimizer.cpp:74)
+    ws.append(bad)
+    s = backend.Solver(prm)
+    singles = []
+    for w in ws:
+        wb = abi.WindowBuffers(w)
+        rc, rb = s.solve_window(wb)
+        singles.append((rc, rb, wb))
+    wbs = [abi.WindowBuffers(w) for w in ws]
+    rbs = s.solve_batch(wbs)
+    for (rc, a, wa), b, wb in zip(singles, rbs, wbs):
+        assert b.struct.status == rc
+        assert b.struct.n_poses_out == a.struct.n_poses_out
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert np.array_equal(wa.point_xyz, wb.point_xyz, equal_nan=True)
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run) and a.struct.chi2_final == b.struct.chi2_final
+    s.close()
+
+
+def test_batch_graph_layer_resident_windows(olib):
+    # the bench's config-5 path: graphs resident side by side, reset + one batched optimise per step
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    gbs, refs = [], []
+    for i in range(4):
+        w = synth.make_window("C1", window_index=i)
+        wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+        gbs.append(gb)
+        s1 = backend.Solver(prm); s1.upload(gb); s1.optimize(); refs.append(s1.download()); s1.close()
+    s = backend.Solver(prm)
+    s.batch_upload(gbs)
+    for _ in range(2):                                     # twice: reset restores the uploaded estimates
+        s.batch_reset()
+        rc, stats = s.batch_optimize()
+        assert rc == abi.OK and all(st.status == abi.OK for st in stats)
+        for i in range(4):
+            got = s.batch_download(i)
+            assert all(np.array_equal(a, b) for a, b in zip(got, refs[i]))
+    s.close()
+
+
+def test_fused_kernel_batch(olib, monkeypatch):
+    # many small windows, one CU each: the fused kernel as a batched launch
+    from visfs_amd import backend
+    monkeypatch.setenv("VISFS_BA_FUSED", "1")
+    prm = abi.default_params(iterations=10, solver=0)
+    ws = [synth.make_window("PROD", window_index=i) for i in range(24)]
+    s = backend.Solver(prm)
+    rbs = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    for w, b in zip(ws, rbs):
+        rc, a = s.solve_window(abi.WindowBuffers(w))
+        assert rc == b.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+    s.close()
+
+
 def test_handle_reuse_across_shapes(olib):
     """One handle, windows of different sizes back to back (the per-frame usage pattern of Estimator::process)."""
     from visfs_amd import backend

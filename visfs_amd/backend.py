@@ -23,7 +23,7 @@ EXPORTS = [
     "visfs_ba_unpack_pose", "visfs_ba_graph_upload", "visfs_ba_graph_reset", "visfs_ba_optimize",
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
-    "visfs_ba_profile_read",
+    "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
 ]
 
 _lib = None
@@ -73,6 +73,10 @@ def load_library():
     lib.visfs_ba_stage_fetch.restype = C.c_int
     lib.visfs_ba_graph_describe.argtypes = [C.c_void_p, C.POINTER(abi.GraphInfo)]
     lib.visfs_ba_graph_describe.restype = C.c_int
+    lib.visfs_ba_batch_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.Graph))]
+    lib.visfs_ba_batch_reset.argtypes = [C.c_void_p]
+    lib.visfs_ba_batch_optimize.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
+    lib.visfs_ba_batch_download.argtypes = [C.c_void_p, C.c_int32, _pd, _pd, _pu8, _pd]
     lib.visfs_ba_profile_enable.argtypes = [C.c_void_p, C.c_uint32]
     lib.visfs_ba_profile_enable.restype = C.c_int
     lib.visfs_ba_profile_read.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
@@ -131,6 +135,29 @@ class Solver:
         if rc in (abi.ERR_DEVICE, abi.ERR_NOT_LOADED, abi.ERR_BAD_ARGUMENT):
             self._check(rc, "optimize")
         return rc, st
+
+    # ---- a batch of independent windows resident side by side (BASELINE config 5): one sequence of launches serves all
+    def batch_upload(self, gbs):
+        self.batch = list(gbs)                    # keep the host arrays alive
+        arr = (C.POINTER(abi.Graph) * len(gbs))(*[C.pointer(g.struct) for g in gbs])
+        self._check(self.lib.visfs_ba_batch_upload(self.h, len(gbs), arr), "batch_upload")
+
+    def batch_reset(self):
+        self._check(self.lib.visfs_ba_batch_reset(self.h), "batch_reset")
+
+    def batch_optimize(self):
+        stats = (abi.Stats * len(self.batch))()
+        rc = self.lib.visfs_ba_batch_optimize(self.h, stats)
+        if rc in (abi.ERR_DEVICE, abi.ERR_NOT_LOADED, abi.ERR_UNSUPPORTED, abi.ERR_BAD_ARGUMENT):
+            self._check(rc, "batch_optimize")
+        return rc, list(stats)
+
+    def batch_download(self, index):
+        gb = self.batch[index]
+        pose = np.zeros((gb.n_poses, 7)); pt = np.zeros((max(gb.n_points, 1), 3))
+        outl = np.zeros(max(gb.n_obs, 1), np.uint8); chi2 = np.zeros(max(gb.n_obs, 1))
+        self._check(self.lib.visfs_ba_batch_download(self.h, index, _p(pose), _p(pt), outl.ctypes.data_as(_pu8), _p(chi2)), "batch_download")
+        return pose, pt[:gb.n_points], outl[:gb.n_obs], chi2[:gb.n_obs]
 
     def download(self):
         g = self.gb

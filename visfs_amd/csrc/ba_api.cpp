@@ -6,10 +6,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,12 +90,23 @@ static void prof_harvest(Workspace& w) {
 
 }  // namespace
 
+// device / pinned scratch of a batched run: the DeviceGraph array the kernels index with blockIdx.y, and the gathered LM states
+struct BatchScratch {
+    DeviceGraph* d_graphs = nullptr; size_t cap_graphs = 0;
+    int* d_states = nullptr; int* h_states = nullptr; size_t cap_states = 0;
+    LmState* d_lm = nullptr; LmState* h_lm = nullptr;      // [cap_states] whole LM states, gathered at the end of a run
+    DeviceGraph* d_all = nullptr; size_t cap_all = 0;      // every graph of a resident batch (visfs_ba_batch_upload), for the one-launch reset
+    LaunchDims all_dims{};
+};
+
 struct visfs_ba_handle {
     visfs_ba_params prm;
     int device = 0;
     std::string err;
     Workspace ws;
     std::vector<Workspace*> batch;
+    int n_batch = 0;                               // graphs resident through visfs_ba_batch_upload
+    BatchScratch scratch;
 };
 
 namespace {
@@ -640,39 +653,47 @@ struct PackedWindow {
     int32_t mono = 0;
 };
 
-int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r) {
+// localOptimize in three steps so that a batch can run the middle one for many windows at once.
+// prepare_window: guards of Optimizer.cpp:74 / :360-364, graph build (:100-223), upload.  Returns 1 when the window is resident and
+// has to be optimised, 0 when `r` is already final (pass-through or refused input).
+int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, PackedWindow& pk) {
     const visfs_ba_params& prm = h->prm;
     r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
     r->iterations_run[0] = r->iterations_run[1] = 0;
     r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
-    if (prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return r->status = VISFS_BA_ERR_UNSUPPORTED; }
-    if (win->n_laser_points < 0 || (win->n_laser_points > 0 && win->grid && !win->laser_xyz)) return r->status = bad(h, "laser points without coordinates");
-    if (win->n_poses < 0 || win->n_points < 0 || win->n_refs < 0 || win->n_links < 0) return r->status = bad(h, "negative sizes");
+    if (prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; r->status = VISFS_BA_ERR_UNSUPPORTED; return 0; }
+    if (win->n_laser_points < 0 || (win->n_laser_points > 0 && win->grid && !win->laser_xyz)) { r->status = bad(h, "laser points without coordinates"); return 0; }
+    if (win->n_poses < 0 || win->n_points < 0 || win->n_refs < 0 || win->n_links < 0) { r->status = bad(h, "negative sizes"); return 0; }
     // guards of Optimizer.cpp:74 and :360-364
     if (!(win->n_poses >= 2 && prm.iterations > 0 && win->pose_ids[0] > 0)) {
         if (win->n_poses == 1 || prm.iterations <= 0) {
             for (int i = 0; i < win->n_poses; ++i) { r->pose_ids_out[i] = win->pose_ids[i]; std::memcpy(r->pose_Twr_out + 12 * i, win->pose_Twr + 12 * i, 96); }
             r->n_poses_out = win->n_poses;
-            return r->status = VISFS_BA_PASSTHROUGH;
+            r->status = VISFS_BA_PASSTHROUGH;
+            return 0;
         }
-        return r->status = VISFS_BA_ERR_TOO_FEW_POSES;
+        r->status = VISFS_BA_ERR_TOO_FEW_POSES;
+        return 0;
     }
-    for (int i = 1; i < win->n_poses; ++i) if (win->pose_ids[i] <= win->pose_ids[i - 1]) return r->status = bad(h, "pose ids must ascend (std::map order)");
-    for (int i = 1; i < win->n_points; ++i) if (win->point_ids[i] <= win->point_ids[i - 1]) return r->status = bad(h, "point ids must ascend (std::map order)");
-    PackedWindow pk;
+    for (int i = 1; i < win->n_poses; ++i) if (win->pose_ids[i] <= win->pose_ids[i - 1]) { r->status = bad(h, "pose ids must ascend (std::map order)"); return 0; }
+    for (int i = 1; i < win->n_points; ++i) if (win->point_ids[i] <= win->point_ids[i - 1]) { r->status = bad(h, "point ids must ascend (std::map order)"); return 0; }
     const int Np = win->n_poses, Nl = win->n_points, Nr = win->n_refs, Nk = win->n_links;
     pk.pose_tq.resize((size_t)Np * 7); pk.pose_fixed.resize(Np); pk.point_used.resize(std::max(Nl, 1));
     pk.obs_point.resize(std::max(Nr, 1)); pk.obs_pose.resize(std::max(Nr, 1)); pk.obs_ref.resize(std::max(Nr, 1)); pk.obs_uvr.resize((size_t)std::max(Nr, 1) * 3);
     pk.odo_from.resize(std::max(Nk, 1)); pk.odo_to.resize(std::max(Nk, 1)); pk.odo_tq.resize((size_t)std::max(Nk, 1) * 7);
     int rc = visfs_ba_pack_window(&prm, win, pk.pose_tq.data(), pk.pose_fixed.data(), pk.point_used.data(), pk.obs_point.data(), pk.obs_pose.data(),
                                   pk.obs_uvr.data(), pk.obs_ref.data(), pk.odo_from.data(), pk.odo_to.data(), pk.odo_tq.data(), &pk.g, &pk.mono);
-    if (rc != VISFS_BA_OK) return r->status = bad(h, "window references must be sorted by (feature, pose)");
+    if (rc != VISFS_BA_OK) { r->status = bad(h, "window references must be sorted by (feature, pose)"); return 0; }
     r->warn_mono_skipped = pk.mono;
     rc = ws_upload(h, w, &pk.g);
-    if (rc != VISFS_BA_OK) return r->status = rc;
-    visfs_ba_stats st;
-    rc = ws_optimize(h, w, &st);
+    if (rc != VISFS_BA_OK) { r->status = rc; return 0; }
+    return 1;
+}
+
+// finish_window: write-back (Optimizer.cpp:284-302 outliers, :320-358 poses and landmarks) from the optimised resident window.
+int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, const PackedWindow& pk, int rc, const visfs_ba_stats& st) {
     if (rc == VISFS_BA_ERR_DEVICE || rc == VISFS_BA_ERR_NOT_LOADED) return r->status = rc;
+    const int Np = win->n_poses, Nl = win->n_points;
     r->status = rc;
     r->iterations_run[0] = st.iterations_run[0]; r->iterations_run[1] = st.iterations_run[1];
     r->chi2_initial = st.chi2_initial; r->chi2_phase1 = st.chi2_phase1; r->chi2_final = st.chi2_final;
@@ -696,6 +717,98 @@ int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win
             if (std::sqrt(dx * dx + dy * dy + dz * dz) < 5.0) { p[0] = pts[3 * l]; p[1] = pts[3 * l + 1]; p[2] = pts[3 * l + 2]; }
         } else { p[0] = p[1] = p[2] = std::nan(""); }
     }
+    return VISFS_BA_OK;
+}
+
+int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r) {
+    PackedWindow pk;
+    if (!prepare_window(h, w, win, r, pk)) return r->status;
+    visfs_ba_stats st;
+    const int rc = ws_optimize(h, w, &st);
+    return finish_window(h, w, win, r, pk, rc, st);
+}
+
+// ------------------------------------------------------------------ batches of independent windows
+// Windows that share the launch geometry class run as ONE sequence of launches with blockIdx.y = window: the kernels of a
+// unit serve every resident window, each gated by its own LmState.  `members` index into ws[].
+int batch_read_states(visfs_ba_handle* h, BatchScratch& bs, int B, hipStream_t stream) {
+    launch_gather_state(bs.d_graphs, B, bs.d_states, stream);
+    HIP_TRY(h, hipMemcpyAsync(bs.h_states, bs.d_states, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    return VISFS_BA_OK;
+}
+
+int batch_run_phase(visfs_ba_handle* h, BatchScratch& bs, int B, const LaunchDims& d, bool small_solve, int max_iter, hipStream_t stream) {
+    if (max_iter <= 0) return VISFS_BA_OK;
+    int remaining = max_iter, guard = 0;
+    bool first = true;
+    while (true) {
+        for (int u = 0; u < remaining; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, stream); first = false; }
+        HIP_TRY(h, hipGetLastError());
+        int rc = batch_read_states(h, bs, B, stream);
+        if (rc != VISFS_BA_OK) return rc;
+        bool all_done = true;
+        int most = 1;
+        for (int b = 0; b < B; ++b) {
+            if (bs.h_states[4 * b + 1] == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
+            if (!bs.h_states[4 * b]) { all_done = false; most = std::max(most, max_iter - bs.h_states[4 * b + 2]); }
+        }
+        if (all_done) break;
+        remaining = most;                                     // rejected trials consumed units without finishing an iteration
+        if (++guard > 16 * max_iter + 16) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
+    }
+    return VISFS_BA_OK;
+}
+
+// Optimizer.cpp:261-318 for every member at once.  On return every member's LmState is in ws[i]->h_state.
+int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Workspace*>& ws, const std::vector<int>& members, hipStream_t stream) {
+    const int B = (int)members.size();
+    if (B == 0) return VISFS_BA_OK;
+    if (bs.cap_graphs < (size_t)B) {
+        if (bs.d_graphs) (void)hipFree(bs.d_graphs);
+        bs.d_graphs = nullptr; bs.cap_graphs = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_graphs), (size_t)B * sizeof(DeviceGraph)));
+        bs.cap_graphs = B;
+    }
+    if (bs.cap_states < (size_t)B) {
+        if (bs.d_states) (void)hipFree(bs.d_states);
+        if (bs.h_states) (void)hipHostFree(bs.h_states);
+        if (bs.d_lm) (void)hipFree(bs.d_lm);
+        if (bs.h_lm) (void)hipHostFree(bs.h_lm);
+        bs.d_states = nullptr; bs.h_states = nullptr; bs.d_lm = nullptr; bs.h_lm = nullptr; bs.cap_states = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_states), (size_t)B * 4 * sizeof(int)));
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bs.h_states), (size_t)B * 4 * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_lm), (size_t)B * sizeof(LmState)));
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bs.h_lm), (size_t)B * sizeof(LmState), hipHostMallocDefault));
+        bs.cap_states = B;
+    }
+    std::vector<DeviceGraph> hg(B);
+    LaunchDims d = dims_of(ws[members[0]]->g);
+    bool fused = true, small_solve = true;
+    for (int b = 0; b < B; ++b) {
+        const Workspace& w = *ws[members[b]];
+        hg[b] = w.g;
+        d = dims_max(d, dims_of(w.g));
+        fused = fused && w.fused; small_solve = small_solve && w.small_solve;
+    }
+    HIP_TRY(h, hipMemcpyAsync(bs.d_graphs, hg.data(), (size_t)B * sizeof(DeviceGraph), hipMemcpyHostToDevice, stream));
+    const int half = h->prm.iterations / 2;
+    launch_reset_batch(bs.d_graphs, B, d, half, h->prm.trust_region == 1, 0, stream);
+    if (fused) {
+        launch_small_optimize_batch(bs.d_graphs, B, h->prm.solver, half, stream);
+    } else {
+        int rc = batch_run_phase(h, bs, B, d, small_solve, half, stream);                       // :265
+        if (rc != VISFS_BA_OK) return rc;
+        launch_phase_end_batch(bs.d_graphs, B, d, 0, 1, half, stream);                           // :270-303
+        rc = batch_run_phase(h, bs, B, d, small_solve, (h->prm.robust_kernel_delta > 0.0) ? half : 0, stream);   // :310-311
+        if (rc != VISFS_BA_OK) return rc;
+        launch_phase_end_batch(bs.d_graphs, B, d, 1, 0, 0, stream);                              // :315-318
+    }
+    launch_gather_lm(bs.d_graphs, B, bs.d_lm, stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(bs.h_lm, bs.d_lm, (size_t)B * sizeof(LmState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    for (int b = 0; b < B; ++b) *ws[members[b]]->h_state = bs.h_lm[b];
     return VISFS_BA_OK;
 }
 
@@ -735,6 +848,12 @@ void visfs_ba_destroy(visfs_ba_handle* h) {
     (void)hipSetDevice(h->device);
     ws_release(h->ws);
     for (Workspace* w : h->batch) { ws_release(*w); delete w; }
+    if (h->scratch.d_graphs) (void)hipFree(h->scratch.d_graphs);
+    if (h->scratch.d_states) (void)hipFree(h->scratch.d_states);
+    if (h->scratch.h_states) (void)hipHostFree(h->scratch.h_states);
+    if (h->scratch.d_lm) (void)hipFree(h->scratch.d_lm);
+    if (h->scratch.h_lm) (void)hipHostFree(h->scratch.h_lm);
+    if (h->scratch.d_all) (void)hipFree(h->scratch.d_all);
     delete h;
 }
 
@@ -865,38 +984,141 @@ int visfs_ba_solve_window(visfs_ba_handle* h, const visfs_ba_window* w, visfs_ba
 int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r) {
     if (!h || n < 0 || (n > 0 && (!w || !r))) return VISFS_BA_ERR_BAD_ARGUMENT;
     for (int i = 0; i < n; ++i) if (!w[i] || !r[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
-    // independent windows: one workspace + stream + host thread per in-flight window
-    // the persistent PCG needs all of a window's workgroups resident: keep the sum of the in-flight grids <= 256 CUs
+    // Independent windows (BASELINE config 5).  Host work (graph build, upload, write-back) runs on up to 8
+    // threads, one workspace per window; the optimisation itself is ONE sequence of launches per group of windows with the
+    // same launch-geometry class, blockIdx.y = window (batch_optimize).  VISFS_BA_BATCH=0 falls back to one stream per lane.
     return guarded(h, [&]() -> int {
-        int max_poses = 1;
-        for (int i = 0; i < n; ++i) max_poses = std::max(max_poses, (int)w[i]->n_poses);
-        const int lanes = std::max(1, std::min<int>(std::min<int>(n, 8), h->prm.solver == 2 ? 256 / max_poses : 8));
-        while ((int)h->batch.size() < lanes) h->batch.push_back(new Workspace());
-        std::vector<int> rcs(n, VISFS_BA_OK);
+        while ((int)h->batch.size() < n) h->batch.push_back(new Workspace());
+        const int lanes = std::max(1, std::min<int>(n, 8));
+        std::vector<PackedWindow> pk(n);
+        std::vector<int> need(n, 0), rcs(n, VISFS_BA_OK);
         std::vector<std::string> errs(lanes);
-        std::vector<std::thread> th;
-        struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{ th };
-        th.reserve(lanes);
-        for (int t = 0; t < lanes; ++t) {
-            th.emplace_back([&, t]() noexcept {
-                int i = t;
-                try {
-                    (void)hipSetDevice(h->device);
-                    visfs_ba_handle local;            // per-thread error string; shares params / device
-                    local.prm = h->prm; local.device = h->device;
-                    for (; i < n; i += lanes) rcs[i] = solve_window_on(&local, *h->batch[t], w[i], r[i]);
-                    errs[t] = local.err;
-                } catch (...) {                       // nothing may escape a thread: mark this lane's remaining windows failed
-                    for (; i < n; i += lanes) { rcs[i] = VISFS_BA_ERR_DEVICE; r[i]->status = VISFS_BA_ERR_DEVICE; r[i]->n_poses_out = 0; }
-                }
-            });
+        auto parallel = [&](auto&& fn) {
+            std::vector<std::thread> th;
+            struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{ th };
+            th.reserve(lanes);
+            for (int t = 0; t < lanes; ++t) {
+                th.emplace_back([&, t]() noexcept {
+                    int i = t;
+                    try {
+                        (void)hipSetDevice(h->device);
+                        visfs_ba_handle local;            // per-thread error string; shares params / device
+                        local.prm = h->prm; local.device = h->device;
+                        for (; i < n; i += lanes) fn(local, i);
+                        if (!local.err.empty()) errs[t] = local.err;
+                    } catch (...) {                       // nothing may escape a thread: mark this lane's remaining windows failed
+                        for (; i < n; i += lanes) { rcs[i] = VISFS_BA_ERR_DEVICE; need[i] = 0; r[i]->status = VISFS_BA_ERR_DEVICE; r[i]->n_poses_out = 0; }
+                    }
+                });
+            }
+        };
+        parallel([&](visfs_ba_handle& local, int i) { need[i] = prepare_window(&local, *h->batch[i], w[i], r[i], pk[i]); if (!need[i]) rcs[i] = r[i]->status; });
+        // groups: lanes per landmark, PCG variant class, small-solve / fused flags must agree inside one batched launch
+        const char* env = std::getenv("VISFS_BA_BATCH");
+        const bool batching = !(env && env[0] == '0');
+        std::map<std::array<int, 4>, std::vector<int>> groups;
+        std::vector<int> singles;
+        for (int i = 0; i < n; ++i) {
+            if (!need[i]) continue;
+            const Workspace& ws = *h->batch[i];
+            const bool batchable = batching && (h->prm.solver == 2 || ws.small_solve || ws.fused);
+            if (!batchable) { singles.push_back(i); continue; }
+            const int cls = ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
+            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
         }
-        for (auto& x : th) x.join();
+        std::vector<visfs_ba_stats> stats(n);
         int worst = VISFS_BA_OK;
+        for (auto& kv : groups) {
+            // keep the persistent PCG grid of one launch within what the device holds comfortably
+            const std::vector<int>& all = kv.second;
+            int rows = 1;
+            for (int i : all) rows = std::max(rows, h->batch[i]->g.Npf);
+            const int per = std::max(1, 2048 / rows);
+            for (size_t o = 0; o < all.size(); o += per) {
+                std::vector<int> members(all.begin() + o, all.begin() + std::min(all.size(), o + per));
+                const int rc = batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
+                for (int i : members) {
+                    if (rc != VISFS_BA_OK) { rcs[i] = rc; worst = VISFS_BA_ERR_DEVICE; continue; }
+                    fill_stats(*h->batch[i]->h_state, &stats[i]);
+                    rcs[i] = h->batch[i]->h_state->status;
+                }
+            }
+        }
+        for (int i : singles) rcs[i] = ws_optimize(h, *h->batch[i], &stats[i]);
+        parallel([&](visfs_ba_handle& local, int i) { if (need[i]) rcs[i] = finish_window(&local, *h->batch[i], w[i], r[i], pk[i], rcs[i], stats[i]); });
         for (int i = 0; i < n; ++i) if (rcs[i] == VISFS_BA_ERR_DEVICE) worst = VISFS_BA_ERR_DEVICE;
         for (int t = 0; t < lanes; ++t) if (!errs[t].empty()) h->err = errs[t];
         return worst;
     });
+}
+
+// GRAPH layer for a batch: n graphs resident side by side, optimised by one sequence of batched launches (bench config 5).
+int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* const* graphs) {
+    if (!h || n < 0 || (n > 0 && !graphs)) return VISFS_BA_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < n; ++i) if (!graphs[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (h->prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return VISFS_BA_ERR_UNSUPPORTED; }
+    return guarded(h, [&]() -> int {
+        while ((int)h->batch.size() < n) h->batch.push_back(new Workspace());
+        h->n_batch = 0;
+        for (int i = 0; i < n; ++i) { const int rc = ws_upload(h, *h->batch[i], graphs[i]); if (rc != VISFS_BA_OK) return rc; }
+        // every graph once more as one array: visfs_ba_batch_reset is then a single launch
+        BatchScratch& bs = h->scratch;
+        if (bs.cap_all < (size_t)n) {
+            if (bs.d_all) (void)hipFree(bs.d_all);
+            bs.d_all = nullptr; bs.cap_all = 0;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_all), (size_t)std::max(n, 1) * sizeof(DeviceGraph)));
+            bs.cap_all = (size_t)std::max(n, 1);
+        }
+        std::vector<DeviceGraph> hg(n);
+        for (int i = 0; i < n; ++i) { hg[i] = h->batch[i]->g; bs.all_dims = i ? dims_max(bs.all_dims, dims_of(hg[i])) : dims_of(hg[i]); }
+        if (n) HIP_TRY(h, hipMemcpy(bs.d_all, hg.data(), (size_t)n * sizeof(DeviceGraph), hipMemcpyHostToDevice));
+        h->n_batch = n;
+        return VISFS_BA_OK;
+    });
+}
+
+int visfs_ba_batch_reset(visfs_ba_handle* h) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (h->n_batch > 0) launch_reset_batch(h->scratch.d_all, h->n_batch, h->scratch.all_dims, h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
+    HIP_TRY(h, hipGetLastError());
+    return VISFS_BA_OK;
+}
+
+int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    return guarded(h, [&]() -> int {
+        const int n = h->n_batch;
+        if (n == 0) { h->err = "no batch resident"; return VISFS_BA_ERR_NOT_LOADED; }
+        std::map<std::array<int, 4>, std::vector<int>> groups;
+        for (int i = 0; i < n; ++i) {
+            const Workspace& ws = *h->batch[i];
+            if (!(h->prm.solver == 2 || ws.small_solve || ws.fused)) { h->err = "batched launches need Optimizer/Solver=2 or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
+            const int cls = ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
+            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
+        }
+        int worst = VISFS_BA_OK;
+        for (auto& kv : groups) {
+            const std::vector<int>& all = kv.second;
+            int rows = 1;
+            for (int i : all) rows = std::max(rows, h->batch[i]->g.Npf);
+            const int per = std::max(1, 2048 / rows);
+            for (size_t o = 0; o < all.size(); o += per) {
+                std::vector<int> members(all.begin() + o, all.begin() + std::min(all.size(), o + per));
+                const int rc = batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
+                if (rc != VISFS_BA_OK) return rc;
+                for (int i : members) {
+                    if (stats) fill_stats(*h->batch[i]->h_state, &stats[i]);
+                    if (h->batch[i]->h_state->status != VISFS_BA_OK) worst = h->batch[i]->h_state->status;
+                }
+            }
+        }
+        return worst;
+    });
+}
+
+int visfs_ba_batch_download(visfs_ba_handle* h, int32_t index, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2) {
+    if (!h || index < 0 || index >= h->n_batch) return VISFS_BA_ERR_BAD_ARGUMENT;
+    return guarded(h, [&]() { return ws_download(h, *h->batch[index], pose_tq, point_xyz, obs_outlier, obs_chi2); });
 }
 
 int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {

@@ -1983,6 +1983,17 @@ __global__ void k_gather_state(const DeviceGraph* gs, int B, int* out) {
     const LmState* st = gs[b].st;
     out[4 * b] = st->done; out[4 * b + 1] = st->status; out[4 * b + 2] = st->phase_iter; out[4 * b + 3] = st->mode;
 }
+// Every window's whole LmState, contiguous (one D2H copy instead of one per window).
+__global__ void k_gather_lm(const DeviceGraph* gs, int B, LmState* out) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const unsigned* src = reinterpret_cast<const unsigned*>(gs[b].st);
+    unsigned* dst = reinterpret_cast<unsigned*>(out + b);
+    for (int t = threadIdx.x; t < (int)(sizeof(LmState) / 4); t += blockDim.x) dst[t] = src[t];
+}
+void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_lm, dim3(B), dim3(64), 0, s, gs, B, out);
+}
 void launch_gather_state(const DeviceGraph* gs, int B, int* out, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_state, dim3((B + 63) / 64), dim3(64), 0, s, gs, B, out);
 }
