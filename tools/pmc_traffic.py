@@ -14,7 +14,7 @@ for arg in sys.argv[2:]:
     d = json.load(open(path))
     out[cfg] = {}
     for kernel, c in d.items():
-        name = kernel.split("::")[-1].split("<")[0]
+        name = kernel.split("<")[0].split("::")[-1]
         f, w = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
         if f is None or w is None:
             continue
