@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -150,6 +151,9 @@ int ws_init(visfs_ba_handle* h, Workspace& w) {
 
 // ------------------------------------------------------------------ graph → device structures
 int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
+    const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (timing) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "  upload %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
     const visfs_ba_params& prm = h->prm;
     const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = gr->n_odo;
     if (Np < 1 || Nl < 0 || No < 0 || Ne < 0) return bad(h, "negative sizes");
@@ -223,6 +227,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         pose_odo_ptr[Npf] = (int32_t)pose_odo.size();
     }
 
+    lap("index");
     // S block structure (g2o buildStructure analogue): per block (i<=j) the co-observation pairs
     std::vector<int64_t> pcount((size_t)Npf * Npf, 0);
     std::vector<uint8_t> has_odo((size_t)Npf * Npf, 0);
@@ -321,6 +326,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (pcg_lds + (size_t)288 * max_row <= budget) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
     }
 
+    lap("pair count");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
     const double mean_track = Nl > 0 ? (double)No / Nl : 1.0;
@@ -423,6 +429,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&w.h_base), static_bytes, hipHostMallocDefault));
         w.h_cap = static_bytes;
     }
+    lap("alloc");
     // fill the staging arena
     Arena hs{ w.h_base, w.h_cap, 0 };
     layout(hs, hg, true);
@@ -483,6 +490,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
             std::memcpy(const_cast<float*>(hg.grid.cost), gr->grid->correspondence_cost, grid_cells * 4);
         }
     }
+    lap("stage fill");
     // device pointers: same offsets
     Arena ds{ w.d_base, w.d_cap, 0 };
     layout(ds, dg, true);
@@ -515,7 +523,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     if (configure_kernels(w.g) != 0) { h->err = "hipFuncSetAttribute failed"; return VISFS_BA_ERR_DEVICE; }
     launch_reset(w.g, prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
     HIP_TRY(h, hipGetLastError());
+    lap("enqueue");
     HIP_TRY(h, hipStreamSynchronize(w.stream));            // staging arena is reused by the next upload
+    lap("h2d+sync");
     w.loaded = true;
     return VISFS_BA_OK;
 }
