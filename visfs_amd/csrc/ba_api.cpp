@@ -97,6 +97,7 @@ struct BatchScratch {
     int* d_states = nullptr; int* h_states = nullptr; size_t cap_states = 0;
     LmState* d_lm = nullptr; LmState* h_lm = nullptr;      // [cap_states] whole LM states, gathered at the end of a run
     DeviceGraph* d_all = nullptr; size_t cap_all = 0;      // every graph of a resident batch (visfs_ba_batch_upload), for the one-launch reset
+    std::vector<DeviceGraph> host_graphs;                  // source of the asynchronous H2D copy of d_graphs: must outlive it
     LaunchDims all_dims{};
 };
 
@@ -792,7 +793,8 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bs.h_lm), (size_t)B * sizeof(LmState), hipHostMallocDefault));
         bs.cap_states = B;
     }
-    std::vector<DeviceGraph> hg(B);
+    std::vector<DeviceGraph>& hg = bs.host_graphs;
+    hg.resize(B);
     LaunchDims d = dims_of(ws[members[0]]->g);
     bool fused = true, small_solve = true;
     for (int b = 0; b < B; ++b) {
