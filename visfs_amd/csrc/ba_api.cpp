@@ -589,6 +589,7 @@ void fill_stats(const LmState& st, visfs_ba_stats* out) {
 // Optimizer.cpp:261-318 on the resident graph.
 int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     const int half = h->prm.iterations / 2;
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
     { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
@@ -628,6 +629,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
 
 int ws_download(visfs_ba_handle* h, Workspace& w, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    HIP_TRY(h, hipSetDevice(h->device));
     int rc = ws_read_state(h, w);
     if (rc != VISFS_BA_OK) return rc;
     const int sel = w.h_state->sel;
@@ -775,6 +777,7 @@ int batch_run_phase(visfs_ba_handle* h, BatchScratch& bs, int B, const LaunchDim
 int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Workspace*>& ws, const std::vector<int>& members, hipStream_t stream) {
     const int B = (int)members.size();
     if (B == 0) return VISFS_BA_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
     if (bs.cap_graphs < (size_t)B) {
         if (bs.d_graphs) (void)hipFree(bs.d_graphs);
         bs.d_graphs = nullptr; bs.cap_graphs = 0;
@@ -973,6 +976,7 @@ int visfs_ba_graph_upload(visfs_ba_handle* h, const visfs_ba_graph* g) {
 int visfs_ba_graph_reset(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
     if (!h->ws.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    HIP_TRY(h, hipSetDevice(h->device));
     launch_reset(h->ws.g, h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
     HIP_TRY(h, hipGetLastError());
     return VISFS_BA_OK;
@@ -1091,6 +1095,7 @@ int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* c
 
 int visfs_ba_batch_reset(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
     if (h->n_batch > 0) launch_reset_batch(h->scratch.d_all, h->n_batch, h->scratch.all_dims, h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
     HIP_TRY(h, hipGetLastError());
     return VISFS_BA_OK;
