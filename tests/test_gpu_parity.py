@@ -290,6 +290,65 @@ def test_solve_window_error_convention(olib):
     s.close(); s0.close()
 
 
+# ---------------------------------------------------------------- size-independent properties at the full BASELINE size
+def _rigid(yaw, pitch, t):
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    R = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]]) @ np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    return R, np.asarray(t, float)
+
+
+def test_c2_gauge_covariance():
+    """Rotating the whole world about its origin (poses G*Twr, landmarks G*p, measurements and odometry untouched) must
+    rotate the solution by G.  No oracle involved — a property of the path itself at the BASELINE size (50 KF / 5k
+    landmarks / 50k observations + 49 odometry edges).  NOT true for a translation of the world, and that is the
+    reference's doing: its pose Jacobian (OptimizeTypeDefine.h:157-176) is the SE(3)-left form in Pc while the update
+    leaves t unrotated, an approximation whose error grows with |t_cw| — shifting C1 by 12 m changes the outlier count
+    from 92 to 2206 in the CPU restatement as well (quirk reproduced)."""
+    from visfs_amd import backend
+    w = synth.make_window("C3")
+    R, t = _rigid(0.7, -0.3, [0.0, 0.0, 0.0])
+    w2 = dict(w)
+    T = np.asarray(w["pose_Twr"]).reshape(-1, 3, 4)
+    w2["pose_Twr"] = np.concatenate([R @ T[:, :, :3], (R @ T[:, :, 3:]) + t[:, None]], axis=2).reshape(-1, 12)
+    w2["point_xyz"] = np.asarray(w["point_xyz"]) @ R.T + t
+    s = backend.Solver(abi.default_params(iterations=20, solver=2))
+    wa, wb = abi.WindowBuffers(w), abi.WindowBuffers(w2)
+    rca, ra = s.solve_window(wa)
+    rcb, rb = s.solve_window(wb)
+    s.close()
+    assert rca == rcb == abi.OK and ra.outliers() == rb.outliers()
+    Ta = ra.pose_Twr_out.reshape(-1, 3, 4)
+    expect = np.concatenate([R @ Ta[:, :, :3], (R @ Ta[:, :, 3:]) + t[:, None]], axis=2).reshape(-1, 12)
+    et, er = synth.pose_errors(rb.pose_Twr_out, expect)
+    assert et < 1e-8 and er < 1e-8
+    ok = ~np.isnan(wa.point_xyz).any(axis=1)
+    assert rel_err(wb.point_xyz[ok], (wa.point_xyz[ok] @ R.T + t)) < 1e-7
+
+
+def test_c2_converged_solution_is_a_fixed_point():
+    """Feeding a solution back in (same measurements, culled references removed) leaves it where it is: the second solve starts
+    at the minimum of the same robust objective, so no pose moves by more than the first solve's own convergence tolerance."""
+    from visfs_amd import backend
+    w = synth.make_window("C2")
+    s = backend.Solver(abi.default_params(iterations=40, solver=2))
+    wa = abi.WindowBuffers(w)
+    rc, ra = s.solve_window(wa)
+    assert rc == abi.OK
+    out = set(ra.outliers())
+    keep = np.array([(int(f), int(p)) not in out for f, p in zip(w["ref_feature"], w["ref_pose"])])
+    w2 = drop_refs(w, keep)
+    w2["pose_Twr"] = ra.pose_Twr_out[:len(w["pose_ids"])].copy()
+    pts = wa.point_xyz.copy(); bad = np.isnan(pts).any(axis=1); pts[bad] = np.asarray(w["point_xyz"])[bad]
+    w2["point_xyz"] = pts
+    wb = abi.WindowBuffers(w2)
+    rc2, rb = s.solve_window(wb)
+    s.close()
+    assert rc2 == abi.OK
+    et, er = synth.pose_errors(rb.pose_Twr_out, ra.pose_Twr_out)
+    assert et < 1e-5 and er < 1e-5
+    assert rb.struct.chi2_final <= rb.struct.chi2_initial * (1 + 1e-9)
+
+
 # ---------------------------------------------------------------- small windows: k_small_solve / fused single-workgroup kernel
 def _solve_in_mode(monkeypatch, w, env, **prm_kw):
     from visfs_amd import backend
