@@ -230,19 +230,26 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
 
     lap("index");
     // S block structure (g2o buildStructure analogue): per block (i<=j) the co-observation pairs
-    std::vector<int64_t> pcount((size_t)Npf * Npf, 0);
+    // free index of every observation's pose once (the two O(sum k_l^2) loops below read it k_l times per observation)
+    std::vector<int32_t> obs_free(std::max(No, 1));
+    for (int k = 0; k < No; ++k) obs_free[k] = pose_free[gr->obs_pose[k]];
+    std::vector<int32_t> pcount((size_t)Npf * Npf, 0);
     std::vector<uint8_t> has_odo((size_t)Npf * Npf, 0);
+    int64_t pairs_seen = 0;
     for (int l = 0; l < Nl; ++l) {
         if (gr->point_fixed[l]) continue;
-        for (int k1 = lm_ptr[l]; k1 < lm_ptr[l + 1]; ++k1) {
-            const int a = pose_free[gr->obs_pose[k1]];
+        const int k_end = lm_ptr[l + 1];
+        for (int k1 = lm_ptr[l]; k1 < k_end; ++k1) {
+            const int a = obs_free[k1];
             if (a < 0) continue;
-            for (int k2 = k1; k2 < lm_ptr[l + 1]; ++k2) {
-                const int b = pose_free[gr->obs_pose[k2]];
-                if (b >= 0) pcount[(size_t)a * Npf + b]++;
+            int32_t* row = pcount.data() + (size_t)a * Npf;
+            for (int k2 = k1; k2 < k_end; ++k2) {
+                const int b = obs_free[k2];
+                if (b >= 0) { row[b]++; ++pairs_seen; }
             }
         }
     }
+    if (pairs_seen > 0x7fffffff) { h->err = "window too large (pair list)"; return VISFS_BA_ERR_UNSUPPORTED; }
     for (int e = 0; e < Ne; ++e) {
         int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
         if (a < 0 || b < 0) continue;
@@ -464,17 +471,19 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         {   // co-observation pairs, written straight into the staging arena (3.5 MB at C2: no intermediate copy)
             int4* pairs = const_cast<int4*>(hg.blk_pairs);
             if (npairs == 0) pairs[0] = make_int4(0, 0, 0, 0);
-            std::vector<int32_t> pos(blk_ptr.begin(), blk_ptr.end() - 1);
+            // write cursor per (a, b): one lookup per pair instead of block id + cursor
+            std::vector<int32_t> cursor((size_t)Npf * Npf, 0);
+            for (int b = 0; b < n_blk; ++b) cursor[(size_t)blk_i[b] * Npf + blk_j[b]] = blk_ptr[b];
             for (int l = 0; l < Nl; ++l) {
                 if (gr->point_fixed[l]) continue;
-                for (int k1 = lm_ptr[l]; k1 < lm_ptr[l + 1]; ++k1) {
-                    const int a = pose_free[gr->obs_pose[k1]];
+                const int k_end = lm_ptr[l + 1];
+                for (int k1 = lm_ptr[l]; k1 < k_end; ++k1) {
+                    const int a = obs_free[k1];
                     if (a < 0) continue;
-                    const size_t rowkey = (size_t)a * Npf;
-                    for (int k2 = k1; k2 < lm_ptr[l + 1]; ++k2) {
-                        const int b = pose_free[gr->obs_pose[k2]];
-                        if (b < 0) continue;
-                        pairs[pos[blk_of[rowkey + b]]++] = make_int4(k1, k2, l, 0);
+                    int32_t* row = cursor.data() + (size_t)a * Npf;
+                    for (int k2 = k1; k2 < k_end; ++k2) {
+                        const int b = obs_free[k2];
+                        if (b >= 0) pairs[row[b]++] = make_int4(k1, k2, l, 0);
                     }
                 }
             }
