@@ -636,23 +636,24 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     return w.h_state->status;
 }
 
-int ws_download(visfs_ba_handle* h, Workspace& w, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2) {
+// state_fresh: w.h_state already holds the LM state of the finished run (ws_optimize / batch_optimize read it): no extra round trip.
+int ws_download(visfs_ba_handle* h, Workspace& w, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2, bool state_fresh = false) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc = ws_read_state(h, w);
-    if (rc != VISFS_BA_OK) return rc;
+    if (!state_fresh) { int rc = ws_read_state(h, w); if (rc != VISFS_BA_OK) return rc; }
     const int sel = w.h_state->sel;
     const DeviceGraph& g = w.g;
+    // every copy is enqueued first, ONE synchronisation at the end
+    std::vector<double> tmp;
     if (pose_tq) {
-        std::vector<double> tmp((size_t)g.Np * POSE_STRIDE);
+        tmp.resize((size_t)g.Np * POSE_STRIDE);
         HIP_TRY(h, hipMemcpyAsync(tmp.data(), g.pose[sel], tmp.size() * 8, hipMemcpyDeviceToHost, w.stream));
-        HIP_TRY(h, hipStreamSynchronize(w.stream));
-        for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) pose_tq[7 * i + q] = tmp[POSE_STRIDE * i + q];
     }
     if (point_xyz && g.Nl) HIP_TRY(h, hipMemcpyAsync(point_xyz, g.pt[sel], (size_t)g.Nl * 24, hipMemcpyDeviceToHost, w.stream));
     if (obs_outlier && g.No) HIP_TRY(h, hipMemcpyAsync(obs_outlier, g.obs_outlier, g.No, hipMemcpyDeviceToHost, w.stream));
     if (obs_chi2 && g.No) HIP_TRY(h, hipMemcpyAsync(obs_chi2, g.obs_chi2_out, (size_t)g.No * 8, hipMemcpyDeviceToHost, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));
+    if (pose_tq) for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) pose_tq[7 * i + q] = tmp[POSE_STRIDE * i + q];
     return VISFS_BA_OK;
 }
 
@@ -722,7 +723,7 @@ int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, 
     if (rc != VISFS_BA_OK && rc != VISFS_BA_ERR_HUGE_CHI2_2) return rc;
     std::vector<double> pose((size_t)Np * 7), pts((size_t)std::max(Nl, 1) * 3);
     std::vector<uint8_t> outl(std::max(pk.g.n_obs, 1));
-    int rc2 = ws_download(h, w, pose.data(), pts.data(), outl.data(), nullptr);
+    int rc2 = ws_download(h, w, pose.data(), pts.data(), outl.data(), nullptr, /*state_fresh=*/true);
     if (rc2 != VISFS_BA_OK) return r->status = rc2;
     // outliers are appended at Optimizer.cpp:296, before the phase-2 abort check
     int n = 0;
