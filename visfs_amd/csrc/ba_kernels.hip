@@ -16,6 +16,10 @@
 //   K7,K8  back-substitution, oplus                            → k_backsub (+ pose oplus in the solver epilogue)
 //   K9     OptimizationAlgorithmLevenberg control              → k_lin_finalize (lambda init) + k_decide
 //   K10    outlier marking (Optimizer.cpp:283-303)             → k_eval + k_phase_end
+//   K11    EdgeOccupiedObservation (laser)                     → laser role of k_odo_linearize, k_backsub / k_eval
+// Small windows: k_small_solve (finalise + solve reduced systems <= 64 x 64 in one workgroup); k_small_optimize (whole
+// optimise in one workgroup, opt-in).  Every kernel is templated on the graph source: One (a window by value) or Many
+// (blockIdx.y selects one of several independent windows sharing the launch).
 //
 // All reductions are fixed-order (halving butterflies + serial tails): no floating-point atomics, results are
 // bitwise reproducible.  Wavefront = 64 everywhere.
@@ -1455,7 +1459,8 @@ __global__ void k_stage_arm(const DeviceGraph g, const double lambda, const int 
 // The production window of VISFS (LocalMap/MapSize = 5: six poses, ~300 landmarks, ~1500 observations) is far too small
 // for one kernel per stage — a stage is a few microseconds of work behind a launch and a dependent-load chain.
 // k_small_optimize runs BOTH optimise phases, the outlier pass and the final evaluation (Optimizer.cpp:261-318) in ONE
-// launch of ONE 1024-thread workgroup: stages are separated by __syncthreads() instead of kernel boundaries, the LM
+// launch of ONE 512-thread workgroup (256 VGPRs per lane: the inlined stage bodies spill at the 128 a 1024-thread block
+// gets): stages are separated by __syncthreads() instead of kernel boundaries, the LM
 // state machine (lm_decide / phase_end_update — the very functions the multi-kernel path runs) is stepped by thread 0
 // and re-read by everyone after the barrier, the reduced camera system (<= 64 x 64) is solved in LDS.  All arithmetic
 // goes through the same device functions as the multi-kernel path (lin_landmark<1>, pose_obs_terms, schur_chunk,
