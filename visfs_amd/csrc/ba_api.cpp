@@ -339,6 +339,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     int group = 4;
     const double mean_track = Nl > 0 ? (double)No / Nl : 1.0;
     while (group < 64 && group < mean_track) group *= 2;
+    { const char* e = std::getenv("VISFS_BA_GROUP"); if (e) { const int gq = std::atoi(e); if (gq == 4 || gq == 8 || gq == 16 || gq == 32 || gq == 64) group = gq; } }   // tuning override
     const int n_lin_a = std::max(1, (Nl + (256 / group) - 1) / (256 / group));
     const int n_eval = (No + 255) / 256 + 1;
     const int n_parts = std::max(n_lin_a + 1, n_eval);
