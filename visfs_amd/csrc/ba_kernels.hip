@@ -493,7 +493,10 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
     const bool have = e < e_end;
     // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
     const int4 pr = have ? g.blk_pairs[e] : make_int4(0, 0, 0, 0);
-    double Y[18], Wb[18], B[3] = { 0.0, 0.0, 0.0 };
+    // The contribution Wa D Wb^T of the pair, through the structure of the tiles: W = [N ; [Pc]x N] (tile_core), so with
+    // P = Na D Nb^T (3x3) the 6x6 result is [P, P Xb^T ; Xa P, Xa P Xb^T] — rows of P crossed with Pc_b, columns with Pc_a —
+    // and the b_s term is [v ; Pc_a x v] with v = Na (D b_l): about half the fp64 work of forming both 6x3 tiles.
+    double G[36], gb[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
     {
         const double* H = g.Hll + 6 * (size_t)pr.z;
         const double2* sa = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.x);
@@ -501,10 +504,11 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
         const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
         const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
         const Intrinsics K = intr_of(g);
-        double Wa[18];
-        hpl_tile(Ti, Vec3{ a0.x, a0.y, a1.x }, a1.y, K, Wa);
-        hpl_tile(Tj, Vec3{ b0.x, b0.y, b1.x }, b1.y, K, Wb);
-        double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 };
+        const Vec3 pa{ a0.x, a0.y, a1.x }, pb{ b0.x, b0.y, b1.x };
+        double Na[9], Nb[9];
+        tile_core(Ti.R, pa, a1.y, K, Na);
+        tile_core(Tj.R, pb, b1.y, K, Nb);
+        double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
         if (have) {
             h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
             if (diag) { const double* Bl = g.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
@@ -515,24 +519,43 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
         // all zero, so drop the term instead of multiplying 0 by inf
         const bool okD = (D[0] == D[0]) && (fabs(D[0]) <= DBL_MAX) && (D[3] == D[3]) && (fabs(D[3]) <= DBL_MAX) && (D[5] == D[5]) && (fabs(D[5]) <= DBL_MAX);
         if (!okD) { D[0] = D[1] = D[2] = D[3] = D[4] = D[5] = 0.0; }
+        double Q[9], P[9];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            Y[r * 3 + 0] = Wa[r * 3] * D[0] + Wa[r * 3 + 1] * D[1] + Wa[r * 3 + 2] * D[2];
-            Y[r * 3 + 1] = Wa[r * 3] * D[1] + Wa[r * 3 + 1] * D[3] + Wa[r * 3 + 2] * D[4];
-            Y[r * 3 + 2] = Wa[r * 3] * D[2] + Wa[r * 3 + 1] * D[4] + Wa[r * 3 + 2] * D[5];
+        for (int r = 0; r < 3; ++r) {                       // Q = Na D
+            Q[3 * r + 0] = Na[3 * r] * D[0] + Na[3 * r + 1] * D[1] + Na[3 * r + 2] * D[2];
+            Q[3 * r + 1] = Na[3 * r] * D[1] + Na[3 * r + 1] * D[3] + Na[3 * r + 2] * D[4];
+            Q[3 * r + 2] = Na[3 * r] * D[2] + Na[3 * r + 1] * D[4] + Na[3 * r + 2] * D[5];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) P[3 * r + c] = Q[3 * r] * Nb[3 * c] + Q[3 * r + 1] * Nb[3 * c + 1] + Q[3 * r + 2] * Nb[3 * c + 2];   // P = Q Nb^T
+        // top half: [P | rows of P crossed with Pc_b]
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double p0 = P[3 * r], p1 = P[3 * r + 1], p2 = P[3 * r + 2];
+            G[6 * r + 0] = p0; G[6 * r + 1] = p1; G[6 * r + 2] = p2;
+            G[6 * r + 3] = pb.y * p2 - pb.z * p1; G[6 * r + 4] = pb.z * p0 - pb.x * p2; G[6 * r + 5] = pb.x * p1 - pb.y * p0;
+        }
+        // bottom half: Pc_a crossed with the columns of the top half
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double t0 = G[c], t1 = G[6 + c], t2 = G[12 + c];
+            G[18 + c] = pa.y * t2 - pa.z * t1; G[24 + c] = pa.z * t0 - pa.x * t2; G[30 + c] = pa.x * t1 - pa.y * t0;
+        }
+        if (diag) {
+            const double v0 = Q[0] * B[0] + Q[1] * B[1] + Q[2] * B[2], v1 = Q[3] * B[0] + Q[4] * B[1] + Q[5] * B[2], v2 = Q[6] * B[0] + Q[7] * B[1] + Q[8] * B[2];
+            gb[0] = v0; gb[1] = v1; gb[2] = v2;
+            gb[3] = pa.y * v2 - pa.z * v1; gb[4] = pa.z * v0 - pa.x * v2; gb[5] = pa.x * v1 - pa.y * v0;
         }
     }
     // two halves of 21 sums (block rows 0-2 + b_s 0-2, block rows 3-5 + b_s 3-5): halves the live accumulator registers
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int rr = 3 * half + r;
+        for (int q = 0; q < 18; ++q) acc[q] = G[18 * half + q];
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
-                acc[r * 6 + c] = Y[rr * 3] * Wb[c * 3] + Y[rr * 3 + 1] * Wb[c * 3 + 1] + Y[rr * 3 + 2] * Wb[c * 3 + 2];
-            acc[18 + r] = Y[rr * 3] * B[0] + Y[rr * 3 + 1] * B[1] + Y[rr * 3 + 2] * B[2];
-        }
+        for (int r = 0; r < 3; ++r) acc[18 + r] = gb[3 * half + r];
         int off = 0, len = 21;
         ReduceScatter<21, 32>::run(acc, lane, off, len);
         if (half == 0) { keep0 = acc[0]; off0 = off; len0 = len; } else { keep1 = acc[0]; off1 = off; len1 = len; }

@@ -239,6 +239,24 @@ BA_HD void hpl_tile(const Rt& T, const Vec3& pc, double wo, const Intrinsics& K,
             Wv[r * 3 + c] = Jx[r] * wo * Jp[c] + Jx[6 + r] * wo * Jp[3 + c] + Jx[12 + r] * wo * Jp[6 + c];
 }
 
+// Structure of the H_pl tile.  With A = d(pi)/d(Pc) (3x3, five non-zeros) the Jacobians of stereo_jacobians are
+// Jp = -A R and Jx = [-A | A [Pc]x], so the tile W = Jx^T (wo I) Jp = [N ; [Pc]x N] with N = (wo A^T A) R: only the 3x3
+// core N has to be formed, the lower half is three cross products.  A^T A = [[2a^2, 0, a(c+e)], [0, b^2, bd],
+// [a(c+e), bd, c^2+d^2+e^2]] with a = fx/z, b = fy/z, c = -fx x/z^2, d = -fy y/z^2, e = c + bf/z^2.
+// Same values as hpl_tile up to rounding (different association); used where the arithmetic is the bound (Schur gather).
+BA_HD void tile_core(const Mat3& R, const Vec3& pc, double wo, const Intrinsics& K, double N[9]) {
+    const double iz = 1.0 / pc.z, iz2 = iz * iz;
+    const double a = K.fx * iz, b = K.fy * iz;
+    const double c = -K.fx * pc.x * iz2, d = -K.fy * pc.y * iz2, e = c + K.bf * iz2;
+    const double m00 = wo * (2.0 * a * a), m02 = wo * (a * (c + e)), m11 = wo * (b * b), m12 = wo * (b * d);
+    const double m22 = wo * (c * c + d * d + e * e);
+    N[0] = m00 * R.m00 + m02 * R.m20; N[1] = m00 * R.m01 + m02 * R.m21; N[2] = m00 * R.m02 + m02 * R.m22;
+    N[3] = m11 * R.m10 + m12 * R.m20; N[4] = m11 * R.m11 + m12 * R.m21; N[5] = m11 * R.m12 + m12 * R.m22;
+    N[6] = m02 * R.m00 + m12 * R.m10 + m22 * R.m20;
+    N[7] = m02 * R.m01 + m12 * R.m11 + m22 * R.m21;
+    N[8] = m02 * R.m02 + m12 * R.m12 + m22 * R.m22;
+}
+
 // [g2o-upstream] RobustKernelHuber::robustify on chi2 = e^T Omega e (delta compared SQUARED).
 BA_HD void huber(double e2, double delta, double& rho0, double& rho1) {
     const double dsqr = delta * delta;
