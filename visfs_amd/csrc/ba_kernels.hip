@@ -1179,11 +1179,17 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int
         if (a < 0 || !lfree) continue;
         const double2* seed = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)k);
         const double2 s0 = seed[0], s1 = seed[1];
-        double Wv[18];
-        hpl_tile(load_Rt(sRt0, ipk), Vec3{ s0.x, s0.y, s1.x }, s1.y, K, Wv);
+        // Hpl^T x through the tile structure W = [N ; [Pc]x N]:  W^T x = N^T (x_t - Pc x x_r)
+        const Vec3 pcs{ s0.x, s0.y, s1.x };
+        double N[9];
+        tile_core(load_Rt(sRt0, ipk).R, pcs, s1.y, K, N);
         const double* xp = g.x + 6 * (size_t)a;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { const double xr = xp[r]; t0 += Wv[r * 3] * xr; t1 += Wv[r * 3 + 1] * xr; t2 += Wv[r * 3 + 2] * xr; }
+        const double u0 = xp[0] - (pcs.y * xp[5] - pcs.z * xp[4]);
+        const double u1 = xp[1] - (pcs.z * xp[3] - pcs.x * xp[5]);
+        const double u2 = xp[2] - (pcs.x * xp[4] - pcs.y * xp[3]);
+        t0 += N[0] * u0 + N[3] * u1 + N[6] * u2;
+        t1 += N[1] * u0 + N[4] * u1 + N[7] * u2;
+        t2 += N[2] * u0 + N[5] * u1 + N[8] * u2;
     }
     t0 = group_sum<G>(t0); t1 = group_sum<G>(t1); t2 = group_sum<G>(t2);
     any = group_max<G>(any);
