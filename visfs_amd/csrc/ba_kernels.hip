@@ -52,23 +52,45 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_mov<0x128>(v);     // row_ror:8  → every lane holds the sum of its row of 16
     return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
+// Value of lane (lane ^ M) without the LDS crossbar: quad_perm / row_ror DPP moves inside a row of 16, v_permlane16_swap /
+// v_permlane32_swap (gfx950) across rows — ds_bpermute costs an LDS round trip per 32 bits and the reductions below
+// issue dozens per wave (tools/shfl_selftest.hip checks every variant against __shfl_xor on the device).
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <int M>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v) {
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);            // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);       // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {                                                                     // row_ror:4 into banks 1,3; row_ror:12 into banks 0,2
+        const unsigned d = __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xA, false);
+        return __builtin_amdgcn_update_dpp(d, v, 0x12C, 0xF, 0x5, false);
+    }
+    else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);      // row_ror:8
+    else if constexpr (M == 16) { const v2u_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (threadIdx.x & 16) ? r.x : r.y; }
+    else { static_assert(M == 32, "lane mask"); const v2u_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (threadIdx.x & 32) ? r.x : r.y; }
 }
+template <int M>
+__device__ __forceinline__ double xor_lane(double v) {
+    // across rows the permlane swaps measured slightly SLOWER than ds_bpermute in the Schur gather (two swaps + two selects per
+    // double against two bpermutes whose latency other waves hide): DPP inside a row, the LDS crossbar across rows
+    if constexpr (M >= 16) return __shfl_xor(v, M, 64);
+    else {
+        const unsigned lo = xor_lane_u32<M>((unsigned)__double2loint(v)), hi = xor_lane_u32<M>((unsigned)__double2hiint(v));
+        return __hiloint2double((int)hi, (int)lo);
+    }
+}
+template <int M> struct XorTree {          // butterflies over the masks M, M/2, ..., 1
+    static __device__ __forceinline__ double sum(double v) { v += xor_lane<M>(v); return XorTree<M / 2>::sum(v); }
+    static __device__ __forceinline__ double max(double v) { v = fmax(v, xor_lane<M>(v)); return XorTree<M / 2>::max(v); }
+};
+template <> struct XorTree<0> {
+    static __device__ __forceinline__ double sum(double v) { return v; }
+    static __device__ __forceinline__ double max(double v) { return v; }
+};
+__device__ __forceinline__ double wave_max(double v) { return XorTree<32>::max(v); }
 template <int G>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double group_sum(double v) { return XorTree<G / 2>::sum(v); }
 template <int G>
-__device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
-}
+__device__ __forceinline__ double group_max(double v) { return XorTree<G / 2>::max(v); }
 
 // Halving reduce-scatter: sums N per-lane values across an aligned group of W lanes with sum_k ceil(N/2^k)
 // shuffles instead of N*log2(W).  At stage M a lane with bit M clear keeps the low half of its array and
@@ -85,7 +107,7 @@ struct ReduceScatter {
             const double hi = (j + H < N) ? a[j + H] : 0.0;
             const double send = up ? lo : hi;
             const double keep = up ? hi : lo;
-            a[j] = keep + __shfl_xor(send, M, 64);
+            a[j] = keep + xor_lane<M>(send);
         }
         if (up) { off += H; len = len > H ? len - H : 0; } else { len = len < H ? len : H; }
         ReduceScatter<H, M / 2>::run(a, lane, off, len);
@@ -806,9 +828,9 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
                     }
                 }
             }
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
+            acc += xor_lane<8>(acc);
+            acc += xor_lane<16>(acc);
+            acc += xor_lane<32>(acc);
             if (lane < 8) sQ[li * 32 + wave * 8 + lane] = acc;
         }
         __syncthreads();
