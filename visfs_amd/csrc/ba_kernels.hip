@@ -810,7 +810,9 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     while (true) {
         if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
         // ---- owned block rows of q = S d: 32 slots (8 per wave) x 8 lanes (6 rows used), fixed-order partials
-        const int slot = tid >> 3, rr = tid & 7;
+        // lane = 8 * row + slot-in-wave: the eight slots of a wave differ in lane bits 0..2, so their sum is three in-row DPP
+        // exchanges (the former layout, slot in the high bits, needed two LDS-crossbar permutes per iteration); same pairing order
+        const int slot = (tid >> 6) * 8 + (tid & 7), rr = (tid & 63) >> 3;
         for (int li = 0; li < i1 - i0; ++li) {
             const int nb = g.row_ptr[i0 + li + 1] - g.row_ptr[i0 + li];
             double acc = 0.0;
@@ -828,10 +830,10 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
                     }
                 }
             }
-            acc += xor_lane<8>(acc);
-            acc += xor_lane<16>(acc);
-            acc += xor_lane<32>(acc);
-            if (lane < 8) sQ[li * 32 + wave * 8 + lane] = acc;
+            acc += xor_lane<1>(acc);
+            acc += xor_lane<2>(acc);
+            acc += xor_lane<4>(acc);
+            if ((lane & 7) == 0) sQ[li * 32 + wave * 8 + (lane >> 3)] = acc;
         }
         __syncthreads();
         PCG_STAMP(1 + 4 * iter);
