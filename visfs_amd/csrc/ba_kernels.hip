@@ -1598,52 +1598,72 @@ __device__ __forceinline__ void sm_pcg(const DeviceGraph& g, LmState* st, const 
     }
 }
 
-// Dense Cholesky of S in LDS by ONE wavefront (lane r owns row r, right-looking, lower triangle), then the two triangular
-// solves.  Wave-synchronous: LDS traffic of one wave is ordered, a wave barrier separates the steps.  The eliminated
-// column is first copied to sCol, so the row update reads two arrays and writes one at distinct, provable offsets and
-// its loads can be batched (a register-resident row per lane, as in k_chol_diag, sent the compiler into a >10 min build
-// inside these large kernels).  A non-positive or non-finite pivot sets LmState::solver_failed.
+// 1 / sqrt(x) for x > 0: v_rsq_f64 seed + two Newton steps (the IEEE sqrt + division pair costs ~500 dependent cycles, and
+// this sits on the critical path of every eliminated column).
+__device__ __forceinline__ double fast_rsqrt(const double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+// Dense Cholesky of S in LDS by ONE wavefront, LEFT-looking (lane r owns row r of the lower triangle): for column c every
+// lane forms s_r = A[r][c] - sum_{k<c} L[r][k] L[c][k] — the same c terms for every lane, two pipelined LDS reads per term,
+// no store inside the loop —, the pivot s_c is broadcast with a readlane, L[r][c] = s_r / sqrt(s_c).  One wave barrier per
+// column; the right-looking form needed two and a row update whose length differs per lane (33 us at order 30, now ~3x less).
+// Then the two triangular solves.  A non-positive or non-finite pivot sets LmState::solver_failed.
 __device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double* __restrict__ sA, const double* __restrict__ sb,
-                                                double* __restrict__ sx, double* __restrict__ sCol) {
+                                                double* __restrict__ sx, double* __restrict__ /*scratch*/) {
     const int r = threadIdx.x & 63;
     const bool act = r < n;
     bool failed = false;
     for (int c = 0; c < n; ++c) {
-        const double p = sA[c * SM_LD + c];
-        if (!(p > 0.0) || !(p <= DBL_MAX)) { failed = true; break; }
-        const double piv = sqrt(p), inv = 1.0 / piv;
-        double l = 0.0;
-        if (act && r >= c) { l = (r == c) ? piv : sA[r * SM_LD + c] * inv; sA[r * SM_LD + c] = l; }
-        sCol[r] = l;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (act && r > c) {
-            double* __restrict__ Ar = sA + r * SM_LD;
-            int c2 = c + 1;
-            for (; c2 + 8 <= r + 1; c2 += 8) {
-                double v[8], w[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { v[u] = Ar[c2 + u]; w[u] = sCol[c2 + u]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) Ar[c2 + u] = v[u] - l * w[u];
-            }
-            for (; c2 <= r; ++c2) Ar[c2] -= l * sCol[c2];
+        double sv = 0.0;
+        if (act && r >= c) {
+            const double* __restrict__ Ar = sA + r * SM_LD;
+            const double* __restrict__ Ac = sA + c * SM_LD;
+            sv = Ar[c];
+            int k = 0;
+            for (; k + 4 <= c; k += 4) sv -= Ar[k] * Ac[k] + Ar[k + 1] * Ac[k + 1] + Ar[k + 2] * Ac[k + 2] + Ar[k + 3] * Ac[k + 3];
+            for (; k < c; ++k) sv -= Ar[k] * Ac[k];
         }
+        const double p = readlane_f64(sv, c);               // lane c holds the pivot
+        if (!(p > 0.0) || !(p <= DBL_MAX)) { failed = true; break; }
+        const double inv = fast_rsqrt(p);
+        if (act && r >= c) sA[r * SM_LD + c] = sv * inv;     // r == c: p / sqrt(p) = sqrt(p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
     if (failed) { if (r == 0) st->solver_failed = 1; return; }
+    // substitutions: the finished component is broadcast with a readlane (uniform index) instead of an LDS-crossbar shuffle,
+    // and the factor entries of four steps are loaded ahead of the dependent chain
     const double inv = act ? 1.0 / sA[r * SM_LD + r] : 1.0;
     double acc = act ? sb[r] : 0.0;
-    for (int c = 0; c < n; ++c) {                           // L y = b
-        const double yc = __shfl(acc * inv, c, 64);
-        if (act && r > c) acc -= sA[r * SM_LD + c] * yc;
-        if (r == c) acc = yc;
+    for (int c0 = 0; c0 < n; c0 += 4) {                     // L y = b
+        double l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) l[u] = (act && c0 + u < n && r > c0 + u) ? sA[r * SM_LD + c0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u;
+            if (c < n) {
+                const double yc = readlane_f64(acc * inv, c);
+                acc = (r == c) ? yc : acc - l[u] * yc;
+            }
+        }
     }
-    for (int c = n - 1; c >= 0; --c) {                      // L^T x = y
-        const double xc = __shfl(acc * inv, c, 64);
-        if (act && r < c) acc -= sA[c * SM_LD + r] * xc;
-        if (r == c) acc = xc;
+    for (int c0 = n - 1; c0 >= 0; c0 -= 4) {                // L^T x = y
+        double l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) l[u] = (act && c0 - u >= 0 && r < c0 - u) ? sA[(c0 - u) * SM_LD + r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 - u;
+            if (c >= 0) {
+                const double xc = readlane_f64(acc * inv, c);
+                acc = (r == c) ? xc : acc - l[u] * xc;
+            }
+        }
     }
     if (act) sx[r] = acc;
 }
