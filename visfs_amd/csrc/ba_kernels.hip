@@ -1612,8 +1612,7 @@ __device__ __forceinline__ double fast_rsqrt(const double x) {
 // no store inside the loop —, the pivot s_c is broadcast with a readlane, L[r][c] = s_r / sqrt(s_c).  One wave barrier per
 // column; the right-looking form needed two and a row update whose length differs per lane (33 us at order 30, now ~3x less).
 // Then the two triangular solves.  A non-positive or non-finite pivot sets LmState::solver_failed.
-__device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double* __restrict__ sA, const double* __restrict__ sb,
-                                                double* __restrict__ sx, double* __restrict__ /*scratch*/) {
+__device__ __forceinline__ bool sm_cholesky_factor_lds(const int n, double* __restrict__ sA) {
     const int r = threadIdx.x & 63;
     const bool act = r < n;
     bool failed = false;
@@ -1634,9 +1633,13 @@ __device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
-    if (failed) { if (r == 0) st->solver_failed = 1; return; }
-    // substitutions: the finished component is broadcast with a readlane (uniform index) instead of an LDS-crossbar shuffle,
-    // and the factor entries of four steps are loaded ahead of the dependent chain
+    return failed;
+}
+// L y = b, L^T x = y on one wavefront: the finished component is broadcast with a readlane (uniform index) instead of an
+// LDS-crossbar shuffle, and the factor entries of four steps are loaded ahead of the dependent chain.
+__device__ __forceinline__ void sm_cholesky_substitute(const int n, const double* __restrict__ sA, const double* __restrict__ sb, double* __restrict__ sx) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < n;
     const double inv = act ? 1.0 / sA[r * SM_LD + r] : 1.0;
     double acc = act ? sb[r] : 0.0;
     for (int c0 = 0; c0 < n; c0 += 4) {                     // L y = b
@@ -1667,6 +1670,45 @@ __device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double
     }
     if (act) sx[r] = acc;
 }
+__device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double* __restrict__ sA, const double* __restrict__ sb,
+                                                double* __restrict__ sx, double* __restrict__ /*scratch*/) {
+    if (sm_cholesky_factor_lds(n, sA)) { if ((threadIdx.x & 63) == 0) st->solver_failed = 1; return; }
+    sm_cholesky_substitute(n, sA, sb, sx);
+}
+
+// Order <= 32 (the production window: 5 free poses → 30): lane r keeps its row of L in REGISTERS (static indices, loops fully
+// unrolled), row c is read from LDS as broadcasts: per column c FMAs fed by c pipelined LDS reads, the pivot by a readlane.
+// Only instantiated in k_small_solve (the fused kernel keeps the LDS-row version: compile time).
+__device__ __forceinline__ bool sm_cholesky_factor32(const int n, double* __restrict__ sA) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < n;
+    double a[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = (act && c <= r && c < n) ? sA[r * SM_LD + c] : 0.0;
+    bool failed = false;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (c < n && !failed) {                                   // uniform
+            const double* __restrict__ Ac = sA + c * SM_LD;
+            double s0 = a[c], s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < c; k += 2) { s0 -= a[k] * Ac[k]; s1 -= a[k + 1] * Ac[k + 1]; }
+            if (c & 1) s0 -= a[c - 1] * Ac[c - 1];
+            const double sv = s0 + s1;
+            const double p = readlane_f64(sv, c);
+            if (!(p > 0.0) || !(p <= DBL_MAX)) failed = true;
+            else {
+                const double l = sv * fast_rsqrt(p);
+                a[c] = (r >= c) ? l : 0.0;
+                if (act && r >= c) sA[r * SM_LD + c] = l;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    return failed;
+}
+
 __device__ __forceinline__ void sm_solve(const DeviceGraph& g, LmState* st, const int solver, const int n6, double* sA, const double* sb, double* sd, double* sx) {
     if (solver == 2) sm_pcg(g, st, n6, sA, sb, sd, sx);
     else sm_cholesky_lds(st, n6, sA, sb, sx, sd);
@@ -1683,8 +1725,15 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
     __shared__ double sA[SM_MAX_N6 * SM_LD];
     __shared__ double sb[SM_MAX_N6], sx[SM_MAX_N6], sd[SM_MAX_N6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VISFS_BA_STAMPS
+#define SS_STAMP(slot) do { if (tid == 0) g.stamps[64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SS_STAMP(slot) do { } while (0)
+#endif
     const int n6 = 6 * g.Npf;
+    SS_STAMP(0);
     for (int b = wave; b < g.n_blk; b += 8) schur_block(g, st, b, lane);
+    SS_STAMP(1);
     for (int t = tid; t < n6 * SM_LD; t += 512) sA[t] = 0.0;
     __syncthreads();
     for (int t = tid; t < g.n_blk * 36; t += 512) {
@@ -1696,8 +1745,18 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
     }
     for (int t = tid; t < n6; t += 512) sb[t] = g.bs[t];
     __syncthreads();
-    if (wave == 0) sm_solve(g, st, solver, n6, sA, sb, sd, sx);
+    SS_STAMP(2);
+    if (wave == 0) {
+        if (solver == 2) sm_pcg(g, st, n6, sA, sb, sd, sx);
+        else {
+            const bool failed = (n6 <= 32) ? sm_cholesky_factor32(n6, sA) : sm_cholesky_factor_lds(n6, sA);
+            if (failed) { if (lane == 0) st->solver_failed = 1; }
+            else sm_cholesky_substitute(n6, sA, sb, sx);
+        }
+    }
+    SS_STAMP(3);
     __syncthreads();
+    SS_STAMP(4);
     if (ld_state(&st->solver_failed) != 0) return;
     for (int t = tid; t < n6; t += 512) g.x[t] = sx[t];
     const int sel = st->sel;
@@ -1708,6 +1767,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
         for (int q = 0; q < 6; ++q) dx[q] = sx[6 * a + q];
         pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
     }
+    SS_STAMP(5);
 }
 
 #ifdef VISFS_BA_STAMPS
