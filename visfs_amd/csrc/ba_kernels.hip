@@ -1679,15 +1679,16 @@ __device__ __forceinline__ void sm_cholesky_lds(LmState* st, const int n, double
 // Order <= 32 (the production window: 5 free poses → 30): lane r keeps its row of L in REGISTERS (static indices, loops fully
 // unrolled), row c is read from LDS as broadcasts: per column c FMAs fed by c pipelined LDS reads, the pivot by a readlane.
 // Only instantiated in k_small_solve (the fused kernel keeps the LDS-row version: compile time).
-__device__ __forceinline__ bool sm_cholesky_factor32(const int n, double* __restrict__ sA) {
+template <int N>
+__device__ __forceinline__ bool sm_cholesky_factor_reg(const int n, double* __restrict__ sA) {
     const int r = threadIdx.x & 63;
     const bool act = r < n;
-    double a[32];
+    double a[N];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) a[c] = (act && c <= r && c < n) ? sA[r * SM_LD + c] : 0.0;
+    for (int c = 0; c < N; ++c) a[c] = (act && c <= r && c < n) ? sA[r * SM_LD + c] : 0.0;
     bool failed = false;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < N; ++c) {
         if (c < n && !failed) {                                   // uniform
             const double* __restrict__ Ac = sA + c * SM_LD;
             double s0 = a[c], s1 = 0.0;
@@ -1749,7 +1750,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
     if (wave == 0) {
         if (solver == 2) sm_pcg(g, st, n6, sA, sb, sd, sx);
         else {
-            const bool failed = (n6 <= 32) ? sm_cholesky_factor32(n6, sA) : sm_cholesky_factor_lds(n6, sA);
+            const bool failed = (n6 <= 32) ? sm_cholesky_factor_reg<32>(n6, sA) : sm_cholesky_factor_reg<64>(n6, sA);
             if (failed) { if (lane == 0) st->solver_failed = 1; }
             else sm_cholesky_substitute(n6, sA, sb, sx);
         }
