@@ -92,6 +92,15 @@ __device__ __forceinline__ double group_sum(double v) { return XorTree<G / 2>::s
 template <int G>
 __device__ __forceinline__ double group_max(double v) { return XorTree<G / 2>::max(v); }
 
+// 1 / sqrt(x) for x > 0: v_rsq_f64 seed + two Newton steps (the IEEE sqrt + division pair costs ~500 dependent cycles, and
+// this sits on the critical path of every eliminated column).
+__device__ __forceinline__ double fast_rsqrt(const double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
 // Halving reduce-scatter: sums N per-lane values across an aligned group of W lanes with sum_k ceil(N/2^k)
 // shuffles instead of N*log2(W).  At stage M a lane with bit M clear keeps the low half of its array and
 // receives its partner's low half; a lane with the bit set does the same with the high halves.  On return
@@ -997,34 +1006,36 @@ __global__ __launch_bounds__(64) void k_chol_diag(const DeviceGraph g, const int
     const int NP = g.chol_np, tid = threadIdx.x;
     double* A = g.dense;
     __shared__ double sL[CH_NB][CH_NB + 1];        // L11, row-major (padded)
-    __shared__ double sCol[CH_NB];                 // the column being eliminated
     __shared__ double sInv[CH_NB];                 // 1 / L11[c][c]
     const int r = tid & 31;
     const bool act = tid < 32;
     double a[CH_NB];
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) a[c] = act ? A[(size_t)(kb + r) * NP + kb + c] : 0.0;
+    // left-looking: s_r = A[r][c] - sum_{k<c} L[r][k] L[c][k] with the lane's own row in registers and row c read from LDS as
+    // broadcasts (written there column by column), the pivot by a readlane, rsq + two Newton steps instead of sqrt + division:
+    // one wave barrier per column (the right-looking form with an IEEE sqrt / division pair cost 0.65 us per column)
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) {
-        const double p = __shfl(a[c], c, 64);                       // pivot: already reduced by the columns before it
-        if (!(p > 0.0) || !(p <= DBL_MAX)) bad = true;
-        const double piv = sqrt(p), inv = 1.0 / piv;
-        const double l = (r == c) ? piv : a[c] * inv;                  // L[r][c] for r >= c
-        a[c] = (r >= c) ? l : 0.0;
-        if (act) sCol[r] = a[c];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        double s0 = a[c], s1 = 0.0;
 #pragma unroll
-        for (int c2 = c + 1; c2 < CH_NB; ++c2) a[c2] -= a[c] * sCol[c2];  // eager update of the row (rows < c carry 0)
+        for (int k = 0; k + 1 < c; k += 2) { s0 -= a[k] * sL[c][k]; s1 -= a[k + 1] * sL[c][k + 1]; }
+        if (c & 1) s0 -= a[c - 1] * sL[c][c - 1];
+        const double sv = s0 + s1;
+        const double p = readlane_f64(sv, c);
+        if (!(p > 0.0) || !(p <= DBL_MAX)) bad = true;
+        const double inv = fast_rsqrt(p);
+        a[c] = (r >= c) ? sv * inv : 0.0;                              // r == c: p / sqrt(p) = sqrt(p)
+        if (act) sL[r][c] = a[c];
+        if (r == c && act) sInv[c] = inv;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        if (r == c && act) sInv[c] = inv;
     }
     if (__any(bad)) { if (tid == 0) st->solver_failed = 1; return; }
     if (act) {
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) { sL[r][c] = a[c]; A[(size_t)(kb + r) * NP + kb + c] = a[c]; }
+        for (int c = 0; c < CH_NB; ++c) A[(size_t)(kb + r) * NP + kb + c] = a[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1125,11 +1136,13 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
             double acc = y[kb + r];
             const double* Lr = A + (size_t)(kb + r) * NP + kb;
             const double inv = 1.0 / Lr[r];
+            double lrow[CH_NB];                                           // the row of L11 ahead of the dependent chain
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) lrow[c] = Lr[c];
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) {
-                const double yc = __shfl(acc * inv, c, 64);               // lane c holds the finished y_c
-                if (r > c) acc -= Lr[c] * yc;
-                if (r == c) acc = yc;
+                const double yc = readlane_f64(acc * inv, c);             // lane c holds the finished y_c (uniform index: no LDS crossbar)
+                acc = (r == c) ? yc : ((r > c) ? acc - lrow[c] * yc : acc);
             }
             if (tid < 32) { sy[r] = acc; y[kb + r] = acc; }
         }
@@ -1149,11 +1162,13 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
             const int r = tid & 31;
             double acc = y[kb + r];
             const double inv = 1.0 / A[(size_t)(kb + r) * NP + kb + r];
+            double lcol[CH_NB];                                           // L^T[r][c] = L[c][r]
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) lcol[c] = A[(size_t)(kb + c) * NP + kb + r];
 #pragma unroll
             for (int c = CH_NB - 1; c >= 0; --c) {
-                const double xc = __shfl(acc * inv, c, 64);
-                if (r < c) acc -= A[(size_t)(kb + c) * NP + kb + r] * xc;   // L^T[r][c] = L[c][r]
-                if (r == c) acc = xc;
+                const double xc = readlane_f64(acc * inv, c);
+                acc = (r == c) ? xc : ((r < c) ? acc - lcol[c] * xc : acc);
             }
             if (tid < 32) { sy[r] = acc; y[kb + r] = acc; }
         }
@@ -1596,15 +1611,6 @@ __device__ __forceinline__ void sm_pcg(const DeviceGraph& g, LmState* st, const 
         st->pcg_total += iter;
         if (iter > st->pcg_max) st->pcg_max = iter;
     }
-}
-
-// 1 / sqrt(x) for x > 0: v_rsq_f64 seed + two Newton steps (the IEEE sqrt + division pair costs ~500 dependent cycles, and
-// this sits on the critical path of every eliminated column).
-__device__ __forceinline__ double fast_rsqrt(const double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
 }
 
 // Dense Cholesky of S in LDS by ONE wavefront, LEFT-looking (lane r owns row r of the lower triangle): for column c every
