@@ -40,8 +40,8 @@ def algorithmic_bytes(kernel, d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", help="C1..C5 / PROD (BASELINE.json configs); C2 is the headline")
     ap.add_argument("--windows-per-gpu", type=int, default=1)
     ap.add_argument("--solver", type=int, default=2, help="Optimizer/Solver: 2 = PCG (headline), 0 = direct Cholesky")
