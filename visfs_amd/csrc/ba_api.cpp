@@ -417,8 +417,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
+        g.chol_f = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
         g.chol_y = A.take<double>(chol_np);
-        g.chol_linv = A.take<double>(32 * 32);
+        g.chol_linv = A.take<double>(2 * 32 * 32);
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };

@@ -148,9 +148,10 @@ struct DeviceGraph {
     unsigned long long* granules; // [2][2*6Npf] {epoch:32 | half of a double:32} hand-off words of the persistent PCG
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
+    double* chol_f;             // [chol_np][chol_np] the Cholesky factor L (direct solver), separate from the matrix being updated
     double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)
     double* chol_y;             // [chol_np]
-    double* chol_linv;          // [32][32] inverse of the current diagonal block
+    double* chol_linv;          // [2][32][32] inverse of the diagonal block of panel p in half p & 1
 
     LmState* st;
     unsigned long long* stamps;  // [128] diagnostic build (-DVISFS_BA_STAMPS) only: real-time stamps of one PCG workgroup

@@ -973,10 +973,11 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
 // Optimizer/Solver 0, 1, 3 (CSparse / Cholmod / Eigen sparse Cholesky in the reference, Optimizer.cpp:76-91) all factor
 // S = L L^T and back-substitute; here S is assembled dense (n = 6 Npf padded to a multiple of 32 with an identity tail)
 // and factored right-looking with 32-wide panels:
-//   k_chol_diag   (one wavefront)  : wave-synchronous Cholesky of the 32x32 diagonal block and its inverse;
-//   k_chol_trsm   (all CUs)        : L21 = A21 L11^-T as independent dot products, one thread per row;
-//   k_chol_syrk   (all CUs)        : A22 -= L21 L21^T on 32x32 tiles per wave with fp64 MFMA (v_mfma_f64_16x16x4_f64) — the
-//                                    dense reduced-camera GEMM, the only MFMA-shaped work on this path;
+//   k_chol_diag   (one wavefront)  : wave-synchronous Cholesky of the first 32x32 diagonal block and its inverse;
+//   k_chol_update (all CUs)        : L21 = A21 L11^-T formed per 64x64 tile into LDS, then A22 -= L21 L21^T on 32x32 tiles per
+//                                    wave with fp64 MFMA (v_mfma_f64_16x16x4_f64) — the dense reduced-camera GEMM, the only
+//                                    MFMA-shaped work on this path; L goes to chol_f, the updated matrix stays in dense;
+//                                    the wave holding the next diagonal block factors it in place (look-ahead);
 //   k_chol_solve  (one workgroup)  : blocked forward / backward substitution, then K8 (pose oplus).
 // A non-positive or non-finite pivot sets LmState::solver_failed (g2o: solver returns false → the LM trial is rejected).
 constexpr int CH_NB = 32;
@@ -1000,18 +1001,19 @@ __global__ __launch_bounds__(256) void k_dense_assemble(const DeviceGraph g) {
 }
 
 // One wavefront: Cholesky of the 32x32 diagonal block and its inverse (lanes 0..31 own one row / one column each).
-__global__ __launch_bounds__(64) void k_chol_diag(const DeviceGraph g, const int kb) {
+// Factor the 32x32 diagonal block at kb and invert it: ONE wavefront (lanes 0..31 = rows; the upper half idles).  The block
+// arrives in sL (LDS, row-major), L11 goes to chol_f, L11^-1 to linv (the ping-pong half of panel kb / 32).
+__device__ __forceinline__ void chol_diag_block(const DeviceGraph& g, const int kb, double (*sL)[CH_NB + 1], double* sInv, const int lane) {
     LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
-    const int NP = g.chol_np, tid = threadIdx.x;
-    double* A = g.dense;
-    __shared__ double sL[CH_NB][CH_NB + 1];        // L11, row-major (padded)
-    __shared__ double sInv[CH_NB];                 // 1 / L11[c][c]
-    const int r = tid & 31;
-    const bool act = tid < 32;
+    const int NP = g.chol_np;
+    const int r = lane & 31;
+    const bool act = lane < 32;
+    double* linv = g.chol_linv + ((kb / CH_NB) & 1) * CH_NB * CH_NB;
     double a[CH_NB];
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) a[c] = act ? A[(size_t)(kb + r) * NP + kb + c] : 0.0;
+    for (int c = 0; c < CH_NB; ++c) a[c] = sL[r][c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     // left-looking: s_r = A[r][c] - sum_{k<c} L[r][k] L[c][k] with the lane's own row in registers and row c read from LDS as
     // broadcasts (written there column by column), the pivot by a readlane, rsq + two Newton steps instead of sqrt + division:
     // one wave barrier per column (the right-looking form with an IEEE sqrt / division pair cost 0.65 us per column)
@@ -1032,10 +1034,10 @@ __global__ __launch_bounds__(64) void k_chol_diag(const DeviceGraph g, const int
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
-    if (__any(bad)) { if (tid == 0) st->solver_failed = 1; return; }
+    if (__any(bad)) { if (lane == 0) st->solver_failed = 1; return; }
     if (act) {
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) A[(size_t)(kb + r) * NP + kb + c] = a[c];
+        for (int c = 0; c < CH_NB; ++c) g.chol_f[(size_t)(kb + r) * NP + kb + c] = a[c];      // the factor lives beside the matrix being updated
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1050,46 +1052,70 @@ __global__ __launch_bounds__(64) void k_chol_diag(const DeviceGraph g, const int
     }
     if (act) {
 #pragma unroll
-        for (int rr = 0; rr < CH_NB; ++rr) g.chol_linv[rr * CH_NB + r] = a[rr];      // row-major L11^-1
+        for (int rr = 0; rr < CH_NB; ++rr) linv[rr * CH_NB + r] = a[rr];      // row-major L11^-1
     }
 }
 
-// L21 = A21 L11^-T: x[c] = sum_{k<=c} a[k] Linv[c][k] — independent dot products, one thread per row, rows over all CUs.
-__global__ __launch_bounds__(256) void k_chol_trsm(const DeviceGraph g, const int kb) {
+// The first panel's diagonal block (the later ones are factored by k_chol_update's look-ahead).
+__global__ __launch_bounds__(64) void k_chol_diag(const DeviceGraph g, const int kb) {
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
     const int NP = g.chol_np, tid = threadIdx.x;
-    __shared__ double sLi[CH_NB][CH_NB + 1];
-    for (int t = tid; t < CH_NB * CH_NB; t += 256) sLi[t / CH_NB][t % CH_NB] = g.chol_linv[t];
-    __syncthreads();
-    const int row = kb + CH_NB + blockIdx.x * 256 + tid;
-    if (row >= NP) return;
-    double a[CH_NB];
-    double* Ar = g.dense + (size_t)row * NP + kb;
+    __shared__ double sL[CH_NB][CH_NB + 1];        // the block, then L11, row-major (padded)
+    __shared__ double sInv[CH_NB];                 // 1 / L11[c][c]
+    if (tid < 32) {
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) a[c] = Ar[c];
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k <= c; ++k) v += a[k] * sLi[c][k];
-        Ar[c] = v;
+        for (int c = 0; c < CH_NB; ++c) sL[tid][c] = g.dense[(size_t)(kb + tid) * NP + kb + c];
     }
+    chol_diag_block(g, kb, sL, sInv, tid);
 }
 
-// A22 -= L21 L21^T.  One wave = one 32x32 tile (2x2 MFMA tiles of 16x16, K = 32 in 8 steps of 4); workgroup = 64x64.
+// One launch per panel: L21 = A21 L11^-T and the trailing update A22 -= L21 L21^T together.  A workgroup owns a 64x64 tile
+// (ti >= tj) of the trailing matrix; it first forms the L21 rows of its two block rows itself (x[c] = sum_{k<=c} a[k] Linv[c][k],
+// one thread per (row, parity of c), L11^-1 in LDS) — redundantly across the tiles of a block row, which costs less than the
+// launch it saves — keeps them in LDS as the MFMA operands, and the diagonal tiles store theirs into the factor matrix
+// chol_f (NOT in place: other tiles of the same launch still read the unconverted A21 from `dense`).
+// One wave = one 32x32 sub-tile (2x2 MFMA tiles of 16x16, K = 32 in 8 steps of 4).
 // fp64 MFMA operand maps (cdna_hip_programming.md §3): A[l&15][k = l>>4], B[k = l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
-__global__ __launch_bounds__(256) void k_chol_syrk(const DeviceGraph g, const int kb) {
+__global__ __launch_bounds__(256) void k_chol_update(const DeviceGraph g, const int kb) {
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
-    const int NP = g.chol_np;
+    const int NP = g.chol_np, tid = threadIdx.x;
     const int t0 = kb + CH_NB;                          // first row / column of the trailing matrix
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti) return;                                // lower triangle of 64x64 tiles
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ri = t0 + 64 * ti + 32 * (wave >> 1), rj = t0 + 64 * tj + 32 * (wave & 1);
+    __shared__ double sLinv[CH_NB][CH_NB + 1];
+    __shared__ double sL[2][64][CH_NB + 1];             // L21 rows of block row ti ([0]) and tj ([1])
+    __shared__ double sD[CH_NB][CH_NB + 1];             // look-ahead: the next diagonal block (tile (0,0), wave 0)
+    __shared__ double sDinv[CH_NB];
+    const double* linv = g.chol_linv + ((kb / CH_NB) & 1) * CH_NB * CH_NB;
+    for (int t = tid; t < CH_NB * CH_NB; t += 256) sLinv[t / CH_NB][t % CH_NB] = linv[t];
+    __syncthreads();
+    {
+        const int which = tid >> 7, row_l = (tid >> 1) & 63, par = tid & 1;      // 2 block rows x 64 rows x 2 parities of c
+        const int row = t0 + 64 * (which ? tj : ti) + row_l;
+        const bool need = (which == 0 || tj != ti) && row < NP;
+        double a[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) a[c] = need ? g.dense[(size_t)row * NP + kb + c] : 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < CH_NB / 2; ++c2) {
+            const int c = 2 * c2 + par;                 // static register indices throughout: k <= 2 c2 for both parities,
+            double v = 0.0;                             // the odd column adds its last term
+#pragma unroll
+            for (int k = 0; k <= 2 * c2; ++k) v += a[k] * sLinv[c][k];
+            if (par) v += a[2 * c2 + 1] * sLinv[c][2 * c2 + 1];
+            sL[which][row_l][c] = v;
+            if (need && which == 0 && tj == ti) g.chol_f[(size_t)row * NP + kb + c] = v;
+        }
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wi = 32 * (wave >> 1), wj = 32 * (wave & 1);
+    const int ri = t0 + 64 * ti + wi, rj = t0 + 64 * tj + wj;
     if (ri >= NP || rj >= NP || rj > ri + 31) return;   // outside the matrix / strictly above the diagonal
-    const double* A = g.dense;
+    const int jb = (tj != ti) ? 1 : 0;
+    double* A = g.dense;
     const int lr = lane & 15, lk = lane >> 4;
     v4f64 acc[2][2];
 #pragma unroll
@@ -1100,23 +1126,36 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const DeviceGraph g, const in
             for (int q = 0; q < 4; ++q)
                 acc[u][v][q] = A[(size_t)(ri + 16 * u + lk + 4 * q) * NP + rj + 16 * v + lr];
 #pragma unroll
-    for (int s = 0; s < CH_NB / 4; ++s) {
-        const int k = kb + 4 * s + lk;
-        const double a0 = -A[(size_t)(ri + lr) * NP + k], a1 = -A[(size_t)(ri + 16 + lr) * NP + k];
-        const double b0 = A[(size_t)(rj + lr) * NP + k], b1 = A[(size_t)(rj + 16 + lr) * NP + k];
+    for (int s2 = 0; s2 < CH_NB / 4; ++s2) {
+        const int k = 4 * s2 + lk;
+        const double a0 = -sL[0][wi + lr][k], a1 = -sL[0][wi + 16 + lr][k];
+        const double b0 = sL[jb][wj + lr][k], b1 = sL[jb][wj + 16 + lr][k];
         acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
-    double* Aw = g.dense;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                Aw[(size_t)(ri + 16 * u + lk + 4 * q) * NP + rj + 16 * v + lr] = acc[u][v][q];
+                A[(size_t)(ri + 16 * u + lk + 4 * q) * NP + rj + 16 * v + lr] = acc[u][v][q];
+    // look-ahead: the wave that owns the next diagonal block (tile (0,0), sub-tile (0,0)) factors and inverts it straight from
+    // its accumulators, so the next panel needs no launch of its own.  Its L11^-1 goes to the other ping-pong half of chol_linv
+    // (this launch's tiles still read the current one).
+    if (ti == 0 && tj == 0 && wave == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sD[16 * u + lk + 4 * q][16 * v + lr] = acc[u][v][q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        chol_diag_block(g, t0, sD, sDinv, lane);
+    }
 }
 
 // Blocked forward (L y = b) and backward (L^T x = y) substitution, then K8.  One workgroup.
@@ -1124,7 +1163,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL) || st->solver_failed) return;
     const int NP = g.chol_np, n6 = 6 * g.Npf, tid = threadIdx.x;
-    const double* A = g.dense;
+    const double* A = g.chol_f;                          // L: diagonal blocks from k_chol_diag, panels from k_chol_update
     double* y = g.chol_y;                               // [NP] work vector
     __shared__ double sy[CH_NB];
     for (int t = tid; t < NP; t += 1024) y[t] = (t < n6) ? g.bs[t] : 0.0;
@@ -2084,14 +2123,10 @@ void launch_direct(const DeviceGraph& g, hipStream_t s) {
     if (grid > 1024) grid = 1024;
     (void)hipMemsetAsync(g.dense, 0, (size_t)NP * NP * sizeof(double), s);     // the factor fills in: clear the scratch every solve
     hipLaunchKernelGGL(k_dense_assemble, dim3(grid), dim3(256), 0, s, g);
-    for (int kb = 0; kb < NP; kb += CH_NB) {
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, g, kb);
-        const int m = NP - kb - CH_NB;
-        if (m > 0) {
-            hipLaunchKernelGGL(k_chol_trsm, dim3((m + 255) / 256), dim3(256), 0, s, g, kb);
-            const int T = (m + 63) / 64;
-            hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, s, g, kb);
-        }
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, g, 0);
+    for (int kb = 0; kb + CH_NB < NP; kb += CH_NB) {                          // one launch per panel: L21, trailing update, next L11
+        const int T = (NP - kb - CH_NB + 63) / 64;
+        hipLaunchKernelGGL(k_chol_update, dim3(T, T), dim3(256), 0, s, g, kb);
     }
     hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, s, g);
 }
