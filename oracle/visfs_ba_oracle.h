@@ -14,7 +14,9 @@
  * ([g2o-upstream] marks: g2o/core/optimization_algorithm_levenberg.cpp,
  * block_solver.hpp, base_binary_edge.hpp, robust_kernel_impl.cpp,
  * solvers/pcg/linear_solver_pcg.hpp).  It is pinned only by the known-answer
- * vectors, finite-difference checks and fixed-point tests under tests/.
+ * vectors, finite-difference checks and fixed-point tests under tests/; the single
+ * piece checked against the reference's own test vectors is the grid addressing of
+ * the laser factor (tests/golden/ref_map2d_cell_index.json).
  */
 #ifndef VISFS_BA_ORACLE_H
 #define VISFS_BA_ORACLE_H

@@ -215,6 +215,53 @@ def test_bicubic_interpolator_properties(olib):
     assert abs(lo[0] - hi[0]) < 1e-6 and abs(lo[1] - hi[1]) < 1e-4 and abs(lo[2] - hi[2]) < 1e-4
 
 
+def test_laser_grid_addressing_matches_reference_unit_tests(olib):
+    """PINNED against the reference's own test vectors (tests/golden/ref_map2d_cell_index.json, transcribed from
+    tests/Map/2d/UT4ProbabilityGrid/UT4ProbabilityGrid.cpp:58-103): the cell the occupied-space functor samples for a world
+    point (axis swap, flip about `max`, half-cell offset, row-major flat index: TypeOccupiedSpace2D.h:28-37,115-118 over
+    MapLimits.h:43-64 / Grid2d.h:93-95) is the cell MapLimits::getCellIndex names for that point.  Identity pose and
+    identity robot->camera transform make the functor's world point the range point itself; a grid that is 0 except for ONE
+    hot cell then answers > 0.5 exactly when the hot cell is the nearest one (Catmull-Rom weight of the nearest sample at an
+    offset <= 0.25 cell is >= 0.86 per axis), and exactly 1 at a cell centre."""
+    import json, os
+    _laser_setup(olib)
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_map2d_cell_index.json")))
+    tq = np.array([0, 0, 0, 0, 0, 0, 1.0]); Tcr = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.0])
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def sample(gb, pt):
+        P = np.array([pt[0], pt[1], 0.3]); e = C.c_double()
+        olib.oracle_laser_edge(p(tq), p(Tcr), p(P), C.byref(gb.struct), C.byref(e), None)
+        return e.value
+
+    checked = 0
+    for case in fx["cases"]:
+        nx, ny = case["num_x_cells"], case["num_y_cells"]
+        base = dict(resolution=case["resolution"], max_x=case["max"][0], max_y=case["max"][1])
+        hit = set()
+        for v in case["points"]:
+            centre = all(((m - q) / case["resolution"] - 0.5) % 1.0 == 0.0 for m, q in zip(case["max"], v["point"]))
+            found = []
+            for y in range(ny):
+                for x in range(nx):
+                    cost = np.zeros((ny, nx), np.float32); cost[y, x] = 1.0
+                    e = sample(abi.GridBuffers(dict(base, cost=cost)), v["point"])
+                    if e > 0.5:
+                        found.append(([x, y], e))
+            assert len(found) == 1, (v, found)                      # inside the limits, one nearest cell
+            if v["cell"] is not None:
+                assert found[0][0] == v["cell"], (v, found)
+            if centre:
+                assert found[0][1] == 1.0
+            hit.add(tuple(found[0][0])); checked += 1
+        if all(v["cell"] is None for v in case["points"]):
+            assert len(hit) == len(case["points"])                  # four points, four distinct cells, all contained
+        # outside the limits the adapter answers kMaxCorrespondenceCost whatever the grid holds
+        far = [case["max"][0] + 50 * case["resolution"], case["max"][1] + 50 * case["resolution"]]
+        assert sample(abi.GridBuffers(dict(base, cost=np.zeros((ny, nx), np.float32))), far) == 0.9
+    assert checked == 13
+
+
 def test_laser_edge_error_and_aliased_jacobian(olib):
     """computeError uses the true pose; linearizeOplus differentiates the functor with q.w aliased to the range point's x
     (ceres autodiff over StaticParameterDims<6, 3>, TypeOccupiedSpace2D.h:145-179): the restated Jacobian must equal
