@@ -46,6 +46,7 @@ struct Workspace {
     LmState* h_state = nullptr;                    // pinned
     DeviceGraph g{};
     bool loaded = false;
+    bool batch_member = false;                     // one of visfs_ba_solve_batch / visfs_ba_batch_upload's windows (shares its launches)
     bool fused = false;                            // the resident window runs on k_small_optimize
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
     // host mirrors for fetch / unpack
@@ -300,17 +301,27 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     }
 
     // Schur chunks: <= SCH_CHUNK co-observation pairs of one block per wavefront
+    // A lane may take several pairs of its chunk (64 per pass) and add them serially before the wave's reduce-scatter.  Measured
+    // (profiles/r01_v8_schur_passes.log): two passes win 4-5 % on a lone mid-size window (C2: half the waves, half the partials
+    // for k_schur_finalize to sum, all of them still resident in one round) and lose 4-7 % once the launch fills the machine
+    // (C4, batched windows: the serial variant needs 216 VGPRs, 2 waves per SIMD instead of 4).  Results differ from the
+    // one-pass chunking in the last bits only (summation order).
+    int64_t chunks64 = 0;
+    for (int b = 0; b < n_blk; ++b) chunks64 += (blk_ptr[b + 1] - blk_ptr[b] + SCH_CHUNK - 1) / SCH_CHUNK;
+    int sch_passes = (!w.batch_member && chunks64 >= 1024 && chunks64 <= 6144) ? 2 : 1;
+    { const char* e = std::getenv("VISFS_BA_SCH_PASSES"); if (e) { const int q = std::atoi(e); if (q >= 1 && q <= 8) sch_passes = q; } }
+    const int sch_chunk = SCH_CHUNK * sch_passes;
     std::vector<int32_t> blk_chunk_ptr(n_blk + 1, 0), sch_blk, sch_ptr;
     for (int b = 0; b < n_blk; ++b) {
         blk_chunk_ptr[b] = (int32_t)sch_blk.size();
-        for (int e = blk_ptr[b]; e < blk_ptr[b + 1]; e += SCH_CHUNK) { sch_blk.push_back(b); sch_ptr.push_back(e); }
+        for (int e = blk_ptr[b]; e < blk_ptr[b + 1]; e += sch_chunk) { sch_blk.push_back(b); sch_ptr.push_back(e); }
     }
     blk_chunk_ptr[n_blk] = (int32_t)sch_blk.size();
     const int n_sch = (int)sch_blk.size();
     std::vector<int4> sch_desc(std::max(n_sch, 1)), blk_desc(2 * (size_t)std::max(n_blk, 1));
     for (int c = 0; c < n_sch; ++c) {
         const int b = sch_blk[c];
-        sch_desc[c] = make_int4(sch_ptr[c], std::min(sch_ptr[c] + SCH_CHUNK, blk_ptr[b + 1]), free_pose[blk_i[b]], free_pose[blk_j[b]]);
+        sch_desc[c] = make_int4(sch_ptr[c], std::min(sch_ptr[c] + sch_chunk, blk_ptr[b + 1]), free_pose[blk_i[b]], free_pose[blk_j[b]]);
     }
     for (int b = 0; b < n_blk; ++b) {
         const int a = blk_i[b];
@@ -510,7 +521,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     layout_dyn(dd, dg);
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group;
-    dg.n_sch = n_sch; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
@@ -1016,7 +1027,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
     // threads, one workspace per window; the optimisation itself is ONE sequence of launches per group of windows with the
     // same launch-geometry class, blockIdx.y = window (batch_optimize).  VISFS_BA_BATCH=0 falls back to one stream per lane.
     return guarded(h, [&]() -> int {
-        while ((int)h->batch.size() < n) h->batch.push_back(new Workspace());
+        while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         const int lanes = std::max(1, std::min<int>(n, 8));
         std::vector<PackedWindow> pk(n);
         std::vector<int> need(n, 0), rcs(n, VISFS_BA_OK);
@@ -1086,7 +1097,7 @@ int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* c
     for (int i = 0; i < n; ++i) if (!graphs[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
     if (h->prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return VISFS_BA_ERR_UNSUPPORTED; }
     return guarded(h, [&]() -> int {
-        while ((int)h->batch.size() < n) h->batch.push_back(new Workspace());
+        while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         h->n_batch = 0;
         for (int i = 0; i < n; ++i) { const int rc = ws_upload(h, *h->batch[i], graphs[i]); if (rc != VISFS_BA_OK) return rc; }
         // every graph once more as one array: visfs_ba_batch_reset is then a single launch

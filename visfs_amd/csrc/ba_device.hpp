@@ -22,7 +22,7 @@ constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
 constexpr int MAX_STAGED_POSES = 640; // 12 doubles each in LDS (60 KiB)
 constexpr int MAX_PCG_FREE_POSES = 256; // persistent PCG: one workgroup per block row, all co-resident (256 CUs, >= 1 workgroup each)
-constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront
+constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront and pass (DeviceGraph::sch_chunk = 64 x passes)
 // fused single-workgroup path (k_small_optimize): limits of a "small" window
 constexpr int SM_MAX_POSES = 16;      // R|t of every pose twice in LDS
 constexpr int SM_MAX_N6 = 64;         // <= 10 free poses: the reduced camera system is solved in LDS
@@ -66,7 +66,8 @@ struct DeviceGraph {
     int32_t Np, Nl, No, Ne, Npf;
     int32_t n_chunks;       // pose-major chunks
     int32_t n_blk;          // stored S blocks (i <= j)
-    int32_t n_sch;          // Schur chunks (<= 64 co-observation pairs of one block each)
+    int32_t n_sch;          // Schur chunks (<= sch_chunk co-observation pairs of one block each)
+    int32_t sch_chunk;      // 64 x passes: pairs per chunk (a lane adds its pairs of the later passes serially)
     int32_t pcg_lds_minv;   // persistent PCG keeps all Minv blocks in LDS
     int32_t pcg_lds_srow;   // ... and its own block row of S
     int32_t pcg_max_row;    // longest block row of S (blocks)

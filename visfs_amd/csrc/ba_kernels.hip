@@ -507,10 +507,72 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
 }
 
 // ================================================================= K5: Schur complement (gather form)
-// k_schur_partial: one wavefront per chunk of <= 64 co-observation pairs of ONE block (i <= j) of the reduced
-// camera matrix, one pair per lane:  Hpl_il (Hll_l + lambda I)^-1 Hpl_jl^T  (+ the b_s term on diagonal blocks),
-// reduce-scattered over the wave into 42 partial sums.
-// One wavefront, one chunk (<= 64 co-observation pairs of one block): shared by k_schur_partial and the fused small-window kernel.
+// k_schur_partial: one wavefront per chunk of co-observation pairs of ONE block (i <= j) of the reduced camera matrix, one
+// pair per lane and pass:  Hpl_il (Hll_l + lambda I)^-1 Hpl_jl^T  (+ the b_s term on diagonal blocks), reduce-scattered over
+// the wave into 42 partial sums.
+// The contribution Wa D Wb^T of ONE pair (tile of pose i, tile of pose j, landmark), through the structure of the tiles:
+// W = [N ; [Pc]x N] (tile_core), so with P = Na D Nb^T (3x3) the 6x6 result is [P, P Xb^T ; Xa P, Xa P Xb^T] — rows of P
+// crossed with Pc_b, columns with Pc_a — and the b_s term is [v ; Pc_a x v] with v = Na (D b_l): about half the fp64 work of
+// forming both 6x3 tiles.  A lane without a pair (have = false) produces exact zeros.
+__device__ __forceinline__ void schur_pair(const DeviceGraph& g, const int4 pr, const bool have, const bool diag, const Rt& Ti, const Rt& Tj,
+                                           const double lambda, double G[36], double gb[6]) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) gb[r] = 0.0;
+    const double* H = g.Hll + 6 * (size_t)pr.z;
+    const double2* sa = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.x);
+    const double2* sb = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.y);
+    const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
+    const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
+    const Intrinsics K = intr_of(g);
+    const Vec3 pa{ a0.x, a0.y, a1.x }, pb{ b0.x, b0.y, b1.x };
+    double Na[9], Nb[9];
+    tile_core(Ti.R, pa, a1.y, K, Na);
+    tile_core(Tj.R, pb, b1.y, K, Nb);
+    double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
+    if (have) {
+        h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
+        if (diag) { const double* Bl = g.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
+    }
+    double D[6];
+    sym3_inverse(h, D);
+    // a landmark without any active edge has Hll = 0 and (Gauss-Newton, lambda = 0) a singular block: its tiles are
+    // all zero, so drop the term instead of multiplying 0 by inf
+    const bool okD = (D[0] == D[0]) && (fabs(D[0]) <= DBL_MAX) && (D[3] == D[3]) && (fabs(D[3]) <= DBL_MAX) && (D[5] == D[5]) && (fabs(D[5]) <= DBL_MAX);
+    if (!okD) { D[0] = D[1] = D[2] = D[3] = D[4] = D[5] = 0.0; }
+    double Q[9], P[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                       // Q = Na D
+        Q[3 * r + 0] = Na[3 * r] * D[0] + Na[3 * r + 1] * D[1] + Na[3 * r + 2] * D[2];
+        Q[3 * r + 1] = Na[3 * r] * D[1] + Na[3 * r + 1] * D[3] + Na[3 * r + 2] * D[4];
+        Q[3 * r + 2] = Na[3 * r] * D[2] + Na[3 * r + 1] * D[4] + Na[3 * r + 2] * D[5];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[3 * r + c] = Q[3 * r] * Nb[3 * c] + Q[3 * r + 1] * Nb[3 * c + 1] + Q[3 * r + 2] * Nb[3 * c + 2];   // P = Q Nb^T
+    // top half: [P | rows of P crossed with Pc_b]
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double p0 = P[3 * r], p1 = P[3 * r + 1], p2 = P[3 * r + 2];
+        G[6 * r + 0] = p0; G[6 * r + 1] = p1; G[6 * r + 2] = p2;
+        G[6 * r + 3] = pb.y * p2 - pb.z * p1; G[6 * r + 4] = pb.z * p0 - pb.x * p2; G[6 * r + 5] = pb.x * p1 - pb.y * p0;
+    }
+    // bottom half: Pc_a crossed with the columns of the top half
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double t0 = G[c], t1 = G[6 + c], t2 = G[12 + c];
+        G[18 + c] = pa.y * t2 - pa.z * t1; G[24 + c] = pa.z * t0 - pa.x * t2; G[30 + c] = pa.x * t1 - pa.y * t0;
+    }
+    if (diag) {
+        const double v0 = Q[0] * B[0] + Q[1] * B[1] + Q[2] * B[2], v1 = Q[3] * B[0] + Q[4] * B[1] + Q[5] * B[2], v2 = Q[6] * B[0] + Q[7] * B[1] + Q[8] * B[2];
+        gb[0] = v0; gb[1] = v1; gb[2] = v2;
+        gb[3] = pa.y * v2 - pa.z * v1; gb[4] = pa.z * v0 - pa.x * v2; gb[5] = pa.x * v1 - pa.y * v0;
+    }
+}
+
+// One wavefront, one chunk (<= 64 pairs of one block, MULTI: <= DeviceGraph::sch_chunk): shared by k_schur_partial and the
+// fused small-window kernel.
+template <bool MULTI>
 __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, const int lane, const double lambda, const double* __restrict__ pose) {
     // one descriptor load, then the pair list and the two poses can be fetched together (no dependent index chain)
     const int4 dsc = g.sch_desc[ch];
@@ -524,60 +586,20 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
     const bool have = e < e_end;
     // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
     const int4 pr = have ? g.blk_pairs[e] : make_int4(0, 0, 0, 0);
-    // The contribution Wa D Wb^T of the pair, through the structure of the tiles: W = [N ; [Pc]x N] (tile_core), so with
-    // P = Na D Nb^T (3x3) the 6x6 result is [P, P Xb^T ; Xa P, Xa P Xb^T] — rows of P crossed with Pc_b, columns with Pc_a —
-    // and the b_s term is [v ; Pc_a x v] with v = Na (D b_l): about half the fp64 work of forming both 6x3 tiles.
-    double G[36], gb[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-    {
-        const double* H = g.Hll + 6 * (size_t)pr.z;
-        const double2* sa = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.x);
-        const double2* sb = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.y);
-        const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
-        const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
-        const Intrinsics K = intr_of(g);
-        const Vec3 pa{ a0.x, a0.y, a1.x }, pb{ b0.x, b0.y, b1.x };
-        double Na[9], Nb[9];
-        tile_core(Ti.R, pa, a1.y, K, Na);
-        tile_core(Tj.R, pb, b1.y, K, Nb);
-        double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
-        if (have) {
-            h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
-            if (diag) { const double* Bl = g.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
-        }
-        double D[6];
-        sym3_inverse(h, D);
-        // a landmark without any active edge has Hll = 0 and (Gauss-Newton, lambda = 0) a singular block: its tiles are
-        // all zero, so drop the term instead of multiplying 0 by inf
-        const bool okD = (D[0] == D[0]) && (fabs(D[0]) <= DBL_MAX) && (D[3] == D[3]) && (fabs(D[3]) <= DBL_MAX) && (D[5] == D[5]) && (fabs(D[5]) <= DBL_MAX);
-        if (!okD) { D[0] = D[1] = D[2] = D[3] = D[4] = D[5] = 0.0; }
-        double Q[9], P[9];
+    double G[36], gb[6];
+    schur_pair(g, pr, have, diag, Ti, Tj, lambda, G, gb);
+    if (MULTI) {
+        // chunks of more than 64 pairs: the lane adds its later pairs (e + 64, e + 128, ...) serially, in that fixed order, so one
+        // reduce-scatter serves the whole chunk (the cross-lane reduction costs about as much VALU time as a pair product)
+        for (int e2 = e + 64; e2 - lane < e_end; e2 += 64) {
+            const bool have2 = e2 < e_end;
+            const int4 pr2 = have2 ? g.blk_pairs[e2] : make_int4(0, 0, 0, 0);
+            double G2[36], gb2[6];
+            schur_pair(g, pr2, have2, diag, Ti, Tj, lambda, G2, gb2);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {                       // Q = Na D
-            Q[3 * r + 0] = Na[3 * r] * D[0] + Na[3 * r + 1] * D[1] + Na[3 * r + 2] * D[2];
-            Q[3 * r + 1] = Na[3 * r] * D[1] + Na[3 * r + 1] * D[3] + Na[3 * r + 2] * D[4];
-            Q[3 * r + 2] = Na[3 * r] * D[2] + Na[3 * r + 1] * D[4] + Na[3 * r + 2] * D[5];
-        }
+            for (int q = 0; q < 36; ++q) G[q] += G2[q];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) P[3 * r + c] = Q[3 * r] * Nb[3 * c] + Q[3 * r + 1] * Nb[3 * c + 1] + Q[3 * r + 2] * Nb[3 * c + 2];   // P = Q Nb^T
-        // top half: [P | rows of P crossed with Pc_b]
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double p0 = P[3 * r], p1 = P[3 * r + 1], p2 = P[3 * r + 2];
-            G[6 * r + 0] = p0; G[6 * r + 1] = p1; G[6 * r + 2] = p2;
-            G[6 * r + 3] = pb.y * p2 - pb.z * p1; G[6 * r + 4] = pb.z * p0 - pb.x * p2; G[6 * r + 5] = pb.x * p1 - pb.y * p0;
-        }
-        // bottom half: Pc_a crossed with the columns of the top half
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double t0 = G[c], t1 = G[6 + c], t2 = G[12 + c];
-            G[18 + c] = pa.y * t2 - pa.z * t1; G[24 + c] = pa.z * t0 - pa.x * t2; G[30 + c] = pa.x * t1 - pa.y * t0;
-        }
-        if (diag) {
-            const double v0 = Q[0] * B[0] + Q[1] * B[1] + Q[2] * B[2], v1 = Q[3] * B[0] + Q[4] * B[1] + Q[5] * B[2], v2 = Q[6] * B[0] + Q[7] * B[1] + Q[8] * B[2];
-            gb[0] = v0; gb[1] = v1; gb[2] = v2;
-            gb[3] = pa.y * v2 - pa.z * v1; gb[4] = pa.z * v0 - pa.x * v2; gb[5] = pa.x * v1 - pa.y * v0;
+            for (int r = 0; r < 6; ++r) gb[r] += gb2[r];
         }
     }
     // two halves of 21 sums (block rows 0-2 + b_s 0-2, block rows 3-5 + b_s 3-5): halves the live accumulator registers
@@ -597,8 +619,8 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
     if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
 }
 
-template <class Src>
-__global__ __launch_bounds__(256, 4) void k_schur_partial(const Src src) {
+template <bool MULTI, class Src>
+__global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src src) {
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
@@ -612,7 +634,7 @@ __global__ __launch_bounds__(256, 4) void k_schur_partial(const Src src) {
     const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int ch = wg * 4 + (threadIdx.x >> 6);
     if (ch >= g.n_sch) return;
-    schur_chunk(g, ch, lane, st->lambda, g.pose[st->sel]);
+    schur_chunk<MULTI>(g, ch, lane, st->lambda, g.pose[st->sel]);
 }
 
 // k_schur_finalize: one wavefront per stored block:
@@ -1912,7 +1934,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
             const double lambda = st->lambda;
             SM_STAMP(3);
             // ---- one damped solve
-            for (int ch = wave; ch < g.n_sch; ch += SM_WAVES) schur_chunk(g, ch, lane, lambda, pose);
+            for (int ch = wave; ch < g.n_sch; ch += SM_WAVES) schur_chunk<false>(g, ch, lane, lambda, pose);
             __syncthreads();
             SM_STAMP(4);
             for (int b = wave; b < g.n_blk; b += SM_WAVES) schur_block(g, st, b, lane);
@@ -2025,6 +2047,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.lin_blocks = g.n_lin_a + g.n_chunks;
     d.backsub_blocks = g.n_lin_a + 1;
     d.sch_wgs = g.n_sch > 0 ? (((g.n_sch + 3) / 4) + 7) / 8 * 8 : 0;
+    d.sch_multi = g.sch_chunk > 64 ? 1 : 0;
     d.fin_wgs = (g.n_blk + 3) / 4;
     d.pcg_rows = g.Npf;
     d.pcg_lds = g.pcg_lds_bytes;
@@ -2038,7 +2061,7 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.np = std::max(a.np, b.np); d.lin_blocks = std::max(a.lin_blocks, b.lin_blocks); d.backsub_blocks = std::max(a.backsub_blocks, b.backsub_blocks);
     d.sch_wgs = std::max(a.sch_wgs, b.sch_wgs); d.fin_wgs = std::max(a.fin_wgs, b.fin_wgs); d.pcg_rows = std::max(a.pcg_rows, b.pcg_rows);
     d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
-    d.has_odo = a.has_odo | b.has_odo;
+    d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
     return d;
 }
 static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)(12 * d.np + extra) * sizeof(double); }
@@ -2068,7 +2091,9 @@ static void launch_lin_finalize_src(const Src& src, int force, int B, hipStream_
 }
 template <class Src>
 static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    if (d.sch_wgs > 0) hipLaunchKernelGGL((k_schur_partial<Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
+    if (d.sch_wgs <= 0) return;
+    if (d.sch_multi) hipLaunchKernelGGL((k_schur_partial<true, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
+    else hipLaunchKernelGGL((k_schur_partial<false, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
 }
 template <class Src>
 static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
@@ -2179,7 +2204,7 @@ void launch_gather_state(const DeviceGraph* gs, int B, int* out, hipStream_t s) 
 }
 
 bool small_path_fits(const DeviceGraph& g) {
-    return g.Np <= SM_MAX_POSES && 6 * g.Npf <= SM_MAX_N6 && g.Npf >= 1 && 4 * g.n_chunks <= SM_MAX_WCHUNKS && g.No <= SM_MAX_OBS && g.n_sch <= SM_MAX_SCH;
+    return g.Np <= SM_MAX_POSES && 6 * g.Npf <= SM_MAX_N6 && g.Npf >= 1 && 4 * g.n_chunks <= SM_MAX_WCHUNKS && g.No <= SM_MAX_OBS && g.n_sch <= SM_MAX_SCH && g.sch_chunk == SCH_CHUNK;
 }
 
 bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= SM_MAX_N6; }
