@@ -382,7 +382,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.blk_i = A.take<int32_t>(std::max(n_blk, 1));
         g.blk_j = A.take<int32_t>(std::max(n_blk, 1));
         g.blk_ptr = A.take<int32_t>(n_blk + 1);
-        g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));
         g.blk_chunk_ptr = A.take<int32_t>(n_blk + 1);
         g.sch_desc = A.take<int4>(std::max(n_sch, 1));
         g.blk_desc = A.take<int4>(2 * (size_t)std::max(n_blk, 1));
@@ -431,6 +430,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.chol_f = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
+        g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };
@@ -481,26 +481,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (!pose_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.pose_odo), pose_odo.data(), pose_odo.size() * 4);
         if (n_blk) { std::memcpy(const_cast<int32_t*>(hg.blk_i), blk_i.data(), (size_t)n_blk * 4); std::memcpy(const_cast<int32_t*>(hg.blk_j), blk_j.data(), (size_t)n_blk * 4); }
         std::memcpy(const_cast<int32_t*>(hg.blk_ptr), blk_ptr.data(), (size_t)(n_blk + 1) * 4);
-        {   // co-observation pairs, written straight into the staging arena (3.5 MB at C2: no intermediate copy)
-            int4* pairs = const_cast<int4*>(hg.blk_pairs);
-            if (npairs == 0) pairs[0] = make_int4(0, 0, 0, 0);
-            // write cursor per (a, b): one lookup per pair instead of block id + cursor
-            std::vector<int32_t> cursor((size_t)Npf * Npf, 0);
-            for (int b = 0; b < n_blk; ++b) cursor[(size_t)blk_i[b] * Npf + blk_j[b]] = blk_ptr[b];
-            for (int l = 0; l < Nl; ++l) {
-                if (gr->point_fixed[l]) continue;
-                const int k_end = lm_ptr[l + 1];
-                for (int k1 = lm_ptr[l]; k1 < k_end; ++k1) {
-                    const int a = obs_free[k1];
-                    if (a < 0) continue;
-                    int32_t* row = cursor.data() + (size_t)a * Npf;
-                    for (int k2 = k1; k2 < k_end; ++k2) {
-                        const int b = obs_free[k2];
-                        if (b >= 0) pairs[row[b]++] = make_int4(k1, k2, l, 0);
-                    }
-                }
-            }
-        }
         std::memcpy(const_cast<int32_t*>(hg.blk_chunk_ptr), blk_chunk_ptr.data(), (size_t)(n_blk + 1) * 4);
         std::memcpy(const_cast<int4*>(hg.sch_desc), sch_desc.data(), sch_desc.size() * sizeof(int4));
         std::memcpy(const_cast<int4*>(hg.blk_desc), blk_desc.data(), blk_desc.size() * sizeof(int4));
@@ -544,6 +524,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     HIP_TRY(h, hipMemcpyAsync(w.d_base, w.h_base, static_bytes, hipMemcpyHostToDevice, w.stream));
     HIP_TRY(h, hipMemsetAsync(w.d_base + static_bytes, 0, total_bytes - static_bytes, w.stream));
     if (configure_kernels(w.g) != 0) { h->err = "hipFuncSetAttribute failed"; return VISFS_BA_ERR_DEVICE; }
+    launch_build_pairs(w.g, w.stream);                     // the co-observation pair lists never exist on the host
     launch_reset(w.g, prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
     HIP_TRY(h, hipGetLastError());
     lap("enqueue");

@@ -107,7 +107,8 @@ struct DeviceGraph {
     const int32_t* blk_i;       // [n_blk] free pose index (row)
     const int32_t* blk_j;       // [n_blk] (col), j >= i
     const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
-    const int4* blk_pairs;      // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark
+    int4* blk_pairs;            // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark, in landmark order
+                                // per block; built on the device at upload (k_build_pairs) from the pose-major observation lists
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block
     const int4* sch_desc;       // [n_sch] (first pair, last pair + 1, pose index of i, pose index of j): ONE load gives a wave all it needs
     const int4* blk_desc;       // [n_blk][2]: (first Schur chunk, last + 1, first odometry entry, last + 1) — entries of blk_odo for an

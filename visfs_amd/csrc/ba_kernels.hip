@@ -506,6 +506,50 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
     if (tid == 0) lin_finalize_update(st, chi_total, md_total);
 }
 
+// ================================================================= upload: co-observation pair lists of the S blocks
+// g2o's buildStructure analogue for the gather-form Schur complement: block (i <= j) of S lists, in landmark order, the pairs
+// (observation of pose i, observation of pose j, landmark) of the free landmarks both poses observe.  One wavefront per block
+// intersects the two poses' observation lists (pose-major, hence sorted by landmark; a pose sees a landmark at most once): a
+// lane per observation of pose i, a binary search in pose j's list, a ballot prefix for the slot — no atomics, so the order
+// (and with it every later summation order) is fixed.  The host has sized blk_ptr from the same rule (counts only).
+__global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= g.n_blk) return;
+    const int i = g.blk_i[b], j = g.blk_j[b];
+    const int sA = g.chunk_ptr[g.pose_chunk_ptr[i]], eA = g.chunk_ptr[g.pose_chunk_ptr[i + 1]];
+    const int sB = g.chunk_ptr[g.pose_chunk_ptr[j]], eB = g.chunk_ptr[g.pose_chunk_ptr[j + 1]];
+    int base = g.blk_ptr[b];
+    const int end = g.blk_ptr[b + 1];
+    if (base == end) return;                              // a block that exists for its odometry edge only
+    for (int t0 = sA; t0 < eA; t0 += 64) {
+        const int t = t0 + lane;
+        bool m = false;
+        int k1 = 0, k2 = 0, l = 0;
+        if (t < eA) {
+            k1 = g.pose_obs[t];
+            l = g.obs_pt[k1];
+            if (!g.pt_fixed[l]) {
+                if (i == j) { m = true; k2 = k1; }
+                else {
+                    int lo = sB, hi = eB;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (g.obs_pt[g.pose_obs[mid]] < l) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < eB) { k2 = g.pose_obs[lo]; m = (g.obs_pt[k2] == l); }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(m);
+        if (m) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < end) g.blk_pairs[pos] = make_int4(k1, k2, l, 0);
+        }
+        base += __popcll(mask);
+    }
+}
+
 // ================================================================= K5: Schur complement (gather form)
 // k_schur_partial: one wavefront per chunk of co-observation pairs of ONE block (i <= j) of the reduced camera matrix, one
 // pair per lane and pass:  Hpl_il (Hll_l + lambda I)^-1 Hpl_jl^T  (+ the b_s term on diagonal blocks), reduce-scattered over
@@ -2122,6 +2166,9 @@ static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int
 }
 
 // ---- single window
+void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
+    if (g.n_blk > 0) hipLaunchKernelGGL(k_build_pairs, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
+}
 void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, s); }
 void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) { launch_lin_finalize_src(One{ g }, force, 1, s); }
 void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_src(One{ g }, dims_of(g), 1, s); }
