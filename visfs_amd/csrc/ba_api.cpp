@@ -48,6 +48,7 @@ struct Workspace {
     bool loaded = false;
     bool batch_member = false;                     // one of visfs_ba_solve_batch / visfs_ba_batch_upload's windows (shares its launches)
     bool fused = false;                            // the resident window runs on k_small_optimize
+    bool spec = false;                             // units end with the speculative linearisation + LM decision launch
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
@@ -408,13 +409,13 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.obs_chi2_out = A.take<double>(std::max(No, 1));
         g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);
         g.obs_chi2 = A.take<double>(std::max(No, 1));
-        g.obs_w = A.take<double>(std::max(No, 1));
-        g.obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
+        g.lin[0].obs_w = A.take<double>(std::max(No, 1));
+        g.lin[0].obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
         g.W = A.take<double>((size_t)std::max(No, 1) * 18);
-        g.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
-        g.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
-        g.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
-        g.odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
+        g.lin[0].Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
+        g.lin[0].bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.lin[0].hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
+        g.lin[0].odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
         g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.bp = A.take<double>(std::max<size_t>(n6, 1));
         g.lin_part = A.take<double>((size_t)n_parts * 2);
@@ -431,6 +432,12 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
         g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
+        g.lin[1].obs_w = A.take<double>(std::max(No, 1));
+        g.lin[1].obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
+        g.lin[1].Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
+        g.lin[1].bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.lin[1].hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
+        g.lin[1].odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };
@@ -518,6 +525,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // (DESIGN.md §4); it pays only when many small windows run side by side
     { const char* e = std::getenv("VISFS_BA_SMALL_SOLVE"); w.small_solve = small_solve_fits(dg) && !(e && e[0] == '0'); }
     { const char* e = std::getenv("VISFS_BA_FUSED"); w.fused = small_path_fits(dg) && e && e[0] == '1'; }
+    // speculative linearise: a rejected trial wastes one linearisation, an accepted one saves k_decide + a launch gap — worth it
+    // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
+    // members keep the gated form.
+    { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = e ? (e[0] == '1') : (!w.batch_member && No <= 150000); }
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
@@ -543,8 +554,10 @@ int ws_read_state(visfs_ba_handle* h, Workspace& w) {
 
 // One unit of the LM state machine (gated on the device; see ba_kernels.hip header).  `first` = first unit of a
 // phase: only there lambda has to be initialised from max|diag H| (k_lin_finalize).
+// w.spec ("speculative linearise"): only the first unit of a phase linearises up front; every unit ENDS with the launch that
+// linearises its trial state beside the LM decision (k_linearize spec = 1), so k_decide and its launch leave the critical path.
 void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
-    { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize(w.g, w.stream); }
+    if (!w.spec || first) { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize(w.g, w.stream); }
     if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE); launch_lin_finalize(w.g, 0, w.stream); }
     { ProfScope p(w, VISFS_BA_K_SCHUR); launch_schur_partial(w.g, w.stream); }
     if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT); launch_small_solve(w.g, h->prm.solver, w.stream); }
@@ -554,7 +567,8 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }
     { ProfScope p(w, VISFS_BA_K_BACKSUB); launch_backsub(w.g, w.stream); }
-    { ProfScope p(w, VISFS_BA_K_DECIDE); launch_decide(w.g, w.stream); }
+    if (w.spec) { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize_decide(w.g, w.stream); }
+    else { ProfScope p(w, VISFS_BA_K_DECIDE); launch_decide(w.g, w.stream); }
 }
 
 // optimizer.optimize(n) for the phase armed in LmState: enqueue units until the device reports `done`.
@@ -619,10 +633,10 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     if (stats) fill_stats(*w.h_state, stats);
     if (w.prof_mask) {
         const LmState& st = *w.h_state;
-        w.active[VISFS_BA_K_LINEARIZE] += st.n_active[0];
+        w.active[VISFS_BA_K_LINEARIZE] += w.spec ? st.n_active[3] + (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0) : st.n_active[0];
         w.active[VISFS_BA_K_LIN_FINALIZE] += (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0);
         w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_SCHUR_FINALIZE] += st.n_active[1];
-        w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
+        if (!w.spec) w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
         w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT] += st.n_active[1];
         w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
         w.active[VISFS_BA_K_PHASE_END] += 2; w.active[VISFS_BA_K_RESET] += 1;
@@ -1264,10 +1278,10 @@ static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size
     switch (which) {
         case VISFS_BA_BUF_OBS_ERR: src = g.obs_err; m = (size_t)g.No * 3; break;
         case VISFS_BA_BUF_OBS_CHI2: src = g.obs_chi2; m = g.No; break;
-        case VISFS_BA_BUF_OBS_WEIGHT: src = g.obs_w; m = g.No; break;
+        case VISFS_BA_BUF_OBS_WEIGHT: src = g.lin[w.h_state->lin_sel & 1].obs_w; m = g.No; break;
         case VISFS_BA_BUF_HPL: src = g.W; m = (size_t)g.No * 18; break;
-        case VISFS_BA_BUF_HLL: src = g.Hll; m = (size_t)g.Nl * 6; break;
-        case VISFS_BA_BUF_BL: src = g.bl; m = (size_t)g.Nl * 3; break;
+        case VISFS_BA_BUF_HLL: src = g.lin[w.h_state->lin_sel & 1].Hll; m = (size_t)g.Nl * 6; break;
+        case VISFS_BA_BUF_BL: src = g.lin[w.h_state->lin_sel & 1].bl; m = (size_t)g.Nl * 3; break;
         case VISFS_BA_BUF_BP: src = g.bp; m = n6; break;
         case VISFS_BA_BUF_BS: src = g.bs; m = n6; break;
         case VISFS_BA_BUF_DX_POSE: src = g.x; m = n6; break;
@@ -1312,7 +1326,7 @@ static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size
     // HPP: diagonal blocks + odometry off-diagonal blocks
     std::vector<double> diag((size_t)std::max(g.Npf, 1) * 36), odo((size_t)std::max(g.Ne, 1) * 120);
     HIP_TRY(h, hipMemcpyAsync(diag.data(), g.Hpp, (size_t)g.Npf * 36 * 8, hipMemcpyDeviceToHost, w.stream));
-    if (g.Ne) HIP_TRY(h, hipMemcpyAsync(odo.data(), g.odo_blk, (size_t)g.Ne * 120 * 8, hipMemcpyDeviceToHost, w.stream));
+    if (g.Ne) HIP_TRY(h, hipMemcpyAsync(odo.data(), g.lin[w.h_state->lin_sel & 1].odo_blk, (size_t)g.Ne * 120 * 8, hipMemcpyDeviceToHost, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));
     for (int a = 0; a < g.Npf; ++a)
         for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) dst[(size_t)(6 * a + r) * n6 + 6 * a + c] = diag[36 * (size_t)a + 6 * r + c];

@@ -60,6 +60,22 @@ struct LmState {
     int32_t pcg_max;        // most PCG iterations any solve of this call needed
     int32_t pcg_timeout;    // a persistent-PCG workgroup gave up waiting (never expected; surfaces as ERR_DEVICE)
     int32_t n_active[4];    // units that did work: 0 linearise, 1 trial, 2 (unused), 3 back-substitution
+    // speculative linearisation (k_linearize / k_odo_linearize with spec = 1 run beside the LM decision of the same launch):
+    int32_t lin_sel;        // which of DeviceGraph::lin[2] holds the linearisation at the committed estimate
+    int32_t spec_go;        // snapshot by k_backsub: this unit produced a trial state worth linearising
+    int32_t spec_src;       // ... the estimate buffer holding it (sel ^ 1 at that time)
+    int32_t spec_dst;       // ... the linearisation buffer to fill (lin_sel ^ 1 at that time)
+};
+
+// The outputs of a linearisation that the Schur complement and the back-substitution consume.  Two sets: while the LM decision
+// on a trial is taken, the trial state is already being linearised into the other set ("speculative linearise").
+struct LinBuf {
+    double* obs_w;              // [No]      rho' (0: inactive)
+    double* obs_pcw;            // [No][4]   tile seed: Pc = R Pw + t (3) and the effective weight rho' / sigma^2 (0: no Hpl tile)
+    double* Hll;                // [Nl][6]
+    double* bl;                 // [Nl][3]
+    double* hpp_part;           // [n_chunks][27] 21 upper + 6 b
+    double* odo_blk;            // [Ne + 1][120] Aii(36) Ajj(36) Aij(36) bi(6) bj(6); slot Ne: the laser edges' aggregate
 };
 
 struct DeviceGraph {
@@ -129,13 +145,8 @@ struct DeviceGraph {
     // ---- linearisation products ----
     double* obs_err;            // [No][3]   (written only when debug != 0)
     double* obs_chi2;           // [No]
-    double* obs_w;              // [No]      rho' (0: inactive)
-    double* obs_pcw;            // [No][4]   tile seed: Pc = R Pw + t (3) and the effective weight rho' / sigma^2 (0: no Hpl tile)
     double* W;                  // [No][18]  Hpl tiles, 6x3 row-major — written only for the stage hooks (debug)
-    double* Hll;                // [Nl][6]
-    double* bl;                 // [Nl][3]
-    double* hpp_part;           // [n_chunks][27] 21 upper + 6 b
-    double* odo_blk;            // [Ne][120] Aii(36) Ajj(36) Aij(36) bi(6) bj(6)
+    LinBuf lin[2];              // rho' weights, tile seeds, Hll, b_l, Hpp partials, odometry blocks: two sets (LmState::lin_sel)
     double* Hpp;                // [Npf][36]
     double* bp;                 // [Npf][6]
     int32_t* pose_pin;          // [Npf] 1: pose has no active edge (outside g2o's active set)
@@ -160,5 +171,20 @@ struct DeviceGraph {
     int32_t stamp_wg;
     int32_t debug;
 };
+
+// Linearisation set k of a graph: explicit selects, no dynamic indexing into the kernel-argument struct.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline LinBuf lin_of(const DeviceGraph& g, const int k) {
+    LinBuf L;
+    L.obs_w = k ? g.lin[1].obs_w : g.lin[0].obs_w;
+    L.obs_pcw = k ? g.lin[1].obs_pcw : g.lin[0].obs_pcw;
+    L.Hll = k ? g.lin[1].Hll : g.lin[0].Hll;
+    L.bl = k ? g.lin[1].bl : g.lin[0].bl;
+    L.hpp_part = k ? g.lin[1].hpp_part : g.lin[0].hpp_part;
+    L.odo_blk = k ? g.lin[1].odo_blk : g.lin[0].odo_blk;
+    return L;
+}
 
 }  // namespace visfs_ba

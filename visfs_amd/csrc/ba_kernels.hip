@@ -183,30 +183,30 @@ __device__ __forceinline__ int upper_idx(int r, int c) { return r * 6 - (r * (r 
 
 // Entry q (< 36: Hpp(r,c); 36..41: b_p) of a free pose: fixed-order sum of its pose-major chunk partials [c0, c1)
 // and of the odometry edges incident to it (entries [o0, o1) of pose_odo).
-__device__ __forceinline__ double hpp_entry_r(const DeviceGraph& g, int q, int c0, int c1, int o0, int o1) {
+__device__ __forceinline__ double hpp_entry_r(const DeviceGraph& g, const LinBuf& L, int q, int c0, int c1, int o0, int o1) {
     double v = 0.0;
     if (q < 36) {
         const int r = q / 6, c = q % 6;
         const int u = r <= c ? upper_idx(r, c) : upper_idx(c, r);
 #pragma unroll 4
-        for (int ch = c0; ch < c1; ++ch) v += g.hpp_part[27 * (size_t)ch + u];
+        for (int ch = c0; ch < c1; ++ch) v += L.hpp_part[27 * (size_t)ch + u];
         for (int n = o0; n < o1; ++n) {
             const int code = g.pose_odo[n];
-            v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 36 : 0) + q];
+            v += L.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 36 : 0) + q];
         }
     } else {
         const int r = q - 36;
 #pragma unroll 4
-        for (int ch = c0; ch < c1; ++ch) v += g.hpp_part[27 * (size_t)ch + 21 + r];
+        for (int ch = c0; ch < c1; ++ch) v += L.hpp_part[27 * (size_t)ch + 21 + r];
         for (int n = o0; n < o1; ++n) {
             const int code = g.pose_odo[n];
-            v += g.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 114 : 108) + r];
+            v += L.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 114 : 108) + r];
         }
     }
     return v;
 }
-__device__ __forceinline__ double hpp_entry(const DeviceGraph& g, int a, int q) {
-    return hpp_entry_r(g, q, g.pose_chunk_ptr[a], g.pose_chunk_ptr[a + 1], g.pose_odo_ptr[a], g.pose_odo_ptr[a + 1]);
+__device__ __forceinline__ double hpp_entry(const DeviceGraph& g, const LinBuf& L, int a, int q) {
+    return hpp_entry_r(g, L, q, g.pose_chunk_ptr[a], g.pose_chunk_ptr[a + 1], g.pose_odo_ptr[a], g.pose_odo_ptr[a + 1]);
 }
 
 // Role B, one observation of a free pose: upper triangle of Jx^T (rho' Omega) Jx and -Jx^T (rho' Omega) e into acc[27]
@@ -238,7 +238,7 @@ __device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k
 // Role A for one landmark handled by G lanes (sub = lane within the group): weights, chi2, tile seeds, Hll, b_l.
 // Shared by k_linearize<G> and the fused small-window kernel (G = 1: one thread per landmark).
 template <int G>
-__device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const int l, const bool lvalid, const int sub, const double* sRt,
+__device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const double* sRt,
                                              const double* __restrict__ pt, const Intrinsics& K, const double iv, const double delta,
                                              double& chi_acc, double& md) {
     int k0 = 0, k1 = 0;
@@ -262,7 +262,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const int l, 
         const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
         double rho0 = c2, rho1 = 1.0;
         if (delta > 0.0) huber(c2, delta, rho0, rho1);
-        g.obs_w[k] = active ? rho1 : 0.0;
+        L.obs_w[k] = active ? rho1 : 0.0;
         g.obs_chi2[k] = active ? c2 : 0.0;
         if (g.debug) { g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
         const bool pfree = g.pose_free[ip] >= 0;
@@ -286,7 +286,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const int l, 
             if (pfree && lfree) wo_tile = wo;
         }
         // the 32-byte tile seed (Hpl is rebuilt from it where it is consumed)
-        double2* seed = reinterpret_cast<double2*>(g.obs_pcw + 4 * (size_t)k);
+        double2* seed = reinterpret_cast<double2*>(L.obs_pcw + 4 * (size_t)k);
         seed[0] = make_double2(pc.x, pc.y);
         seed[1] = make_double2(pc.z, wo_tile);
         if (g.debug) {
@@ -307,26 +307,117 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const int l, 
             const int idx = off + j;
             if (j < len) {
                 if (idx < 6) {
-                    g.Hll[6 * (size_t)l + idx] = hb[j];
+                    L.Hll[6 * (size_t)l + idx] = hb[j];
                     if (lfree && (idx == 0 || idx == 3 || idx == 5)) md = fmax(md, fabs(hb[j]));
                 } else {
-                    g.bl[3 * (size_t)l + (idx - 6)] = hb[j];
+                    L.bl[3 * (size_t)l + (idx - 6)] = hb[j];
                 }
             }
         }
     }
 }
 
+// ================================================================= K9: Levenberg-Marquardt control
+// [g2o-upstream] OptimizationAlgorithmLevenberg::solve, second half; one workgroup.  Sets the gate of the next unit.
+// The scalar half of [g2o-upstream] OptimizationAlgorithmLevenberg::solve (and the Gauss-Newton variant): one thread.
+// ok = the linear solve succeeded; chi / sc = robust chi2 at the trial state and computeScale's sum.
+// spec: the accepted trial's linearisation is already in the other buffer set (speculative linearise): flip lin_sel with sel.
+__device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc, const bool spec) {
+    const int ph = st->phase;
+    st->trials_run[ph] += 1;
+    st->solver_failed = 0;
+    if (ok) st->n_active[3] += 1;
+    if (st->pcg_timeout) { st->status = 8; st->done = 1; st->mode = 0; return; }     // VISFS_BA_ERR_DEVICE
+    if (st->gauss_newton) {
+        // OptimizationAlgorithmGaussNewton: always take the step; Fail ends the phase
+        if (ok) { st->sel ^= 1; if (spec) st->lin_sel ^= 1; }
+        if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = 0.0; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
+        if (ok) st->current_chi = chi;
+        st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
+        if (!ok || st->phase_iter >= st->max_iter) { st->done = 1; st->mode = 0; } else st->mode = MODE_LIN | MODE_TRIAL;
+        return;
+    }
+    const double tempChi = ok ? chi : DBL_MAX;
+    const double scale = (ok ? sc : 0.0) + 1e-3;
+    const double rho = (st->current_chi - tempChi) / scale;
+    st->temp_chi = tempChi; st->scale = scale; st->rho = rho;
+    bool iteration_over = false, terminate = false;
+    if (rho > 0.0 && tempChi <= DBL_MAX && tempChi == tempChi) {
+        double alpha = 1.0 - pow(2.0 * rho - 1.0, 3.0);
+        alpha = fmin(alpha, 2.0 / 3.0);
+        const double scaleFactor = fmax(1.0 / 3.0, alpha);
+        st->lambda = lambda * scaleFactor;
+        st->ni = 2.0;
+        st->current_chi = tempChi;
+        st->sel ^= 1;                               // discardTop: the trial becomes the estimate
+        if (spec) st->lin_sel ^= 1;
+        st->trial_q += 1;
+        iteration_over = true;
+    } else {
+        const double nl = lambda * st->ni;
+        st->lambda = nl;
+        st->ni *= 2.0;                              // pop: estimate unchanged
+        if (!(fabs(nl) <= DBL_MAX)) iteration_over = true;            // !isfinite(lambda): break before qmax++
+        else {
+            st->trial_q += 1;
+            if (!(rho < 0.0) || st->trial_q >= 10) iteration_over = true;   // loop runs while rho < 0 && qmax < 10
+        }
+    }
+    if (iteration_over) {
+        if (st->trial_q == 10 || rho == 0.0) terminate = true;
+        if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = st->lambda; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
+        st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
+        st->trial_q = 0;
+        if (terminate || st->phase_iter >= st->max_iter) { st->done = 1; st->mode = 0; }
+        else st->mode = MODE_LIN | MODE_TRIAL;      // next unit linearises at the (possibly unchanged) estimate
+    } else {
+        st->mode = MODE_TRIAL;                      // same linearisation, larger lambda
+    }
+}
+
+__device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc, false); }
+
+// The k_decide role: 256 threads sum the trial's chi2 / computeScale partials, thread 0 steps the LM state machine.
+__device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, double* red, const bool spec) {
+    if (!(st->mode & MODE_TRIAL)) return;
+    const int tid = threadIdx.x;
+    const bool ok = !st->solver_failed && !st->pcg_timeout;
+    const double lambda = st->lambda;
+    double chi = 0.0, sc = 0.0;
+    if (ok) {
+        for (int w = tid; w < g.n_lin_a + 1; w += 256) { chi += g.trial_part[2 * w]; sc += g.trial_part[2 * w + 1]; }
+        for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
+    }
+    chi = block_sum_256(chi, red);
+    sc = block_sum_256(sc, red);
+    if (tid != 0) return;
+    lm_decide(st, ok, lambda, chi, sc, spec);
+}
+
 // ================================================================= K1/K2/K4: linearise the stereo edges
+// spec = 0: linearise the committed estimate (first unit of a phase, stage hooks, large windows) when the gate says so.
+// spec = 1 ("speculative linearise", the last launch of a unit): the trial state that k_backsub has just completed is
+// linearised into the OTHER buffer set while one extra workgroup takes the LM decision on that trial (the k_decide role): an
+// accepted trial — the common case — finds its linearisation ready and only flips LmState::lin_sel; a rejected one leaves the
+// current set untouched.  The linearising workgroups read the snapshot k_backsub left (spec_go / spec_src / spec_dst), never a
+// field the decision writes, so the launch has no intra-kernel race.
 template <int G, class Src>
-__global__ __launch_bounds__(256) void k_linearize(const Src src) {
+__global__ __launch_bounds__(256) void k_linearize(const Src src, const int spec) {
     const DeviceGraph& g = graph_of(src);
-    const LmState* st = g.st;
-    if (!(st->mode & MODE_LIN)) return;
+    LmState* st = g.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;                       // [Np][12]
     double* red = smem + 12 * g.Np;           // [4 * 27]
-    const int sel = st->sel;
+    int sel, ls;
+    if (spec) {
+        if ((int)blockIdx.x == g.n_lin_a + g.n_chunks) { decide_role(g, st, red, true); return; }
+        if (!st->spec_go) return;
+        sel = st->spec_src; ls = st->spec_dst;
+    } else {
+        if (!(st->mode & MODE_LIN)) return;
+        sel = st->sel; ls = st->lin_sel;
+    }
+    const LinBuf L = lin_of(g, ls);
     const double* __restrict__ pose = g.pose[sel];
     const double* __restrict__ pt = g.pt[sel];
     stage_poses(pose, g.Np, sRt);
@@ -341,7 +432,7 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
         const int l = bid * LPW + tid / G, sub = tid % G;
         const bool lvalid = l < g.Nl;
         double chi_acc = 0.0, md = 0.0;
-        lin_landmark<G>(g, l, lvalid, sub, sRt, pt, K, iv, delta, chi_acc, md);
+        lin_landmark<G>(g, L, l, lvalid, sub, sRt, pt, K, iv, delta, chi_acc, md);
         const double chi_tot = block_sum_256(chi_acc, red);
         const double md_tot = block_max_256(md, red);
         if (tid == 0) { g.lin_part[2 * bid] = chi_tot; g.lin_part[2 * bid + 1] = md_tot; }
@@ -360,16 +451,16 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
         ReduceScatter<27, 32>::run(acc, lane, off, len);
         if (len >= 1) red[wave * 27 + off] = acc[0];
         __syncthreads();
-        if (tid < 27) g.hpp_part[27 * (size_t)c + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
+        if (tid < 27) L.hpp_part[27 * (size_t)c + tid] = red[tid] + red[27 + tid] + red[54 + tid] + red[81 + tid];
     }
 }
 
 // One wheel-odometry edge: its five 6x6 / 6x1 contributions into odo_blk[e_] (120 doubles); returns its chi2
 // (0 and zero blocks when both poses are fixed: allVerticesFixed).  Shared with the fused small-window kernel.
-__device__ __forceinline__ double odo_edge_blocks(const DeviceGraph& g, const int e_, const double* __restrict__ pose, const double ic) {
+__device__ __forceinline__ double odo_edge_blocks(const DeviceGraph& g, const LinBuf& L, const int e_, const double* __restrict__ pose, const double ic) {
     const int i = g.odo_i[e_], j = g.odo_j[e_];
     const bool fi = g.pose_free[i] >= 0, fj = g.pose_free[j] >= 0;
-    double* o = g.odo_blk + 120 * (size_t)e_;
+    double* o = L.odo_blk + 120 * (size_t)e_;
     if (!fi && !fj) { for (int q = 0; q < 120; ++q) o[q] = 0.0; return 0.0; }
     double e[6], Ji[36], Jj[36];
     odo_linearize(pose + POSE_STRIDE * i, pose + POSE_STRIDE * j, g.odo_tq + 7 * e_, e, Ji, Jj);
@@ -412,8 +503,8 @@ __device__ __forceinline__ double laser_point_terms(const DeviceGraph& g, const 
     return e * (il * e);
 }
 // Entry t (< 27) of the reduced laser sums into the pseudo-edge slot Ne of odo_blk (full symmetric 6x6 + b).
-__device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const int t, const double v) {
-    double* o = g.odo_blk + 120 * (size_t)g.Ne;
+__device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const LinBuf& L, const int t, const double v) {
+    double* o = L.odo_blk + 120 * (size_t)g.Ne;
     if (t < 21) {
         int r = 0, base = 0;
         while (t >= base + (6 - r)) { base += 6 - r; ++r; }
@@ -425,17 +516,20 @@ __device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const int
 // ================================================================= K3: wheel-odometry edges
 // EdgePoseConstraint, Omega = I6 / odometryCovariance (Optimizer.cpp:117-121), no robust kernel.  One workgroup.
 template <class Src>
-__global__ __launch_bounds__(256) void k_odo_linearize(const Src src) {
+__global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec) {
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
-    if (!(st->mode & MODE_LIN)) return;
+    int sel, ls;
+    if (spec) { if (!st->spec_go) return; sel = st->spec_src; ls = st->spec_dst; }
+    else { if (!(st->mode & MODE_LIN)) return; sel = st->sel; ls = st->lin_sel; }
+    const LinBuf L = lin_of(g, ls);
     __shared__ double red[4];
-    const double* __restrict__ pose = g.pose[st->sel];
+    const double* __restrict__ pose = g.pose[sel];
     const double ic = g.inv_odo_cov;
     const int tid = threadIdx.x;
     double chi_acc = 0.0;
     for (int e_ = tid; e_ < g.Ne; e_ += 256) {
-        chi_acc += odo_edge_blocks(g, e_, pose, ic);
+        chi_acc += odo_edge_blocks(g, L, e_, pose, ic);
     }
     // laser occupied-space edges (EdgeOccupiedObservation, Omega = 1 / laserCovariance, Optimizer.cpp:232-249, no kernel):
     // all on one pose, so the workgroup reduces J^T Omega J (upper triangle) and -J^T Omega e into slot Ne of odo_blk.
@@ -455,7 +549,7 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const Src src) {
         if (len >= 1) redz[wave * 27 + off] = acc[0];
         __syncthreads();
         if (tid < 27) {
-            laser_store_slot(g, tid, redz[tid] + redz[27 + tid] + redz[54 + tid] + redz[81 + tid]);
+            laser_store_slot(g, L, tid, redz[tid] + redz[27 + tid] + redz[54 + tid] + redz[81 + tid]);
         }
     }
     const double chi_tot = block_sum_256(chi_acc, red);
@@ -482,12 +576,13 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
     LmState* st = g.st;
     if (!(st->mode & MODE_LIN)) return;
     if (!force && st->phase_iter != 0) return;
+    const LinBuf L = lin_of(g, st->lin_sel);
     __shared__ double red[1024];
     const int tid = threadIdx.x;
     double md = 0.0;
     for (int t = tid; t < g.Npf * 42; t += 1024) {
         const int a = t / 42, q = t % 42;
-        const double v = hpp_entry(g, a, q);
+        const double v = hpp_entry(g, L, a, q);
         if (q < 36) { g.Hpp[36 * (size_t)a + q] = v; if (q % 7 == 0) md = fmax(md, fabs(v)); }
         else g.bp[6 * (size_t)a + (q - 36)] = v;
     }
@@ -558,13 +653,13 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
 // W = [N ; [Pc]x N] (tile_core), so with P = Na D Nb^T (3x3) the 6x6 result is [P, P Xb^T ; Xa P, Xa P Xb^T] — rows of P
 // crossed with Pc_b, columns with Pc_a — and the b_s term is [v ; Pc_a x v] with v = Na (D b_l): about half the fp64 work of
 // forming both 6x3 tiles.  A lane without a pair (have = false) produces exact zeros.
-__device__ __forceinline__ void schur_pair(const DeviceGraph& g, const int4 pr, const bool have, const bool diag, const Rt& Ti, const Rt& Tj,
+__device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L, const int4 pr, const bool have, const bool diag, const Rt& Ti, const Rt& Tj,
                                            const double lambda, double G[36], double gb[6]) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) gb[r] = 0.0;
-    const double* H = g.Hll + 6 * (size_t)pr.z;
-    const double2* sa = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.x);
-    const double2* sb = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)pr.y);
+    const double* H = L.Hll + 6 * (size_t)pr.z;
+    const double2* sa = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.x);
+    const double2* sb = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.y);
     const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
     const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
     const Intrinsics K = intr_of(g);
@@ -575,7 +670,7 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const int4 pr, 
     double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
     if (have) {
         h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
-        if (diag) { const double* Bl = g.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
+        if (diag) { const double* Bl = L.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
     }
     double D[6];
     sym3_inverse(h, D);
@@ -617,7 +712,7 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const int4 pr, 
 // One wavefront, one chunk (<= 64 pairs of one block, MULTI: <= DeviceGraph::sch_chunk): shared by k_schur_partial and the
 // fused small-window kernel.
 template <bool MULTI>
-__device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, const int lane, const double lambda, const double* __restrict__ pose) {
+__device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& L, const int ch, const int lane, const double lambda, const double* __restrict__ pose) {
     // one descriptor load, then the pair list and the two poses can be fetched together (no dependent index chain)
     const int4 dsc = g.sch_desc[ch];
     const int e = dsc.x + lane, e_end = dsc.y;
@@ -631,7 +726,7 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
     // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
     const int4 pr = have ? g.blk_pairs[e] : make_int4(0, 0, 0, 0);
     double G[36], gb[6];
-    schur_pair(g, pr, have, diag, Ti, Tj, lambda, G, gb);
+    schur_pair(g, L, pr, have, diag, Ti, Tj, lambda, G, gb);
     if (MULTI) {
         // chunks of more than 64 pairs: the lane adds its later pairs (e + 64, e + 128, ...) serially, in that fixed order, so one
         // reduce-scatter serves the whole chunk (the cross-lane reduction costs about as much VALU time as a pair product)
@@ -639,7 +734,7 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const int ch, 
             const bool have2 = e2 < e_end;
             const int4 pr2 = have2 ? g.blk_pairs[e2] : make_int4(0, 0, 0, 0);
             double G2[36], gb2[6];
-            schur_pair(g, pr2, have2, diag, Ti, Tj, lambda, G2, gb2);
+            schur_pair(g, L, pr2, have2, diag, Ti, Tj, lambda, G2, gb2);
 #pragma unroll
             for (int q = 0; q < 36; ++q) G[q] += G2[q];
 #pragma unroll
@@ -668,6 +763,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
+    const LinBuf L = lin_of(g, st->lin_sel);
     const int lane = threadIdx.x & 63;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
     // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
@@ -678,7 +774,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int ch = wg * 4 + (threadIdx.x >> 6);
     if (ch >= g.n_sch) return;
-    schur_chunk<MULTI>(g, ch, lane, st->lambda, g.pose[st->sel]);
+    schur_chunk<MULTI>(g, L, ch, lane, st->lambda, g.pose[st->sel]);
 }
 
 // k_schur_finalize: one wavefront per stored block:
@@ -687,7 +783,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
 // Poses without any active edge are outside g2o's active set: their block is pinned to I (dx = 0).
 // It also clears the hand-off words of the persistent PCG that follows (one zeroing per damped solve).
 // One wavefront, one stored block of S: shared by k_schur_finalize and the fused small-window kernel.
-__device__ __forceinline__ void schur_block(const DeviceGraph& g, LmState* st, const int b, const int lane) {
+__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
     {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
         const int nwords = 4 * 6 * g.Npf;
         for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
@@ -708,13 +804,13 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, LmState* st, c
             double base = 0.0;
             for (int n = bd.z; n < bd.w; ++n) {
                 const int code = g.blk_odo[n];
-                base += g.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
+                base += L.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
             }
             g.S[36 * (size_t)b + lane] = base - part;
         }
         return;
     }
-    const double hv = (lane < 42) ? hpp_entry_r(g, lane, be.z, be.w, bd.z, bd.w) : 0.0;
+    const double hv = (lane < 42) ? hpp_entry_r(g, L, lane, be.z, be.w, bd.z, bd.w) : 0.0;
     const bool on_diag = lane < 36 && r == c;
     const unsigned long long nz = __ballot(on_diag && hv != 0.0);
     const bool pin = (nz == 0ull);
@@ -754,10 +850,11 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
+    const LinBuf L = lin_of(g, st->lin_sel);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= g.n_blk) return;
-    schur_block(g, st, b, lane);
+    schur_block(g, L, st, b, lane);
 }
 
 // ================================================================= K6: block-Jacobi PCG on S, persistent
@@ -1301,7 +1398,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
 // K7 + trial chi2 for one landmark handled by G lanes: dl = (Hll + lambda I)^-1 (b_l - sum_i Hpl_il^T x_i), the trial point,
 // and the robust chi2 of its edges at the trial state.  sRt = trial poses, sRt0 = poses of the linearisation point.
 template <int G>
-__device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int l, const bool lvalid, const int sub, const double* sRt, const double* sRt0,
+__device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const double* sRt, const double* sRt0,
                                                  const double* __restrict__ pt, double* __restrict__ pt_t, const double lambda, const Intrinsics& K,
                                                  const double iv, const double delta, double& chi_acc, double& scale_acc) {
     int k0 = 0, k1 = 0;
@@ -1315,13 +1412,13 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int
     // c_l = b_l - sum_i Hpl_il^T x_i
     double t0 = 0, t1 = 0, t2 = 0, any = 0.0;
     for (int k = k0 + sub; k < k1; k += G) {
-        const double w = g.obs_w[k];
+        const double w = L.obs_w[k];
         if (w == 0.0) continue;
         any = 1.0;
         const int ipk = g.obs_pose[k];
         const int a = g.pose_free[ipk];
         if (a < 0 || !lfree) continue;
-        const double2* seed = reinterpret_cast<const double2*>(g.obs_pcw + 4 * (size_t)k);
+        const double2* seed = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)k);
         const double2 s0 = seed[0], s1 = seed[1];
         // Hpl^T x through the tile structure W = [N ; [Pc]x N]:  W^T x = N^T (x_t - Pc x x_r)
         const Vec3 pcs{ s0.x, s0.y, s1.x };
@@ -1339,8 +1436,8 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int
     any = group_max<G>(any);
     double d0 = 0, d1 = 0, d2 = 0;
     if (lvalid && lfree && any != 0.0) {
-        const double* H = g.Hll + 6 * (size_t)l;
-        const double* B = g.bl + 3 * (size_t)l;
+        const double* H = L.Hll + 6 * (size_t)l;
+        const double* B = L.bl + 3 * (size_t)l;
         const double h[6] = { H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda };
         double D[6];
         sym3_inverse(h, D);
@@ -1357,7 +1454,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int
     }
     // computeActiveErrors + activeRobustChi2 at the trial state
     for (int k = k0 + sub; k < k1; k += G) {
-        if (g.obs_w[k] == 0.0) continue;
+        if (L.obs_w[k] == 0.0) continue;
         const Rt T = load_Rt(sRt, g.obs_pose[k]);
         Vec3 pc;
         const Vec3 e = stereo_error(T, pn, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
@@ -1372,8 +1469,12 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const int
 template <int G, class Src>
 __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    const LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL) || st->solver_failed || st->pcg_timeout) return;
+    LmState* st = g.st;
+    const bool go = (st->mode & MODE_TRIAL) && !st->solver_failed && !st->pcg_timeout;
+    // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
+    if (!go) return;
+    const LinBuf L = lin_of(g, st->lin_sel);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;
     double* red = smem + 12 * g.Np;
@@ -1414,88 +1515,18 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
     double chi_acc = 0.0, scale_acc = 0.0;
-    backsub_landmark<G>(g, l, lvalid, sub, sRt, sRt0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
+    backsub_landmark<G>(g, L, l, lvalid, sub, sRt, sRt0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
     if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; }
 }
 
-// ================================================================= K9: Levenberg-Marquardt control
-// [g2o-upstream] OptimizationAlgorithmLevenberg::solve, second half; one workgroup.  Sets the gate of the next unit.
-// The scalar half of [g2o-upstream] OptimizationAlgorithmLevenberg::solve (and the Gauss-Newton variant): one thread.
-// ok = the linear solve succeeded; chi / sc = robust chi2 at the trial state and computeScale's sum.
-__device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc) {
-    const int ph = st->phase;
-    st->trials_run[ph] += 1;
-    st->solver_failed = 0;
-    if (ok) st->n_active[3] += 1;
-    if (st->pcg_timeout) { st->status = 8; st->done = 1; st->mode = 0; return; }     // VISFS_BA_ERR_DEVICE
-    if (st->gauss_newton) {
-        // OptimizationAlgorithmGaussNewton: always take the step; Fail ends the phase
-        if (ok) st->sel ^= 1;
-        if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = 0.0; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
-        if (ok) st->current_chi = chi;
-        st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
-        if (!ok || st->phase_iter >= st->max_iter) { st->done = 1; st->mode = 0; } else st->mode = MODE_LIN | MODE_TRIAL;
-        return;
-    }
-    const double tempChi = ok ? chi : DBL_MAX;
-    const double scale = (ok ? sc : 0.0) + 1e-3;
-    const double rho = (st->current_chi - tempChi) / scale;
-    st->temp_chi = tempChi; st->scale = scale; st->rho = rho;
-    bool iteration_over = false, terminate = false;
-    if (rho > 0.0 && tempChi <= DBL_MAX && tempChi == tempChi) {
-        double alpha = 1.0 - pow(2.0 * rho - 1.0, 3.0);
-        alpha = fmin(alpha, 2.0 / 3.0);
-        const double scaleFactor = fmax(1.0 / 3.0, alpha);
-        st->lambda = lambda * scaleFactor;
-        st->ni = 2.0;
-        st->current_chi = tempChi;
-        st->sel ^= 1;                               // discardTop: the trial becomes the estimate
-        st->trial_q += 1;
-        iteration_over = true;
-    } else {
-        const double nl = lambda * st->ni;
-        st->lambda = nl;
-        st->ni *= 2.0;                              // pop: estimate unchanged
-        if (!(fabs(nl) <= DBL_MAX)) iteration_over = true;            // !isfinite(lambda): break before qmax++
-        else {
-            st->trial_q += 1;
-            if (!(rho < 0.0) || st->trial_q >= 10) iteration_over = true;   // loop runs while rho < 0 && qmax < 10
-        }
-    }
-    if (iteration_over) {
-        if (st->trial_q == 10 || rho == 0.0) terminate = true;
-        if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = st->lambda; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
-        st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
-        st->trial_q = 0;
-        if (terminate || st->phase_iter >= st->max_iter) { st->done = 1; st->mode = 0; }
-        else st->mode = MODE_LIN | MODE_TRIAL;      // next unit linearises at the (possibly unchanged) estimate
-    } else {
-        st->mode = MODE_TRIAL;                      // same linearisation, larger lambda
-    }
-}
-
-__device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc); }
-
+// ================================================================= K9: Levenberg-Marquardt control (lm_decide / decide_role: above k_linearize)
 template <class Src>
 __global__ __launch_bounds__(256) void k_decide(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
     __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const bool ok = !st->solver_failed && !st->pcg_timeout;
-    const double lambda = st->lambda;
-    double chi = 0.0, sc = 0.0;
-    if (ok) {
-        for (int w = tid; w < g.n_lin_a + 1; w += 256) { chi += g.trial_part[2 * w]; sc += g.trial_part[2 * w + 1]; }
-        for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
-    }
-    chi = block_sum_256(chi, red);
-    sc = block_sum_256(sc, red);
-    if (tid != 0) return;
-    lm_decide(st, ok, lambda, chi, sc);
+    decide_role(g, g.st, red, false);
 }
 
 // ================================================================= K10: per-edge chi2, outlier marking
@@ -1612,6 +1643,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
         if (restore) st->sel = 0;
         st->pcg_max = 0; st->pcg_timeout = 0;
+        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1;
         st->n_active[0] = st->n_active[1] = st->n_active[2] = st->n_active[3] = 0;
         st->phase = 0; st->max_iter = max_iter; st->phase_iter = 0; st->trial_q = 0;
         st->done = (max_iter <= 0) ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->solver_failed = 0;
@@ -1834,6 +1866,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
+    const LinBuf L = lin_of(g, st->lin_sel);
     __shared__ double sA[SM_MAX_N6 * SM_LD];
     __shared__ double sb[SM_MAX_N6], sx[SM_MAX_N6], sd[SM_MAX_N6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1844,7 +1877,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
 #endif
     const int n6 = 6 * g.Npf;
     SS_STAMP(0);
-    for (int b = wave; b < g.n_blk; b += 8) schur_block(g, st, b, lane);
+    for (int b = wave; b < g.n_blk; b += 8) schur_block(g, L, st, b, lane);
     SS_STAMP(1);
     for (int t = tid; t < n6 * SM_LD; t += 512) sA[t] = 0.0;
     __syncthreads();
@@ -1890,6 +1923,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
 template <class Src>
 __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const int solver, const int half) {
     const DeviceGraph& g = graph_of(src);
+    const LinBuf L = lin_of(g, 0);            // one workgroup, stages in order: no second linearisation set needed
     LmState* st = g.st;
     __shared__ double sRt[SM_MAX_POSES * 12];              // R|t of the estimate
     __shared__ double sRtT[SM_MAX_POSES * 12];             // ... of the trial state
@@ -1919,7 +1953,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                 stage_poses(pose, g.Np, sRt);
                 __syncthreads();
                 double chi_acc = 0.0, md = 0.0;
-                for (int l = tid; l < g.Nl; l += SM_T) lin_landmark<1>(g, l, true, 0, sRt, pt, K, iv, delta, chi_acc, md);
+                for (int l = tid; l < g.Nl; l += SM_T) lin_landmark<1>(g, L, l, true, 0, sRt, pt, K, iv, delta, chi_acc, md);
                 SM_STAMP(1);
                 // pose-major pass: one wave per 64 observations of a LIN_CHUNK; the four partials of a chunk are added in
                 // role B's order, so hpp_part comes out bit-identical to k_linearize's
@@ -1934,13 +1968,13 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                     ReduceScatter<27, 32>::run(acc, lane, off, len);
                     if (len >= 1) sPart[wc * 27 + off] = acc[0];
                 }
-                for (int e_ = tid; e_ < g.Ne; e_ += SM_T) chi_acc += odo_edge_blocks(g, e_, pose, ic);
+                for (int e_ = tid; e_ < g.Ne; e_ += SM_T) chi_acc += odo_edge_blocks(g, L, e_, pose, ic);
                 __syncthreads();
                 SM_STAMP(2);
                 for (int t = tid; t < 27 * g.n_chunks; t += SM_T) {
                     const int c = t / 27, q = t - 27 * c;
                     const double* pp = sPart + (4 * c) * 27 + q;
-                    g.hpp_part[t] = ((pp[0] + pp[27]) + pp[54]) + pp[81];
+                    L.hpp_part[t] = ((pp[0] + pp[27]) + pp[54]) + pp[81];
                 }
                 if (g.Nz > 0) {                            // laser edges: all on one pose, reduced into the pseudo-edge slot
                     __syncthreads();                       // sPart is reused
@@ -1957,14 +1991,14 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                         double v = 0.0;
 #pragma unroll
                         for (int w = 0; w < SM_WAVES; ++w) v += sPart[w * 27 + tid];
-                        laser_store_slot(g, tid, v);
+                        laser_store_slot(g, L, tid, v);
                     }
                 }
                 __syncthreads();
                 if (first) {                               // computeLambdaInit needs max|diag H| and the chi2 of the linearisation
                     for (int t = tid; t < g.Npf * 42; t += SM_T) {
                         const int a = t / 42, q = t % 42;
-                        const double v = hpp_entry(g, a, q);
+                        const double v = hpp_entry(g, L, a, q);
                         if (q < 36) { g.Hpp[36 * (size_t)a + q] = v; if (q % 7 == 0) md = fmax(md, fabs(v)); }
                         else g.bp[6 * (size_t)a + (q - 36)] = v;
                     }
@@ -1978,10 +2012,10 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
             const double lambda = st->lambda;
             SM_STAMP(3);
             // ---- one damped solve
-            for (int ch = wave; ch < g.n_sch; ch += SM_WAVES) schur_chunk<false>(g, ch, lane, lambda, pose);
+            for (int ch = wave; ch < g.n_sch; ch += SM_WAVES) schur_chunk<false>(g, L, ch, lane, lambda, pose);
             __syncthreads();
             SM_STAMP(4);
-            for (int b = wave; b < g.n_blk; b += SM_WAVES) schur_block(g, st, b, lane);
+            for (int b = wave; b < g.n_blk; b += SM_WAVES) schur_block(g, L, st, b, lane);
             for (int t = tid; t < n6 * SM_LD; t += SM_T) sA[t] = 0.0;
             __syncthreads();
             SM_STAMP(5);
@@ -2015,7 +2049,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                 stage_poses(pose_t, g.Np, sRtT);
                 __syncthreads();
                 SM_STAMP(8);
-                for (int l = tid; l < g.Nl; l += SM_T) backsub_landmark<1>(g, l, true, 0, sRtT, sRt, pt, pt_t, lambda, K, iv, delta, chi_t, sc);
+                for (int l = tid; l < g.Nl; l += SM_T) backsub_landmark<1>(g, L, l, true, 0, sRtT, sRt, pt, pt_t, lambda, K, iv, delta, chi_t, sc);
                 SM_STAMP(9);
                 for (int e_ = tid; e_ < g.Ne; e_ += SM_T) {
                     const int i = g.odo_i[e_], j = g.odo_j[e_];
@@ -2111,23 +2145,23 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
 static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)(12 * d.np + extra) * sizeof(double); }
 
 template <int G, class Src>
-static void launch_lin_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    hipLaunchKernelGGL((k_linearize<G, Src>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
+static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
+    hipLaunchKernelGGL((k_linearize<G, Src>), dim3(d.lin_blocks + (spec ? 1 : 0), B), dim3(256), lds_poses(d, 4 * 27), s, src, spec);
 }
 template <int G, class Src>
 static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     hipLaunchKernelGGL((k_backsub<G, Src>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
 }
 template <class Src>
-static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
+    if (d.has_odo) hipLaunchKernelGGL((k_odo_linearize<Src>), dim3(1, B), dim3(256), 0, s, src, spec);     // lin_part[n_lin_a] stays 0 otherwise
     switch (d.group) {
-        case 4: launch_lin_t<4>(src, d, B, s); break;
-        case 8: launch_lin_t<8>(src, d, B, s); break;
-        case 16: launch_lin_t<16>(src, d, B, s); break;
-        case 32: launch_lin_t<32>(src, d, B, s); break;
-        default: launch_lin_t<64>(src, d, B, s); break;
+        case 4: launch_lin_t<4>(src, d, B, spec, s); break;
+        case 8: launch_lin_t<8>(src, d, B, spec, s); break;
+        case 16: launch_lin_t<16>(src, d, B, spec, s); break;
+        case 32: launch_lin_t<32>(src, d, B, spec, s); break;
+        default: launch_lin_t<64>(src, d, B, spec, s); break;
     }
-    if (d.has_odo) hipLaunchKernelGGL((k_odo_linearize<Src>), dim3(1, B), dim3(256), 0, s, src);     // lin_part[n_lin_a] stays 0 otherwise
 }
 template <class Src>
 static void launch_lin_finalize_src(const Src& src, int force, int B, hipStream_t s) {
@@ -2169,7 +2203,8 @@ static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
     if (g.n_blk > 0) hipLaunchKernelGGL(k_build_pairs, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
 }
-void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, s); }
+void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 0, s); }
+void launch_linearize_decide(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 1, s); }
 void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) { launch_lin_finalize_src(One{ g }, force, 1, s); }
 void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_src(One{ g }, dims_of(g), 1, s); }
 void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) { launch_schur_finalize_src(One{ g }, dims_of(g), 1, s); }
@@ -2214,7 +2249,7 @@ void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int m
 // One unit of the LM state machine for every window of the batch (PCG or, for reduced systems <= 64 x 64, k_small_solve).
 void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s) {
     const Many src{ gs };
-    launch_linearize_src(src, d, B, s);
+    launch_linearize_src(src, d, B, 0, s);
     if (first) launch_lin_finalize_src(src, 0, B, s);
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);

@@ -17,6 +17,7 @@ int configure_kernels(const DeviceGraph& g);
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s);        // upload: co-observation pair lists of the S blocks
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s);
 void launch_linearize(const DeviceGraph& g, hipStream_t s);          // k_linearize (+ k_odo_linearize when the window has odometry edges)
+void launch_linearize_decide(const DeviceGraph& g, hipStream_t s);   // last launch of a unit: linearise the trial state beside the LM decision (k_decide role)
 void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s);
 void launch_schur_partial(const DeviceGraph& g, hipStream_t s);
 void launch_schur_finalize(const DeviceGraph& g, hipStream_t s);
