@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvisfs_ba_hip.so")
+LIB_PATH = os.environ.get("VISFS_BA_LIB") or os.path.join(_HERE, "lib", "libvisfs_ba_hip.so")     # override: A/B of library builds (tools/)
 
 _pd = C.POINTER(C.c_double)
 _pu8 = C.POINTER(C.c_uint8)

@@ -402,6 +402,16 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     Arena dyn{ nullptr, 0, static_bytes };
     DeviceGraph dg{};
     auto layout_dyn = [&](Arena& A, DeviceGraph& g) {
+        for (int k = 0; k < 2; ++k) {                       // the two linearisation sets: same layout, constant distance
+            LinBuf& L = g.lin[k];
+            L.obs_w = A.take<double>(std::max(No, 1));
+            L.obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
+            L.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
+            L.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
+            L.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
+            L.odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
+        }
+        g.lin_stride = reinterpret_cast<char*>(g.lin[1].obs_w) - reinterpret_cast<char*>(g.lin[0].obs_w);
         g.pose[0] = A.take<double>((size_t)Np * POSE_STRIDE); g.pose[1] = A.take<double>((size_t)Np * POSE_STRIDE);
         g.pt[0] = A.take<double>((size_t)std::max(Nl, 1) * 3); g.pt[1] = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.obs_level = A.take<uint8_t>(std::max(No, 1));
@@ -409,13 +419,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.obs_chi2_out = A.take<double>(std::max(No, 1));
         g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);
         g.obs_chi2 = A.take<double>(std::max(No, 1));
-        g.lin[0].obs_w = A.take<double>(std::max(No, 1));
-        g.lin[0].obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
         g.W = A.take<double>((size_t)std::max(No, 1) * 18);
-        g.lin[0].Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
-        g.lin[0].bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
-        g.lin[0].hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
-        g.lin[0].odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
         g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.bp = A.take<double>(std::max<size_t>(n6, 1));
         g.lin_part = A.take<double>((size_t)n_parts * 2);
@@ -432,12 +436,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
         g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
-        g.lin[1].obs_w = A.take<double>(std::max(No, 1));
-        g.lin[1].obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
-        g.lin[1].Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
-        g.lin[1].bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
-        g.lin[1].hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
-        g.lin[1].odo_blk = A.take<double>((size_t)(Ne + 1) * 120);
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };

@@ -147,6 +147,7 @@ struct DeviceGraph {
     double* obs_chi2;           // [No]
     double* W;                  // [No][18]  Hpl tiles, 6x3 row-major — written only for the stage hooks (debug)
     LinBuf lin[2];              // rho' weights, tile seeds, Hll, b_l, Hpp partials, odometry blocks: two sets (LmState::lin_sel)
+    long long lin_stride;       // bytes from a member of lin[0] to the same member of lin[1]
     double* Hpp;                // [Npf][36]
     double* bp;                 // [Npf][6]
     int32_t* pose_pin;          // [Npf] 1: pose has no active edge (outside g2o's active set)
@@ -172,18 +173,40 @@ struct DeviceGraph {
     int32_t debug;
 };
 
-// Linearisation set k of a graph: explicit selects, no dynamic indexing into the kernel-argument struct.
+// A wave-uniform pointer, pinned to scalar registers (the batched kernels read their graph from HBM with vector loads; without
+// this the six pointers of a LinBuf stay live in VGPRs across the whole kernel).
+template <class T>
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline LinBuf lin_of(const DeviceGraph& g, const int k) {
+inline T* sgpr_ptr(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+#else
+    return p;
+#endif
+}
+
+// Linearisation set k of a graph.  The two sets have the same internal layout at a constant byte distance (lin_stride), so the
+// selection is one multiply-add per pointer on set 0 — selecting between two loaded pointers would keep both sets' pointers
+// live (+20 VGPRs in the batched kernels, whose graph lives in HBM, cost k_linearize a wave of occupancy).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline LinBuf lin_of(const DeviceGraph& g, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    k = __builtin_amdgcn_readfirstlane(k);      // wave-uniform by construction
+#endif
+    const long long off = (long long)k * g.lin_stride;
     LinBuf L;
-    L.obs_w = k ? g.lin[1].obs_w : g.lin[0].obs_w;
-    L.obs_pcw = k ? g.lin[1].obs_pcw : g.lin[0].obs_pcw;
-    L.Hll = k ? g.lin[1].Hll : g.lin[0].Hll;
-    L.bl = k ? g.lin[1].bl : g.lin[0].bl;
-    L.hpp_part = k ? g.lin[1].hpp_part : g.lin[0].hpp_part;
-    L.odo_blk = k ? g.lin[1].odo_blk : g.lin[0].odo_blk;
+    L.obs_w = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].obs_w) + off));
+    L.obs_pcw = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].obs_pcw) + off));
+    L.Hll = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].Hll) + off));
+    L.bl = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].bl) + off));
+    L.hpp_part = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].hpp_part) + off));
+    L.odo_blk = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].odo_blk) + off));
     return L;
 }
 

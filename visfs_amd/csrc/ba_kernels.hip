@@ -173,9 +173,34 @@ __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Int
 struct One { DeviceGraph g; };
 struct Many { const DeviceGraph* gs; };
 __device__ __forceinline__ const DeviceGraph& graph_of(const One& s) { return s.g; }
-__device__ __forceinline__ const DeviceGraph& graph_of(const Many& s) { return s.gs[blockIdx.y]; }
+// The graph array of a batch is written by the host before the launches and never by a kernel: reading it through the constant
+// address space lets the compiler fetch the members with scalar loads into SGPRs (as it does for the by-value graph of One)
+// instead of keeping vector-loaded copies live in VGPRs.
+__device__ __forceinline__ const DeviceGraph& graph_of(const Many& s) {
+    typedef const __attribute__((address_space(4))) DeviceGraph* ConstGraphPtr;
+    ConstGraphPtr p = (ConstGraphPtr)(s.gs + blockIdx.y);
+    return *(const DeviceGraph*)p;
+}
 
 // chi2() = e . (Omega e), Omega = I3 / pixelVariance (Optimizer.cpp:153)
+// How a kernel gets its linearisation set.  A window on its own (One) may run the speculative unit, so the set is chosen at run
+// time (lin_of: six pointers in SGPRs).  The windows of a batched launch (Many) never do — their set is always lin[0], read
+// in place from the graph in HBM at the point of use (computing six pointers up front cost k_linearize / k_backsub 9-13 %
+// in the batched launches: the graph of a batch is read with vector loads and the pointers stayed live in VGPRs).
+template <class Src> struct LinSel;
+template <> struct LinSel<One> {
+    static constexpr bool two_sets = true;
+    LinBuf L;
+    __device__ __forceinline__ LinSel(const DeviceGraph& g, const int k) : L(lin_of(g, k)) {}
+    __device__ __forceinline__ const LinBuf& get() const { return L; }
+};
+template <> struct LinSel<Many> {
+    static constexpr bool two_sets = false;
+    const LinBuf& R;
+    __device__ __forceinline__ LinSel(const DeviceGraph& g, const int) : R(g.lin[0]) {}
+    __device__ __forceinline__ const LinBuf& get() const { return R; }
+};
+
 __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x * (iv * e.x) + e.y * (iv * e.y) + e.z * (iv * e.z); }
 
 // Upper-triangle index of (r,c), r <= c, in the 21-entry packing used by role B.
@@ -401,8 +426,9 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
 // accepted trial — the common case — finds its linearisation ready and only flips LmState::lin_sel; a rejected one leaves the
 // current set untouched.  The linearising workgroups read the snapshot k_backsub left (spec_go / spec_src / spec_dst), never a
 // field the decision writes, so the launch has no intra-kernel race.
-template <int G, class Src>
-__global__ __launch_bounds__(256) void k_linearize(const Src src, const int spec) {
+template <int G, class Src, bool SPEC>
+__global__ __launch_bounds__(256) void k_linearize(const Src src) {
+    constexpr bool spec = SPEC;
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -417,11 +443,12 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src, const int spec
         if (!(st->mode & MODE_LIN)) return;
         sel = st->sel; ls = st->lin_sel;
     }
-    const LinBuf L = lin_of(g, ls);
+    sel = __builtin_amdgcn_readfirstlane(sel);          // wave-uniform: keeps the selected estimate pointers in SGPRs
     const double* __restrict__ pose = g.pose[sel];
     const double* __restrict__ pt = g.pt[sel];
     stage_poses(pose, g.Np, sRt);
     __syncthreads();
+    const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();                     // after the staging: its pointer loads overlap the pose loads
     const Intrinsics K = intr_of(g);
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
     const int bid = blockIdx.x, tid = threadIdx.x;
@@ -516,13 +543,14 @@ __device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const Lin
 // ================================================================= K3: wheel-odometry edges
 // EdgePoseConstraint, Omega = I6 / odometryCovariance (Optimizer.cpp:117-121), no robust kernel.  One workgroup.
 template <class Src>
-__global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec) {
+__global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec_arg) {
+    const bool spec = LinSel<Src>::two_sets && spec_arg;
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     int sel, ls;
     if (spec) { if (!st->spec_go) return; sel = st->spec_src; ls = st->spec_dst; }
     else { if (!(st->mode & MODE_LIN)) return; sel = st->sel; ls = st->lin_sel; }
-    const LinBuf L = lin_of(g, ls);
+    const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();
     __shared__ double red[4];
     const double* __restrict__ pose = g.pose[sel];
     const double ic = g.inv_odo_cov;
@@ -576,7 +604,7 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
     LmState* st = g.st;
     if (!(st->mode & MODE_LIN)) return;
     if (!force && st->phase_iter != 0) return;
-    const LinBuf L = lin_of(g, st->lin_sel);
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     __shared__ double red[1024];
     const int tid = threadIdx.x;
     double md = 0.0;
@@ -763,7 +791,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
-    const LinBuf L = lin_of(g, st->lin_sel);
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     const int lane = threadIdx.x & 63;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
     // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
@@ -850,7 +878,7 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
-    const LinBuf L = lin_of(g, st->lin_sel);
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= g.n_blk) return;
@@ -1472,13 +1500,12 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     LmState* st = g.st;
     const bool go = (st->mode & MODE_TRIAL) && !st->solver_failed && !st->pcg_timeout;
     // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
+    if (LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
     if (!go) return;
-    const LinBuf L = lin_of(g, st->lin_sel);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;
     double* red = smem + 12 * g.Np;
-    const int sel = st->sel;
+    const int sel = st->sel, ls = st->lin_sel;
     const double* __restrict__ pose_t = g.pose[sel ^ 1];      // trial poses (written by the solver epilogue)
     const double* __restrict__ pt = g.pt[sel];
     double* __restrict__ pt_t = g.pt[sel ^ 1];
@@ -1511,6 +1538,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     stage_poses(pose_t, g.Np, sRt);
     stage_poses(g.pose[sel], g.Np, sRt0);
     __syncthreads();
+    const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();
     constexpr int LPW = 256 / G;
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
@@ -1866,7 +1894,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
-    const LinBuf L = lin_of(g, st->lin_sel);
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     __shared__ double sA[SM_MAX_N6 * SM_LD];
     __shared__ double sb[SM_MAX_N6], sx[SM_MAX_N6], sd[SM_MAX_N6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2146,7 +2174,8 @@ static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)
 
 template <int G, class Src>
 static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
-    hipLaunchKernelGGL((k_linearize<G, Src>), dim3(d.lin_blocks + (spec ? 1 : 0), B), dim3(256), lds_poses(d, 4 * 27), s, src, spec);
+    if (LinSel<Src>::two_sets && spec) hipLaunchKernelGGL((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds_poses(d, 4 * 27), s, src);
+    else hipLaunchKernelGGL((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
 }
 template <int G, class Src>
 static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
@@ -2249,7 +2278,7 @@ void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int m
 // One unit of the LM state machine for every window of the batch (PCG or, for reduced systems <= 64 x 64, k_small_solve).
 void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s) {
     const Many src{ gs };
-    launch_linearize_src(src, d, B, 0, s);
+    launch_linearize_src(src, d, B, 0, s);             // batched windows keep the gated unit (LinSel<Many>: set 0 only)
     if (first) launch_lin_finalize_src(src, 0, B, s);
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
