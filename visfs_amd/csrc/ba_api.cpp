@@ -436,6 +436,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
         g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
+        g.pose_lm = A.take<int32_t>(pose_obs.size());                           // likewise
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };
@@ -505,6 +506,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     Arena dd{ w.d_base, w.d_cap, static_bytes };
     layout_dyn(dd, dg);
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
+    dg.n_pose_obs = cnt[Npf];
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group;
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;

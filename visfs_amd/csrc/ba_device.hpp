@@ -81,6 +81,7 @@ struct LinBuf {
 struct DeviceGraph {
     int32_t Np, Nl, No, Ne, Npf;
     int32_t n_chunks;       // pose-major chunks
+    int32_t n_pose_obs;     // entries of pose_obs (observations of free poses)
     int32_t n_blk;          // stored S blocks (i <= j)
     int32_t n_sch;          // Schur chunks (<= sch_chunk co-observation pairs of one block each)
     int32_t sch_chunk;      // 64 x passes: pairs per chunk (a lane adds its pairs of the later passes serially)
@@ -123,6 +124,7 @@ struct DeviceGraph {
     const int32_t* blk_i;       // [n_blk] free pose index (row)
     const int32_t* blk_j;       // [n_blk] (col), j >= i
     const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
+    int32_t* pose_lm;           // [n_pose_obs] landmark of each entry of pose_obs (ascending within a pose); built on the device at upload
     int4* blk_pairs;            // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark, in landmark order
                                 // per block; built on the device at upload (k_build_pairs) from the pose-major observation lists
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block

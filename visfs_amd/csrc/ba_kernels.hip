@@ -633,8 +633,14 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
 // g2o's buildStructure analogue for the gather-form Schur complement: block (i <= j) of S lists, in landmark order, the pairs
 // (observation of pose i, observation of pose j, landmark) of the free landmarks both poses observe.  One wavefront per block
 // intersects the two poses' observation lists (pose-major, hence sorted by landmark; a pose sees a landmark at most once): a
-// lane per observation of pose i, a binary search in pose j's list, a ballot prefix for the slot — no atomics, so the order
+// lane per observation of pose i, a binary search in pose j's list (pose_lm: the landmark of every pose-major entry), a ballot
+// prefix for the slot — no atomics, so the order
 // (and with it every later summation order) is fixed.  The host has sized blk_ptr from the same rule (counts only).
+__global__ __launch_bounds__(256) void k_pose_landmarks(const DeviceGraph g) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < g.n_pose_obs) g.pose_lm[t] = g.obs_pt[g.pose_obs[t]];
+}
+
 __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -645,31 +651,40 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
     int base = g.blk_ptr[b];
     const int end = g.blk_ptr[b + 1];
     if (base == end) return;                              // a block that exists for its odometry edge only
-    for (int t0 = sA; t0 < eA; t0 += 64) {
-        const int t = t0 + lane;
-        bool m = false;
-        int k1 = 0, k2 = 0, l = 0;
-        if (t < eA) {
-            k1 = g.pose_obs[t];
-            l = g.obs_pt[k1];
-            if (!g.pt_fixed[l]) {
-                if (i == j) { m = true; k2 = k1; }
-                else {
-                    int lo = sB, hi = eB;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (g.obs_pt[g.pose_obs[mid]] < l) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo < eB) { k2 = g.pose_obs[lo]; m = (g.obs_pt[k2] == l); }
+    int top = 1;                                          // largest power of two <= |B| (uniform trip count of the search)
+    while (2 * top <= eB - sB) top *= 2;
+    constexpr int U = 4;                                  // observations per lane and round: U independent searches in flight
+    for (int t0 = sA; t0 < eA; t0 += 64 * U) {
+        int k1[U], l[U], lo[U];
+        bool cand[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 64 * u + lane;
+            cand[u] = false; k1[u] = 0; l[u] = 0; lo[u] = sB;
+            if (t < eA) { k1[u] = g.pose_obs[t]; l[u] = g.pose_lm[t]; cand[u] = !g.pt_fixed[l[u]]; }
+        }
+        // lower bound of l in pose j's landmark list, branch-free: lo ends at the first entry >= l
+        if (i != j) {
+            for (int step = top; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int probe = lo[u] + step - 1;
+                    if (cand[u] && probe < eB && g.pose_lm[probe] < l[u]) lo[u] += step;
                 }
             }
         }
-        const unsigned long long mask = __ballot(m);
-        if (m) {
-            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < end) g.blk_pairs[pos] = make_int4(k1, k2, l, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool m = cand[u];
+            int k2 = k1[u];
+            if (i != j) { m = m && lo[u] < eB && g.pose_lm[lo[u]] == l[u]; if (m) k2 = g.pose_obs[lo[u]]; }
+            const unsigned long long mask = __ballot(m);
+            if (m) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < end) g.blk_pairs[pos] = make_int4(k1[u], k2, l[u], 0);
+            }
+            base += __popcll(mask);
         }
-        base += __popcll(mask);
     }
 }
 
@@ -2230,7 +2245,9 @@ static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int
 
 // ---- single window
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
-    if (g.n_blk > 0) hipLaunchKernelGGL(k_build_pairs, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
+    if (g.n_blk <= 0) return;
+    if (g.n_pose_obs > 0) hipLaunchKernelGGL(k_pose_landmarks, dim3((g.n_pose_obs + 255) / 256), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(k_build_pairs, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
 }
 void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 0, s); }
 void launch_linearize_decide(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 1, s); }
