@@ -113,7 +113,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # untimed calibration pass: HIP-event pairs around every kernel class → per-kernel breakdown + the dominant kernel
+    # untimed calibration pass: a HIP-event pair on every kernel launch → per-kernel breakdown + the dominant kernel
     data_kernels = ("k_linearize", "k_schur_partial", "k_backsub", "k_pcg")
     solvers[0].profile_enable(True)
     for _ in range(3):
@@ -122,7 +122,7 @@ def main():
     null_us = 1e3 * getattr(solvers[0], "null_pair_ms", 0.0)     # an empty event pair: the mechanism's own share of every duration
     cand = [k for k in data_kernels if calib.get(k, {}).get("active_launches", 0) > 0]
     dom = max(cand, key=lambda k: calib[k]["active_ms"]) if cand else None
-    # timed region: events only around the dominant kernel's launches (on the library's own stream), every 8th step
+    # timed region: events only on the dominant kernel's launches (on the library's own stream), every 8th step
     solvers[0].profile_enable(False)
     vdist.barrier(world, bar_dev)
     torch.cuda.synchronize()
@@ -130,7 +130,7 @@ def main():
     iters = 0
     last = None
     for k in range(args.steps):
-        # HIP-event pairs cost ~5 us per record on the stream: instrument every 8th step of the timed region only
+        # instrument every 8th step of the timed region only (event bookkeeping is host work between launches)
         if dom:
             solvers[0].profile_enable([dom] if k % 8 == 0 else False)
         n, last = step()
@@ -150,9 +150,10 @@ def main():
     d["pcg_iters_per_launch"] = (last.pcg_iterations / max(1, last.trials_run[0] + last.trials_run[1])) if last is not None else 0
 
     def roof(kernel, p):
-        # avg_launch_us is the HIP-event pair duration as measured, WITHOUT correction: it carries the event mechanism's own
-        # share (rocprofv3's kernel durations in profiles/*kernel_stats.csv are 2.2-2.9 us shorter per launch at C2), so
-        # `achieved` / `frac` are lower bounds.  event_pair_null_us = what an EMPTY pair measures on the same stream.
+        # avg_launch_us: HIP events ATTACHED to the launch (hipExtLaunchKernelGGL start / stop events = the dispatch's own
+        # timestamps, what rocprofv3 reports: profiles/*kernel_stats.csv agrees within a few per cent).  Kernel classes of several
+        # launches (direct solver, linearise with odometry) are still bracketed by a pair recorded on the stream, which carries
+        # the event mechanism's own share: event_pair_null_us = what an EMPTY recorded pair measures there.
         avg_us = 1e3 * p["active_ms"] / p["active_launches"]
         byts = algorithmic_bytes(kernel, d)
         achieved = byts / (avg_us * 1e-6) / 1e9

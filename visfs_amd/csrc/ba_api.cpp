@@ -65,21 +65,28 @@ struct Workspace {
     int n6() const { return 6 * g.Npf; }
 };
 
-// RAII: records an event pair on the workspace stream around the launches of one kernel class.
+// RAII: one duration sample per launch of a kernel class.  `attached` (classes that are ONE kernel launch): the event pair is
+// handed to the launch itself and carries the dispatch's own start / end timestamps — the figure rocprofv3 reports.  Otherwise
+// (several kernels per class: direct solver, linearise with odometry, phase end) the pair is recorded around the launches on
+// the workspace stream and includes the event mechanism's own share (visfs_ba_profile::null_pair_ms).
 struct ProfScope {
-    Workspace& w; int k; bool on; hipEvent_t a{};
+    Workspace& w; int k; bool on; bool attached; hipEvent_t a{}, b{};
     static hipEvent_t take(Workspace& w) {
         if (w.ev_used == w.ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; w.ev_pool.push_back(e); }
         return w.ev_pool[w.ev_used++];
     }
-    ProfScope(Workspace& w_, int k_) : w(w_), k(k_), on((w_.prof_mask >> k_) & 1u) {
-        if (on) { a = take(w); if (a) (void)hipEventRecord(a, w.stream); else on = false; }
+    ProfScope(Workspace& w_, int k_, bool attached_ = false) : w(w_), k(k_), on((w_.prof_mask >> k_) & 1u), attached(attached_) {
+        if (!on) return;
+        a = take(w); b = take(w);
+        if (!a || !b) { on = false; return; }
+        if (attached) arm_launch_events(a, b);
+        else (void)hipEventRecord(a, w.stream);
     }
     ~ProfScope() {
         if (!on) return;
-        hipEvent_t b = take(w);
-        if (!b) return;
-        (void)hipEventRecord(b, w.stream);
+        if (attached) {
+            if (launch_events_pending()) { arm_launch_events(nullptr, nullptr); return; }   // nothing was launched: no sample
+        } else (void)hipEventRecord(b, w.stream);
         w.recs.push_back({ k, a, b });
     }
 };
@@ -557,18 +564,18 @@ int ws_read_state(visfs_ba_handle* h, Workspace& w) {
 // w.spec ("speculative linearise"): only the first unit of a phase linearises up front; every unit ENDS with the launch that
 // linearises its trial state beside the LM decision (k_linearize spec = 1), so k_decide and its launch leave the critical path.
 void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
-    if (!w.spec || first) { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize(w.g, w.stream); }
-    if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE); launch_lin_finalize(w.g, 0, w.stream); }
-    { ProfScope p(w, VISFS_BA_K_SCHUR); launch_schur_partial(w.g, w.stream); }
-    if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT); launch_small_solve(w.g, h->prm.solver, w.stream); }
+    if (!w.spec || first) { ProfScope p(w, VISFS_BA_K_LINEARIZE, w.g.Ne == 0 && w.g.Nz == 0); launch_linearize(w.g, w.stream); }
+    if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_lin_finalize(w.g, 0, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_SCHUR, true); launch_schur_partial(w.g, w.stream); }
+    if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, h->prm.solver, w.stream); }
     else {
-        { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE); launch_schur_finalize(w.g, w.stream); }
-        if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG); launch_pcg(w.g, w.stream); }
+        { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
+        if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }
-    { ProfScope p(w, VISFS_BA_K_BACKSUB); launch_backsub(w.g, w.stream); }
-    if (w.spec) { ProfScope p(w, VISFS_BA_K_LINEARIZE); launch_linearize_decide(w.g, w.stream); }
-    else { ProfScope p(w, VISFS_BA_K_DECIDE); launch_decide(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_BACKSUB, true); launch_backsub(w.g, w.stream); }
+    if (w.spec) { ProfScope p(w, VISFS_BA_K_LINEARIZE, w.g.Ne == 0 && w.g.Nz == 0); launch_linearize_decide(w.g, w.stream); }
+    else { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
 }
 
 // optimizer.optimize(n) for the phase armed in LmState: enqueue units until the device reports `done`.

@@ -26,6 +26,7 @@
 #include "ba_kernels.hpp"
 
 #include <float.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 
@@ -2161,6 +2162,19 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
 // Every launcher exists once, templated on the graph source: One{g} for a single window (grid.y = 1), Many{gs} for a batch
 // of independent windows (grid.y = number of windows, grid.x sized for the largest one; smaller windows' surplus
 // workgroups return at once).
+// Measurement: an armed event pair is attached to the NEXT timed launch itself (hipExtLaunchKernelGGL: the events take the
+// dispatch's own start / end timestamps, which is what rocprofv3 reports), instead of being recorded around it on the stream.
+static thread_local hipEvent_t tl_ev_start = nullptr, tl_ev_stop = nullptr;
+void arm_launch_events(hipEvent_t a, hipEvent_t b) { tl_ev_start = a; tl_ev_stop = b; }
+bool launch_events_pending() { return tl_ev_start != nullptr; }
+#define TIMED_LAUNCH(kern, grid, block, lds, stream, ...)                                                                    \
+    do {                                                                                                                     \
+        if (tl_ev_start) {                                                                                                   \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, tl_ev_start, tl_ev_stop, 0, __VA_ARGS__);                  \
+            tl_ev_start = tl_ev_stop = nullptr;                                                                              \
+        } else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                              \
+    } while (0)
+
 LaunchDims dims_of(const DeviceGraph& g) {
     LaunchDims d;
     d.group = g.group;
@@ -2189,12 +2203,12 @@ static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)
 
 template <int G, class Src>
 static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
-    if (LinSel<Src>::two_sets && spec) hipLaunchKernelGGL((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds_poses(d, 4 * 27), s, src);
-    else hipLaunchKernelGGL((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
+    if (LinSel<Src>::two_sets && spec) TIMED_LAUNCH((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds_poses(d, 4 * 27), s, src);
+    else TIMED_LAUNCH((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
 }
 template <int G, class Src>
 static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    hipLaunchKernelGGL((k_backsub<G, Src>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
+    TIMED_LAUNCH((k_backsub<G, Src>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
 }
 template <class Src>
 static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
@@ -2209,23 +2223,23 @@ static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, int
 }
 template <class Src>
 static void launch_lin_finalize_src(const Src& src, int force, int B, hipStream_t s) {
-    hipLaunchKernelGGL((k_lin_finalize<Src>), dim3(1, B), dim3(1024), 0, s, src, force);
+    TIMED_LAUNCH((k_lin_finalize<Src>), dim3(1, B), dim3(1024), 0, s, src, force);
 }
 template <class Src>
 static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     if (d.sch_wgs <= 0) return;
-    if (d.sch_multi) hipLaunchKernelGGL((k_schur_partial<true, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
-    else hipLaunchKernelGGL((k_schur_partial<false, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
+    if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
+    else TIMED_LAUNCH((k_schur_partial<false, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
 }
 template <class Src>
 static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    hipLaunchKernelGGL((k_schur_finalize<Src>), dim3(d.fin_wgs, B), dim3(256), 0, s, src);
+    TIMED_LAUNCH((k_schur_finalize<Src>), dim3(d.fin_wgs, B), dim3(256), 0, s, src);
 }
 template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    if (d.pcg_rows <= 64) hipLaunchKernelGGL((k_pcg<1, true, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
-    else if (d.pcg_rows <= 128) hipLaunchKernelGGL((k_pcg<2, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
-    else hipLaunchKernelGGL((k_pcg<4, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
+    if (d.pcg_rows <= 64) TIMED_LAUNCH((k_pcg<1, true, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    else if (d.pcg_rows <= 128) TIMED_LAUNCH((k_pcg<2, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    else TIMED_LAUNCH((k_pcg<4, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
 }
 template <class Src>
 static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
@@ -2256,7 +2270,7 @@ void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_pa
 void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) { launch_schur_finalize_src(One{ g }, dims_of(g), 1, s); }
 void launch_pcg(const DeviceGraph& g, hipStream_t s) { launch_pcg_src(One{ g }, dims_of(g), 1, s); }
 void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, s); }
-void launch_decide(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
+void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
     launch_phase_end_src(One{ g }, dims_of(g), 1, phase_just_done, mark, next_max_iter, s);
 }
@@ -2264,7 +2278,7 @@ void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int rest
     hipLaunchKernelGGL((k_reset<One>), dim3(dims_of(g).reset_blocks), dim3(256), 0, s, One{ g }, max_iter, gauss_newton, restore);
 }
 void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s) {
-    hipLaunchKernelGGL((k_small_solve<One>), dim3(1), dim3(512), 0, s, One{ g }, solver);
+    TIMED_LAUNCH((k_small_solve<One>), dim3(1), dim3(512), 0, s, One{ g }, solver);
 }
 void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s) {
     hipLaunchKernelGGL((k_small_optimize<One>), dim3(1), dim3(SM_T), 0, s, One{ g }, solver, half);

@@ -14,6 +14,8 @@ LaunchDims dims_of(const DeviceGraph& g);
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b);
 
 int configure_kernels(const DeviceGraph& g);
+void arm_launch_events(hipEvent_t start, hipEvent_t stop);             // measurement: attach an event pair to the next timed launch (this thread)
+bool launch_events_pending();                                        // ... still armed: no timed launch has consumed it
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s);        // upload: co-observation pair lists of the S blocks
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s);
 void launch_linearize(const DeviceGraph& g, hipStream_t s);          // k_linearize (+ k_odo_linearize when the window has odometry edges)
