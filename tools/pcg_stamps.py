@@ -6,9 +6,10 @@ import numpy as np
 from visfs_amd import abi, backend, synth
 backend.LIB_PATH = os.path.join(ROOT, "visfs_amd", "lib", "libvisfs_ba_hip_stamps.so")
 lib = backend.load_library()
+CFG = sys.argv[1] if len(sys.argv) > 1 else "C2"
 for wg in (0, 24, 48):
     os.environ["VISFS_BA_STAMP_WG"] = str(wg)
-    w = synth.make_window("C2"); prm = abi.default_params(iterations=20, solver=2)
+    w = synth.make_window(CFG); prm = abi.default_params(iterations=20, solver=2)
     gb, *_ = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
     s = backend.Solver(prm); s.upload(gb)
     for _ in range(3):

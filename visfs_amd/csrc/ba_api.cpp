@@ -337,19 +337,15 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         blk_desc[2 * b] = make_int4(blk_chunk_ptr[b], blk_chunk_ptr[b + 1], dg ? pose_odo_ptr[a] : blk_odo_ptr[b], dg ? pose_odo_ptr[a + 1] : blk_odo_ptr[b + 1]);
         blk_desc[2 * b + 1] = make_int4(a, blk_j[b], pose_chunk_ptr[a], pose_chunk_ptr[a + 1]);
     }
-    // persistent PCG: LDS plan (4 vectors always; all Minv blocks and the own block row of S when they fit in 60 KiB)
     if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 256 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
     int max_row = 0;
     for (int a = 0; a < Npf; ++a) max_row = std::max(max_row, row_ptr[a + 1] - row_ptr[a]);
-    // persistent PCG: LDS plan.  d, q (+ s beyond 64 free poses), scalars, the row's column/code tables always; all Minv
-    // blocks (beyond 64 free poses; below that they live in registers) and the own block row of S when they fit.
-    // Co-residency of the hand-off needs every workgroup resident: <= 200 workgroups may own most of a CU's LDS each,
-    // more than that must fit two per CU.
-    size_t pcg_lds = (size_t)((Npf > 64 ? 3 : 2) * 6 * Npf + 32 + 32) * 8 + (size_t)8 * max_row + 16;
-    int lds_minv = 0, lds_srow = 0;
+    // persistent PCG: LDS plan.  d, q, scalars, the row's column/code tables always; the own block row of S when it fits.
+    // Co-residency of the hand-off needs every workgroup resident: at most 256 workgroups, one per CU.
+    size_t pcg_lds = (size_t)(2 * 6 * Npf + 32 + 32) * 8 + (size_t)8 * max_row + 16;
+    int lds_minv = 0, lds_srow = 0;                      // Minv lives in registers (one block per thread) at every size
     {
         const size_t budget = (size_t)150 * 1024;        // one workgroup per CU may own most of its 160 KiB
-        if (Npf > 64 && pcg_lds + (size_t)288 * Npf <= budget) { lds_minv = 1; pcg_lds += (size_t)288 * Npf; }
         if (pcg_lds + (size_t)288 * max_row <= budget) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
     }
 

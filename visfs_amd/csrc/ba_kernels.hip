@@ -922,8 +922,13 @@ __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long 
 }
 
 // BPL = 6-blocks owned by each lane of wave 0 (ceil(Npf / 64)); MREG: the lane keeps its Minv block in registers (BPL == 1).
-template <int BPL, bool MREG, class Src>
+// WIDE (more than 64 free poses; BPL = 1, MREG): the vector recurrences run on ALL four waves, thread a owns 6-block a (r, d and
+// its Minv block in registers), and the two dot products of an iteration are workgroup reductions (wave butterfly + four LDS
+// partials in fixed order) — with wave 0 alone owning up to four blocks per lane and Minv in LDS the vector step cost 5 us
+// of an 8 us iteration at C4 (199 block rows) and the set-up 8.5 us.
+template <int BPL, bool MREG, class Src, bool WIDE>
 __global__ __launch_bounds__(256) void k_pcg(const Src src) {
+    static_assert(!WIDE || (BPL == 1 && MREG), "WIDE: one block per thread, Minv in registers");
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     const int i0 = blockIdx.x, i1 = i0 + 1;
     double* sd = smem;                                                // d (every workgroup holds the full vector)
     double* sq = smem + n6;                                           // q of the current iteration
-    double* sP = smem + 2 * n6;                                       // [32] scalars
+    double* sP = smem + 2 * n6;                                       // [32] scalars ([8..15]: partials of the WIDE reductions)
     double* sQ = sP + 32;                                             // [R][4][8] per-wave partial rows of q
     double* ss = sQ + 32 * R;                                         // [n6] s = Minv r, only when BPL > 1 (else registers)
     double* sM = ss + (BPL > 1 ? n6 : 0);                             // [Npf][36] when pcg_lds_minv
@@ -947,6 +952,18 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     int* sCol = reinterpret_cast<int*>(sS + (g.pcg_lds_srow ? 36 * (size_t)R * g.pcg_max_row : 0));   // [R][max_row]
     int* sCode = sCol + R * g.pcg_max_row;
     const int MR = g.pcg_max_row;
+    const int blk0 = WIDE ? tid : lane;                               // first 6-block this thread owns in the vector recurrences
+    const bool vec = WIDE || wave == 0;                               // this thread takes part in them
+    // sum over the owners: one wave (butterfly) or the workgroup (butterfly, four LDS partials added in fixed order); `slot`
+    // alternates so that a partial is never overwritten before every wave has read it (one barrier per reduction)
+    auto owners_sum = [&](const double v, const int slot) -> double {
+        const double ws = wave_sum(v);
+        if (!WIDE) return ws;
+        double* red4 = sP + 8 + 4 * slot;
+        if (lane == 0) red4[wave] = ws;
+        __syncthreads();
+        return ((red4[0] + red4[1]) + red4[2]) + red4[3];
+    };
     for (int li = 0; li < i1 - i0; ++li) {
         const int rb = g.row_ptr[i0 + li], nb = g.row_ptr[i0 + li + 1] - rb;
         for (int n = tid; n < nb; n += 256) { sCol[li * MR + n] = g.row_col[rb + n]; sCode[li * MR + n] = g.row_blk[rb + n]; }
@@ -956,16 +973,15 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
         for (int t = tid; t < 36 * g.Npf; t += 256) sM[t] = g.Minv[t];
     }
     if (tid == 0) sP[2] = 0.0;                                         // hand-off timeout flag of the workgroup
-    // ---- wave 0: lane owns the 6-blocks a = lane + 64 k.  r = b ; d = M^-1 r ; dn = r.d   (fixed order)
+    // ---- the owners of the vector recurrences (wave 0: lane = block; WIDE: thread = block).  r = b ; d = M^-1 r ; dn = r.d   (fixed order)
     double rr_[BPL][6], dd_[BPL][6], xown[6], mm_[MREG ? 36 : 1];
 #pragma unroll
     for (int c = 0; c < 6; ++c) xown[c] = 0.0;
     double dn = 0.0, d0 = 0.0;
-    if (wave == 0) {
-        double part = 0.0;
+    if (vec) {
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
-            const int a = lane + 64 * k;
+            const int a = blk0 + 64 * k;
             const bool own = a < g.Npf;
 #pragma unroll
             for (int c = 0; c < 6; ++c) rr_[k][c] = own ? g.bs[6 * a + c] : 0.0;
@@ -978,27 +994,31 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
         // (for !MREG the Minv copy above is completed by the barrier below before it is read)
     }
     __syncthreads();
-    if (wave == 0) {
+    {
         double part = 0.0;
+        if (vec) {
 #pragma unroll
-        for (int k = 0; k < BPL; ++k) {
-            const int a = lane + 64 * k;
-            const bool own = a < g.Npf;
+            for (int k = 0; k < BPL; ++k) {
+                const int a = blk0 + 64 * k;
+                const bool own = a < g.Npf;
 #pragma unroll
-            for (int r6 = 0; r6 < 6; ++r6) {
-                double v = 0.0;
+                for (int r6 = 0; r6 < 6; ++r6) {
+                    double v = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) v += (MREG ? mm_[6 * r6 + c] : (own ? Minv[36 * a + 6 * r6 + c] : 0.0)) * rr_[k][c];
-                dd_[k][r6] = v;
-                part += rr_[k][r6] * v;
-                if (own) sd[6 * a + r6] = v;
+                    for (int c = 0; c < 6; ++c) v += (MREG ? mm_[6 * r6 + c] : (own ? Minv[36 * a + 6 * r6 + c] : 0.0)) * rr_[k][c];
+                    dd_[k][r6] = v;
+                    part += rr_[k][r6] * v;
+                    if (own) sd[6 * a + r6] = v;
+                }
             }
         }
-        dn = wave_sum(part);
-        d0 = 1e-6 * dn;
-        const double res_in = st->pcg_res_in;
-        if (res_in > 0.0 && res_in > d0) d0 = res_in;
-        if (lane == 0) { sP[0] = dn; sP[1] = d0; }
+        if (vec) {                                                     // (WIDE: every thread, so the barrier inside is uniform)
+            dn = owners_sum(part, 0);
+            d0 = 1e-6 * dn;
+            const double res_in = st->pcg_res_in;
+            if (res_in > 0.0 && res_in > d0) d0 = res_in;
+            if (tid == 0) { sP[0] = dn; sP[1] = d0; }
+        }
     }
     if (g.pcg_lds_srow) {
         // own block rows; transposed blocks are stored transposed so that the mat-vec reads every block row-major.
@@ -1099,13 +1119,13 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
         __syncthreads();
         PCG_STAMP(3 + 4 * iter);
         // ---- vector recurrences on wave 0, blocks in registers (identical in every workgroup: same data, same order)
-        if (wave == 0) {
+        if (vec) {
             // q of the owned blocks: registers when one block per lane, re-read from LDS otherwise (register budget)
             double qq[BPL == 1 ? 6 : 1], sv1[BPL == 1 ? 6 : 1];
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = lane + 64 * k;
+                const int a = blk0 + 64 * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1114,12 +1134,12 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
                     part += dd_[k][c] * qv;
                 }
             }
-            const double dq = wave_sum(part);
+            const double dq = owners_sum(part, 1);
             const double alpha = dn / dq;
             part = 0.0;
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = lane + 64 * k;
+                const int a = blk0 + 64 * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1136,11 +1156,11 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
                     part += rr_[k][r6] * v;
                 }
             }
-            const double dnn = wave_sum(part);
+            const double dnn = owners_sum(part, 0);
             const double beta = dnn / dn;
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = lane + 64 * k;
+                const int a = blk0 + 64 * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1149,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
                     if (own) sd[6 * a + c] = dd_[k][c];
                 }
             }
-            if (lane == 0) sP[0] = dnn;
+            if (tid == 0) sP[0] = dnn;
         }
         __syncthreads();
         PCG_STAMP(4 + 4 * iter);
@@ -1159,15 +1179,15 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     }
     if (timeout) { if (tid == 0) st->pcg_timeout = 1; return; }
     // x is final: the lane owning this workgroup's block row stores it and does K8 (oplus); workgroup 0 publishes the statistics.
-    if (wave == 0) {
-        if (lane == (i0 & 63)) {
+    if (vec) {
+        if (WIDE ? (tid == i0) : (lane == (i0 & 63))) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) g.x[6 * i0 + c] = xown[c];
             const int ip = g.free_pose[i0];
             const int sel = st->sel;
             pose_oplus(g.pose[sel] + POSE_STRIDE * ip, xown, g.pose[sel ^ 1] + POSE_STRIDE * ip);
         }
-        if (lane == 0 && blockIdx.x == 0) {
+        if (tid == 0 && blockIdx.x == 0) {
             st->pcg_residual = 0.5 * dn;
             st->pcg_iter = iter;
             st->pcg_total += iter;
@@ -2237,9 +2257,8 @@ static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B
 }
 template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    if (d.pcg_rows <= 64) TIMED_LAUNCH((k_pcg<1, true, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
-    else if (d.pcg_rows <= 128) TIMED_LAUNCH((k_pcg<2, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
-    else TIMED_LAUNCH((k_pcg<4, false, Src>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
+    if (d.pcg_rows <= 64) TIMED_LAUNCH((k_pcg<1, true, Src, false>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    else TIMED_LAUNCH((k_pcg<1, true, Src, true>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
 }
 template <class Src>
 static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
@@ -2354,8 +2373,7 @@ bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= 
 int configure_kernels(const DeviceGraph& g) {
     // dynamic LDS above 64 KiB needs an explicit opt-in (never the case with the limits in ba_device.hpp, kept for safety)
     if (g.pcg_lds_bytes > 64 * 1024) {
-        const void* f = g.Npf <= 64 ? reinterpret_cast<const void*>(k_pcg<1, true, One>) : g.Npf <= 128 ? reinterpret_cast<const void*>(k_pcg<2, false, One>)
-                      : reinterpret_cast<const void*>(k_pcg<4, false, One>);
+        const void* f = g.Npf <= 64 ? reinterpret_cast<const void*>(k_pcg<1, true, One, false>) : reinterpret_cast<const void*>(k_pcg<1, true, One, true>);
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, g.pcg_lds_bytes) != hipSuccess) return -1;
     }
     return 0;
