@@ -569,8 +569,8 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
         if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }
-    { ProfScope p(w, VISFS_BA_K_BACKSUB, true); launch_backsub(w.g, w.stream); }
-    if (w.spec) { ProfScope p(w, VISFS_BA_K_LINEARIZE, w.g.Ne == 0 && w.g.Nz == 0); launch_linearize_decide(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_BACKSUB, true); if (w.spec && (w.g.Ne > 0 || w.g.Nz > 0)) launch_backsub_odospec(w.g, w.stream); else launch_backsub(w.g, w.stream); }
+    if (w.spec) { ProfScope p(w, VISFS_BA_K_LINEARIZE, true); launch_linearize_decide(w.g, w.stream); }
     else { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
 }
 

@@ -543,17 +543,10 @@ __device__ __forceinline__ void laser_store_slot(const DeviceGraph& g, const Lin
 
 // ================================================================= K3: wheel-odometry edges
 // EdgePoseConstraint, Omega = I6 / odometryCovariance (Optimizer.cpp:117-121), no robust kernel.  One workgroup.
-template <class Src>
-__global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec_arg) {
-    const bool spec = LinSel<Src>::two_sets && spec_arg;
-    const DeviceGraph& g = graph_of(src);
-    const LmState* st = g.st;
-    int sel, ls;
-    if (spec) { if (!st->spec_go) return; sel = st->spec_src; ls = st->spec_dst; }
-    else { if (!(st->mode & MODE_LIN)) return; sel = st->sel; ls = st->lin_sel; }
-    const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();
-    __shared__ double red[4];
-    const double* __restrict__ pose = g.pose[sel];
+// The role as a function (256 threads; red4: 4 doubles, redz: 4 * 27 doubles of LDS): linearises every odometry edge and the laser
+// edges at `pose` into set L, returns the workgroup's chi2 sum.  Run by k_odo_linearize and — for the speculative unit — by the
+// odometry workgroup of k_backsub, which has the trial poses in hand a whole launch earlier.
+__device__ __forceinline__ double odo_role(const DeviceGraph& g, const LinBuf& L, const double* __restrict__ pose, double* red4, double* redz) {
     const double ic = g.inv_odo_cov;
     const int tid = threadIdx.x;
     double chi_acc = 0.0;
@@ -563,7 +556,6 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int 
     // laser occupied-space edges (EdgeOccupiedObservation, Omega = 1 / laserCovariance, Optimizer.cpp:232-249, no kernel):
     // all on one pose, so the workgroup reduces J^T Omega J (upper triangle) and -J^T Omega e into slot Ne of odo_blk.
     if (g.Nz > 0) {
-        __shared__ double redz[4 * 27];
         const double il = g.inv_laser_cov;
         const double* tq = pose + POSE_STRIDE * g.laser_pose;
         double acc[27];
@@ -581,8 +573,22 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int 
             laser_store_slot(g, L, tid, redz[tid] + redz[27 + tid] + redz[54 + tid] + redz[81 + tid]);
         }
     }
-    const double chi_tot = block_sum_256(chi_acc, red);
-    if (tid == 0) { g.lin_part[2 * g.n_lin_a] = chi_tot; g.lin_part[2 * g.n_lin_a + 1] = 0.0; }
+    return block_sum_256(chi_acc, red4);
+}
+
+template <class Src>
+__global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec_arg) {
+    const bool spec = LinSel<Src>::two_sets && spec_arg;
+    const DeviceGraph& g = graph_of(src);
+    const LmState* st = g.st;
+    int sel, ls;
+    if (spec) { if (!st->spec_go) return; sel = st->spec_src; ls = st->spec_dst; }
+    else { if (!(st->mode & MODE_LIN)) return; sel = st->sel; ls = st->lin_sel; }
+    const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();
+    __shared__ double red[4];
+    __shared__ double redz[4 * 27];
+    const double chi_tot = odo_role(g, L, g.pose[sel], red, redz);
+    if (threadIdx.x == 0) { g.lin_part[2 * g.n_lin_a] = chi_tot; g.lin_part[2 * g.n_lin_a + 1] = 0.0; }
 }
 
 // One thread: chi2 / max|diag H| of a fresh linearisation; computeLambdaInit on the first iteration of a phase ([g2o-upstream] tau = 1e-5).
@@ -1530,7 +1536,11 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 }
 
 // ================================================================= K7/K8 + chi2 at the trial state
-template <int G, class Src>
+// ODOSPEC (speculative unit of a window with odometry / laser edges): the workgroup that evaluates those edges at the trial poses
+// also linearises them there, into the set the speculative k_linearize is about to fill — k_odo_linearize (6.6 us, one
+// workgroup) leaves the unit.  The role is register-hungry (224 VGPRs), so this instantiation runs at two waves per SIMD: it is
+// used only where k_backsub is a single round of waves anyway (the speculative unit's size limit).
+template <int G, class Src, bool ODOSPEC>
 __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
@@ -1568,6 +1578,11 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
         }
         const double chi_tot = block_sum_256(chi_acc, red);
         if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; }
+        if (ODOSPEC) {
+            __syncthreads();
+            const LinSel<Src> lspec(g, ls ^ 1);                      // == spec_dst of the snapshot above
+            (void)odo_role(g, lspec.get(), pose_t, smem, smem + 8);  // this workgroup stages no poses: the LDS is free
+        }
         return;
     }
     double* sRt0 = red + 8;                   // poses of the linearisation point (tiles are rebuilt there)
@@ -2227,12 +2242,15 @@ static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, h
     else TIMED_LAUNCH((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
 }
 template <int G, class Src>
-static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    TIMED_LAUNCH((k_backsub<G, Src>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
+static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odospec, hipStream_t s) {
+    if (LinSel<Src>::two_sets && odospec)
+        TIMED_LAUNCH((k_backsub<G, Src, LinSel<Src>::two_sets>), dim3(d.backsub_blocks, B), dim3(256), (size_t)std::max(24 * d.np + 8, 128) * sizeof(double), s, src);
+    else TIMED_LAUNCH((k_backsub<G, Src, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
 }
 template <class Src>
 static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
-    if (d.has_odo) hipLaunchKernelGGL((k_odo_linearize<Src>), dim3(1, B), dim3(256), 0, s, src, spec);     // lin_part[n_lin_a] stays 0 otherwise
+    // (speculative unit: the odometry / laser edges were linearised by k_backsub<ODOSPEC> already)
+    if (d.has_odo && !spec) hipLaunchKernelGGL((k_odo_linearize<Src>), dim3(1, B), dim3(256), 0, s, src, spec);     // lin_part[n_lin_a] stays 0 otherwise
     switch (d.group) {
         case 4: launch_lin_t<4>(src, d, B, spec, s); break;
         case 8: launch_lin_t<8>(src, d, B, spec, s); break;
@@ -2261,13 +2279,13 @@ static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream
     else TIMED_LAUNCH((k_pcg<1, true, Src, true>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
 }
 template <class Src>
-static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, int odospec, hipStream_t s) {
     switch (d.group) {
-        case 4: launch_backsub_t<4>(src, d, B, s); break;
-        case 8: launch_backsub_t<8>(src, d, B, s); break;
-        case 16: launch_backsub_t<16>(src, d, B, s); break;
-        case 32: launch_backsub_t<32>(src, d, B, s); break;
-        default: launch_backsub_t<64>(src, d, B, s); break;
+        case 4: launch_backsub_t<4>(src, d, B, odospec, s); break;
+        case 8: launch_backsub_t<8>(src, d, B, odospec, s); break;
+        case 16: launch_backsub_t<16>(src, d, B, odospec, s); break;
+        case 32: launch_backsub_t<32>(src, d, B, odospec, s); break;
+        default: launch_backsub_t<64>(src, d, B, odospec, s); break;
     }
 }
 template <class Src>
@@ -2288,7 +2306,8 @@ void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) { launc
 void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_src(One{ g }, dims_of(g), 1, s); }
 void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) { launch_schur_finalize_src(One{ g }, dims_of(g), 1, s); }
 void launch_pcg(const DeviceGraph& g, hipStream_t s) { launch_pcg_src(One{ g }, dims_of(g), 1, s); }
-void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, s); }
+void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 0, s); }
+void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 1, s); }
 void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
     launch_phase_end_src(One{ g }, dims_of(g), 1, phase_just_done, mark, next_max_iter, s);
@@ -2333,7 +2352,7 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
     else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
-    launch_backsub_src(src, d, B, s);
+    launch_backsub_src(src, d, B, 0, s);
     hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
 }
 void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {

@@ -26,6 +26,7 @@ void launch_schur_finalize(const DeviceGraph& g, hipStream_t s);
 void launch_pcg(const DeviceGraph& g, hipStream_t s);                // persistent block-Jacobi PCG, one launch per damped solve
 void launch_direct(const DeviceGraph& g, hipStream_t s);             // dense assemble + Cholesky
 void launch_backsub(const DeviceGraph& g, hipStream_t s);
+void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s);   // speculative unit with odometry / laser edges: also linearises them at the trial poses
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
 bool small_solve_fits(const DeviceGraph& g);                         // 6 Npf <= 64: S is finalised and solved by one workgroup
