@@ -654,17 +654,28 @@ int ws_download(visfs_ba_handle* h, Workspace& w, double* pose_tq, double* point
     if (!state_fresh) { int rc = ws_read_state(h, w); if (rc != VISFS_BA_OK) return rc; }
     const int sel = w.h_state->sel;
     const DeviceGraph& g = w.g;
-    // every copy is enqueued first, ONE synchronisation at the end
+    // every copy is enqueued first, ONE synchronisation at the end.  The copies land in the workspace's PINNED staging arena (idle
+    // between uploads) and are moved to the caller's pageable buffers by the host: a device-to-pageable copy is staged and
+    // serialised by the runtime chunk by chunk.
+    const size_t b_pose = pose_tq ? (size_t)g.Np * POSE_STRIDE * 8 : 0, b_pt = (point_xyz && g.Nl) ? (size_t)g.Nl * 24 : 0;
+    const size_t b_out = (obs_outlier && g.No) ? (size_t)g.No : 0, b_chi = (obs_chi2 && g.No) ? (size_t)g.No * 8 : 0;
+    const size_t o_pose = 0, o_pt = (o_pose + b_pose + 255) & ~size_t(255), o_chi = (o_pt + b_pt + 255) & ~size_t(255), o_out = (o_chi + b_chi + 255) & ~size_t(255);
+    const bool staged = w.h_base && o_out + b_out <= w.h_cap;
     std::vector<double> tmp;
-    if (pose_tq) {
-        tmp.resize((size_t)g.Np * POSE_STRIDE);
-        HIP_TRY(h, hipMemcpyAsync(tmp.data(), g.pose[sel], tmp.size() * 8, hipMemcpyDeviceToHost, w.stream));
-    }
-    if (point_xyz && g.Nl) HIP_TRY(h, hipMemcpyAsync(point_xyz, g.pt[sel], (size_t)g.Nl * 24, hipMemcpyDeviceToHost, w.stream));
-    if (obs_outlier && g.No) HIP_TRY(h, hipMemcpyAsync(obs_outlier, g.obs_outlier, g.No, hipMemcpyDeviceToHost, w.stream));
-    if (obs_chi2 && g.No) HIP_TRY(h, hipMemcpyAsync(obs_chi2, g.obs_chi2_out, (size_t)g.No * 8, hipMemcpyDeviceToHost, w.stream));
+    char* hb = w.h_base;
+    if (!staged && pose_tq) tmp.resize((size_t)g.Np * POSE_STRIDE);
+    if (pose_tq) HIP_TRY(h, hipMemcpyAsync(staged ? (void*)(hb + o_pose) : (void*)tmp.data(), g.pose[sel], b_pose, hipMemcpyDeviceToHost, w.stream));
+    if (b_pt) HIP_TRY(h, hipMemcpyAsync(staged ? (void*)(hb + o_pt) : (void*)point_xyz, g.pt[sel], b_pt, hipMemcpyDeviceToHost, w.stream));
+    if (b_out) HIP_TRY(h, hipMemcpyAsync(staged ? (void*)(hb + o_out) : (void*)obs_outlier, g.obs_outlier, b_out, hipMemcpyDeviceToHost, w.stream));
+    if (b_chi) HIP_TRY(h, hipMemcpyAsync(staged ? (void*)(hb + o_chi) : (void*)obs_chi2, g.obs_chi2_out, b_chi, hipMemcpyDeviceToHost, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));
-    if (pose_tq) for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) pose_tq[7 * i + q] = tmp[POSE_STRIDE * i + q];
+    const double* ps = staged ? reinterpret_cast<const double*>(hb + o_pose) : tmp.data();
+    if (pose_tq) for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) pose_tq[7 * i + q] = ps[POSE_STRIDE * i + q];
+    if (staged) {
+        if (b_pt) std::memcpy(point_xyz, hb + o_pt, b_pt);
+        if (b_out) std::memcpy(obs_outlier, hb + o_out, b_out);
+        if (b_chi) std::memcpy(obs_chi2, hb + o_chi, b_chi);
+    }
     return VISFS_BA_OK;
 }
 
