@@ -574,26 +574,6 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     else { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
 }
 
-// optimizer.optimize(n) for the phase armed in LmState: enqueue units until the device reports `done`.
-int run_phase(visfs_ba_handle* h, Workspace& w, int max_iter) {
-    if (max_iter <= 0) return VISFS_BA_OK;
-    int guard = 0;
-    int remaining = max_iter;
-    bool first = true;
-    while (true) {
-        for (int u = 0; u < remaining; ++u) { enqueue_unit(h, w, first); first = false; }
-        HIP_TRY(h, hipGetLastError());
-        int rc = ws_read_state(h, w);
-        if (rc != VISFS_BA_OK) return rc;
-        const LmState& st = *w.h_state;
-        if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
-        if (st.done) break;
-        remaining = std::max(1, max_iter - st.phase_iter);       // rejected trials consumed units without finishing an iteration
-        if (++guard > 16 * max_iter + 16) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
-    }
-    return VISFS_BA_OK;
-}
-
 void fill_stats(const LmState& st, visfs_ba_stats* out) {
     std::memset(out, 0, sizeof(*out));
     out->status = st.status;
@@ -624,15 +604,38 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
         if (w.prof_mask) { w.active[VISFS_BA_K_SMALL] += 1; w.active[VISFS_BA_K_RESET] += 1; }
         return w.h_state->status;
     }
-    int rc = run_phase(h, w, half);                               // :265
-    if (rc != VISFS_BA_OK) return rc;
-    { ProfScope p(w, VISFS_BA_K_PHASE_END); launch_phase_end(w.g, 0, 1, half, w.stream); }   // :270-303
-    rc = run_phase(h, w, (h->prm.robust_kernel_delta > 0.0) ? half : 0);   // :310-311 (gated off on abort)
-    if (rc != VISFS_BA_OK) return rc;
-    { ProfScope p(w, VISFS_BA_K_PHASE_END); launch_phase_end(w.g, 1, 0, 0, w.stream); }      // :315-318
-    HIP_TRY(h, hipGetLastError());
-    rc = ws_read_state(h, w);
-    if (rc != VISFS_BA_OK) return rc;
+    // Both phases, their ends and the outlier pass are enqueued BEFORE the host knows how the first phase went: the phase-end
+    // kernels act only when the phase they close is done (LmState::done / ended), so the common solve — no rejected trial beyond
+    // the units of its phase — costs ONE state read instead of one per phase (each is a stream drain plus the bubble until the
+    // next launches arrive: ~25 us, 5 % of a production-size solve).  Whatever is left is driven from the state that comes back.
+    const int half2 = (h->prm.robust_kernel_delta > 0.0) ? half : 0;                                // :310-311 (gated off on abort)
+    auto enqueue_units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { enqueue_unit(h, w, first); first = false; } };
+    auto phase_end = [&](int which) {
+        ProfScope p(w, VISFS_BA_K_PHASE_END);
+        if (which == 0) launch_phase_end(w.g, 0, 1, half2, w.stream);                               // :270-303
+        else launch_phase_end(w.g, 1, 0, 0, w.stream);                                              // :315-318
+    };
+    enqueue_units(half, true);                                                                      // :265
+    phase_end(0);
+    enqueue_units(half2, true);
+    phase_end(1);
+    int rc = VISFS_BA_OK;
+    for (int guard = 0;; ++guard) {
+        HIP_TRY(h, hipGetLastError());
+        rc = ws_read_state(h, w);
+        if (rc != VISFS_BA_OK) return rc;
+        const LmState& st = *w.h_state;
+        if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
+        if (st.ended >= 2 || st.status != 0) break;                                                // finished, or aborted by a chi2 guard
+        if (guard > 16 * h->prm.iterations + 32) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
+        if (!st.done) {
+            // rejected trials consumed units without finishing an iteration: top the phase up, then what follows it
+            enqueue_units(std::max(1, st.max_iter - st.phase_iter), false);
+            if (st.ended == 0) { phase_end(0); enqueue_units(half2, true); }
+            phase_end(1);
+        } else if (st.ended == 0) { phase_end(0); enqueue_units(half2, true); phase_end(1); }
+        else phase_end(1);
+    }
     if (stats) fill_stats(*w.h_state, stats);
     if (w.prof_mask) {
         const LmState& st = *w.h_state;

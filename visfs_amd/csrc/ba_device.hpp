@@ -65,6 +65,7 @@ struct LmState {
     int32_t spec_go;        // snapshot by k_backsub: this unit produced a trial state worth linearising
     int32_t spec_src;       // ... the estimate buffer holding it (sel ^ 1 at that time)
     int32_t spec_dst;       // ... the linearisation buffer to fill (lin_sel ^ 1 at that time)
+    int32_t ended;          // phase ends applied so far (0, 1, 2): k_eval / k_phase_end act only when the phase they close is done
 };
 
 // The outputs of a linearisation that the Schur complement and the back-substitution consume.  Two sets: while the LM decision

@@ -1611,10 +1611,12 @@ __global__ __launch_bounds__(256) void k_decide(const Src src) {
 // ================================================================= K10: per-edge chi2, outlier marking
 // Optimizer.cpp:270-303: computeActiveErrors; edges with chi2() > kernel->delta() (UNSQUARED) go to level 1.
 template <class Src>
-__global__ __launch_bounds__(256) void k_eval(const Src src, const int mark) {
+__global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, const int phase_just_done) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (st->status != 0) return;
+    // the host may enqueue a phase end before it knows that the phase is over (one state read per solve): act only then
+    if (phase_just_done >= 0 && (!st->done || st->ended != phase_just_done)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;
     double* red = smem + 12 * g.Np;
@@ -1671,6 +1673,7 @@ __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark) {
 // One workgroup: closes a phase (Optimizer.cpp:271-280 after phase 1, :315-318 after phase 2) and arms the next.
 // One thread: closes a phase (Optimizer.cpp:271-280 after phase 1, :315-318 after phase 2) and arms the next.
 __device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st, const double chi, const double nout, const int phase_just_done, const int next_max_iter) {
+    st->ended = phase_just_done + 1;
     if (phase_just_done == 0) {
         st->chi2_phase1 = chi; st->chi2_final = chi;
         if (st->max_iter <= 0) st->chi2_initial = chi;        // optimize(0): nothing linearised
@@ -1694,6 +1697,7 @@ __global__ __launch_bounds__(256) void k_phase_end(const Src src, const int phas
     const int nparts = (g.No + 255) / 256 + 1;          // partials written by k_eval
     LmState* st = g.st;
     if (st->status != 0) return;
+    if (!st->done || st->ended != phase_just_done) return;      // (same gate as k_eval, which does not modify the state)
     __shared__ double red[4];
     const int tid = threadIdx.x;
     double chi = 0.0, nout = 0.0;
@@ -1722,7 +1726,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
         if (restore) st->sel = 0;
         st->pcg_max = 0; st->pcg_timeout = 0;
-        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1;
+        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1; st->ended = 0;
         st->n_active[0] = st->n_active[1] = st->n_active[2] = st->n_active[3] = 0;
         st->phase = 0; st->max_iter = max_iter; st->phase_iter = 0; st->trial_q = 0;
         st->done = (max_iter <= 0) ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->solver_failed = 0;
@@ -2290,7 +2294,7 @@ static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, int o
 }
 template <class Src>
 static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
-    hipLaunchKernelGGL((k_eval<Src>), dim3(d.eval_blocks, B), dim3(256), lds_poses(d, 8), s, src, mark);
+    hipLaunchKernelGGL((k_eval<Src>), dim3(d.eval_blocks, B), dim3(256), lds_poses(d, 8), s, src, mark, phase_just_done);
     hipLaunchKernelGGL((k_phase_end<Src>), dim3(1, B), dim3(256), 0, s, src, phase_just_done, next_max_iter);
 }
 
