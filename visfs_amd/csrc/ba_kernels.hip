@@ -703,10 +703,15 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
 // W = [N ; [Pc]x N] (tile_core), so with P = Na D Nb^T (3x3) the 6x6 result is [P, P Xb^T ; Xa P, Xa P Xb^T] — rows of P
 // crossed with Pc_b, columns with Pc_a — and the b_s term is [v ; Pc_a x v] with v = Na (D b_l): about half the fp64 work of
 // forming both 6x3 tiles.  A lane without a pair (have = false) produces exact zeros.
+// ACC: ADD the contribution to G / gb (a lane's later pairs of a multi-pass chunk) instead of writing it — only the pair's own top
+// half (18 values, which its bottom half is built from) is live beside the accumulators, not a second 36 + 6.
+template <bool ACC>
 __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L, const int4 pr, const bool have, const bool diag, const Rt& Ti, const Rt& Tj,
                                            const double lambda, double G[36], double gb[6]) {
+    if (!ACC) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) gb[r] = 0.0;
+        for (int r = 0; r < 6; ++r) gb[r] = 0.0;
+    }
     const double* H = L.Hll + 6 * (size_t)pr.z;
     const double2* sa = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.x);
     const double2* sb = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.y);
@@ -740,22 +745,27 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
 #pragma unroll
         for (int c = 0; c < 3; ++c) P[3 * r + c] = Q[3 * r] * Nb[3 * c] + Q[3 * r + 1] * Nb[3 * c + 1] + Q[3 * r + 2] * Nb[3 * c + 2];   // P = Q Nb^T
     // top half: [P | rows of P crossed with Pc_b]
+    double T[18];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const double p0 = P[3 * r], p1 = P[3 * r + 1], p2 = P[3 * r + 2];
-        G[6 * r + 0] = p0; G[6 * r + 1] = p1; G[6 * r + 2] = p2;
-        G[6 * r + 3] = pb.y * p2 - pb.z * p1; G[6 * r + 4] = pb.z * p0 - pb.x * p2; G[6 * r + 5] = pb.x * p1 - pb.y * p0;
+        T[6 * r + 0] = p0; T[6 * r + 1] = p1; T[6 * r + 2] = p2;
+        T[6 * r + 3] = pb.y * p2 - pb.z * p1; T[6 * r + 4] = pb.z * p0 - pb.x * p2; T[6 * r + 5] = pb.x * p1 - pb.y * p0;
     }
+#pragma unroll
+    for (int q = 0; q < 18; ++q) { if (ACC) G[q] += T[q]; else G[q] = T[q]; }
     // bottom half: Pc_a crossed with the columns of the top half
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        const double t0 = G[c], t1 = G[6 + c], t2 = G[12 + c];
-        G[18 + c] = pa.y * t2 - pa.z * t1; G[24 + c] = pa.z * t0 - pa.x * t2; G[30 + c] = pa.x * t1 - pa.y * t0;
+        const double t0 = T[c], t1 = T[6 + c], t2 = T[12 + c];
+        const double u0 = pa.y * t2 - pa.z * t1, u1 = pa.z * t0 - pa.x * t2, u2 = pa.x * t1 - pa.y * t0;
+        if (ACC) { G[18 + c] += u0; G[24 + c] += u1; G[30 + c] += u2; } else { G[18 + c] = u0; G[24 + c] = u1; G[30 + c] = u2; }
     }
     if (diag) {
         const double v0 = Q[0] * B[0] + Q[1] * B[1] + Q[2] * B[2], v1 = Q[3] * B[0] + Q[4] * B[1] + Q[5] * B[2], v2 = Q[6] * B[0] + Q[7] * B[1] + Q[8] * B[2];
-        gb[0] = v0; gb[1] = v1; gb[2] = v2;
-        gb[3] = pa.y * v2 - pa.z * v1; gb[4] = pa.z * v0 - pa.x * v2; gb[5] = pa.x * v1 - pa.y * v0;
+        const double w0 = pa.y * v2 - pa.z * v1, w1 = pa.z * v0 - pa.x * v2, w2 = pa.x * v1 - pa.y * v0;
+        if (ACC) { gb[0] += v0; gb[1] += v1; gb[2] += v2; gb[3] += w0; gb[4] += w1; gb[5] += w2; }
+        else { gb[0] = v0; gb[1] = v1; gb[2] = v2; gb[3] = w0; gb[4] = w1; gb[5] = w2; }
     }
 }
 
@@ -776,19 +786,14 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
     const int4 pr = have ? g.blk_pairs[e] : make_int4(0, 0, 0, 0);
     double G[36], gb[6];
-    schur_pair(g, L, pr, have, diag, Ti, Tj, lambda, G, gb);
+    schur_pair<false>(g, L, pr, have, diag, Ti, Tj, lambda, G, gb);
     if (MULTI) {
         // chunks of more than 64 pairs: the lane adds its later pairs (e + 64, e + 128, ...) serially, in that fixed order, so one
         // reduce-scatter serves the whole chunk (the cross-lane reduction costs about as much VALU time as a pair product)
         for (int e2 = e + 64; e2 - lane < e_end; e2 += 64) {
             const bool have2 = e2 < e_end;
             const int4 pr2 = have2 ? g.blk_pairs[e2] : make_int4(0, 0, 0, 0);
-            double G2[36], gb2[6];
-            schur_pair(g, L, pr2, have2, diag, Ti, Tj, lambda, G2, gb2);
-#pragma unroll
-            for (int q = 0; q < 36; ++q) G[q] += G2[q];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) gb[r] += gb2[r];
+            schur_pair<true>(g, L, pr2, have2, diag, Ti, Tj, lambda, G, gb);
         }
     }
     // two halves of 21 sums (block rows 0-2 + b_s 0-2, block rows 3-5 + b_s 3-5): halves the live accumulator registers
