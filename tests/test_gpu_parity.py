@@ -538,3 +538,57 @@ def test_handle_reuse_across_shapes(olib):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+# ---------------------------------------------------------------- the speculative unit, chunk passes, the WIDE PCG kernel
+def _stats_tuple(st):
+    return (list(st.iterations_run), list(st.trials_run), st.pcg_iterations, st.n_outliers, st.chi2_initial, st.chi2_phase1, st.chi2_final,
+            [st.trace_lambda[i] for i in range(st.n_trace)], [st.trace_chi2[i] for i in range(st.n_trace)])
+
+
+@pytest.mark.parametrize("case", ["C1", "PROD", "LASER", "HARD", "GN"])
+def test_speculative_unit_equals_gated_unit(olib, monkeypatch, case):
+    """the unit that linearises the trial state beside the LM decision (and, with odometry / laser edges, inside
+    k_backsub) performs the arithmetic of the gated unit — every output, counter and trace entry must be bit-identical,
+    rejected trials (HARD) and Gauss-Newton included."""
+    kw = dict(iterations=20, solver=2)
+    if case == "LASER":
+        w = synth.make_laser_window(with_visual=True, n_points=400)
+    elif case == "HARD":
+        w = hard_window()
+    elif case == "GN":
+        w = synth.make_window("C1"); kw["trust_region"] = 1
+    else:
+        w = synth.make_window(case)
+    _, rc0, st0, out0 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="0"), **kw)
+    _, rc1, st1, out1 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="1"), **kw)
+    assert rc0 == rc1 == abi.OK
+    assert _stats_tuple(st0) == _stats_tuple(st1)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out0, out1))
+    if case == "HARD":
+        assert sum(st0.trials_run) > sum(st0.iterations_run)          # the window really rejects trials
+
+
+def test_schur_chunk_passes_agree_to_rounding(olib, monkeypatch):
+    # 64 / 128 / 192 pairs per chunk: same sums in a different association
+    w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11)
+    ref = None
+    for passes in ("1", "2", "3"):
+        info, rc, st, out = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SCH_PASSES=passes), iterations=10, solver=2)
+        assert rc == abi.OK
+        if ref is None:
+            ref = (info, st, out)
+            continue
+        assert info["n_schur_chunks"] < ref[0]["n_schur_chunks"]
+        assert list(st.iterations_run) == list(ref[1].iterations_run)
+        assert rel_err(out[0], ref[2][0]) < 1e-11 and rel_err(out[1], ref[2][1]) < 1e-11
+        assert abs(st.chi2_final - ref[1].chi2_final) <= 1e-11 * ref[1].chi2_final
+
+
+def test_wide_pcg_kernel_matches_oracle(olib):
+    """More than 64 free poses: the vector recurrences of the persistent PCG run on all four waves (k_pcg WIDE)."""
+    w = synth.make_window("custom", n_kf=100, n_lm=3000, n_obs=24000, seed=21)
+    o, s, gb = make_pair(olib, w, iterations=10, solver=2)
+    assert s.describe()["n_free_poses"] > 64
+    check_optimize(o, s, pose_tol=1e-9)
+    s.close(); o.close()
