@@ -103,7 +103,7 @@ static void prof_harvest(Workspace& w) {
 // device / pinned scratch of a batched run: the DeviceGraph array the kernels index with blockIdx.y, and the gathered LM states
 struct BatchScratch {
     DeviceGraph* d_graphs = nullptr; size_t cap_graphs = 0;
-    int* d_states = nullptr; int* h_states = nullptr; size_t cap_states = 0;
+    size_t cap_states = 0;
     LmState* d_lm = nullptr; LmState* h_lm = nullptr;      // [cap_states] whole LM states, gathered at the end of a run
     DeviceGraph* d_all = nullptr; size_t cap_all = 0;      // every graph of a resident batch (visfs_ba_batch_upload), for the one-launch reset
     std::vector<DeviceGraph> host_graphs;                  // source of the asynchronous H2D copy of d_graphs: must outlive it
@@ -776,37 +776,7 @@ int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win
     return finish_window(h, w, win, r, pk, rc, st);
 }
 
-// ------------------------------------------------------------------ batches of independent windows
-// Windows that share the launch geometry class run as ONE sequence of launches with blockIdx.y = window: the kernels of a
-// unit serve every resident window, each gated by its own LmState.  `members` index into ws[].
-int batch_read_states(visfs_ba_handle* h, BatchScratch& bs, int B, hipStream_t stream) {
-    launch_gather_state(bs.d_graphs, B, bs.d_states, stream);
-    HIP_TRY(h, hipMemcpyAsync(bs.h_states, bs.d_states, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(h, hipStreamSynchronize(stream));
-    return VISFS_BA_OK;
-}
 
-int batch_run_phase(visfs_ba_handle* h, BatchScratch& bs, int B, const LaunchDims& d, bool small_solve, int max_iter, hipStream_t stream) {
-    if (max_iter <= 0) return VISFS_BA_OK;
-    int remaining = max_iter, guard = 0;
-    bool first = true;
-    while (true) {
-        for (int u = 0; u < remaining; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, stream); first = false; }
-        HIP_TRY(h, hipGetLastError());
-        int rc = batch_read_states(h, bs, B, stream);
-        if (rc != VISFS_BA_OK) return rc;
-        bool all_done = true;
-        int most = 1;
-        for (int b = 0; b < B; ++b) {
-            if (bs.h_states[4 * b + 1] == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
-            if (!bs.h_states[4 * b]) { all_done = false; most = std::max(most, max_iter - bs.h_states[4 * b + 2]); }
-        }
-        if (all_done) break;
-        remaining = most;                                     // rejected trials consumed units without finishing an iteration
-        if (++guard > 16 * max_iter + 16) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
-    }
-    return VISFS_BA_OK;
-}
 
 // Optimizer.cpp:261-318 for every member at once.  On return every member's LmState is in ws[i]->h_state.
 int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Workspace*>& ws, const std::vector<int>& members, hipStream_t stream) {
@@ -820,13 +790,9 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         bs.cap_graphs = B;
     }
     if (bs.cap_states < (size_t)B) {
-        if (bs.d_states) (void)hipFree(bs.d_states);
-        if (bs.h_states) (void)hipHostFree(bs.h_states);
         if (bs.d_lm) (void)hipFree(bs.d_lm);
         if (bs.h_lm) (void)hipHostFree(bs.h_lm);
-        bs.d_states = nullptr; bs.h_states = nullptr; bs.d_lm = nullptr; bs.h_lm = nullptr; bs.cap_states = 0;
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_states), (size_t)B * 4 * sizeof(int)));
-        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bs.h_states), (size_t)B * 4 * sizeof(int), hipHostMallocDefault));
+        bs.d_lm = nullptr; bs.h_lm = nullptr; bs.cap_states = 0;
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_lm), (size_t)B * sizeof(LmState)));
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bs.h_lm), (size_t)B * sizeof(LmState), hipHostMallocDefault));
         bs.cap_states = B;
@@ -846,18 +812,36 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     launch_reset_batch(bs.d_graphs, B, d, half, h->prm.trust_region == 1, 0, stream);
     if (fused) {
         launch_small_optimize_batch(bs.d_graphs, B, h->prm.solver, half, stream);
-    } else {
-        int rc = batch_run_phase(h, bs, B, d, small_solve, half, stream);                       // :265
-        if (rc != VISFS_BA_OK) return rc;
-        launch_phase_end_batch(bs.d_graphs, B, d, 0, 1, half, stream);                           // :270-303
-        rc = batch_run_phase(h, bs, B, d, small_solve, (h->prm.robust_kernel_delta > 0.0) ? half : 0, stream);   // :310-311
-        if (rc != VISFS_BA_OK) return rc;
-        launch_phase_end_batch(bs.d_graphs, B, d, 1, 0, 0, stream);                              // :315-318
     }
-    launch_gather_lm(bs.d_graphs, B, bs.d_lm, stream);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(bs.h_lm, bs.d_lm, (size_t)B * sizeof(LmState), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(h, hipStreamSynchronize(stream));
+    // As for a single window (ws_optimize): both phases and their device-gated ends are enqueued up front and the whole LM states
+    // come back in ONE copy; windows that rejected trials are topped up from what comes back.  Every launch is gated per window,
+    // so the same sequence is safe for windows at different points of the schedule.
+    const int half2 = (h->prm.robust_kernel_delta > 0.0) ? half : 0;                                // :310-311
+    auto units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, stream); first = false; } };
+    auto phase_end = [&](int which) {
+        if (which == 0) launch_phase_end_batch(bs.d_graphs, B, d, 0, 1, half2, stream);             // :270-303
+        else launch_phase_end_batch(bs.d_graphs, B, d, 1, 0, 0, stream);                            // :315-318
+    };
+    if (!fused) { units(half, true); phase_end(0); units(half2, true); phase_end(1); }              // :265
+    for (int guard = 0;; ++guard) {
+        launch_gather_lm(bs.d_graphs, B, bs.d_lm, stream);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(bs.h_lm, bs.d_lm, (size_t)B * sizeof(LmState), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        if (fused) break;
+        bool all_finished = true;
+        int top_up = 0;
+        for (int b = 0; b < B; ++b) {
+            const LmState& st = bs.h_lm[b];
+            if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
+            if (st.ended >= 2 || st.status != 0) continue;
+            all_finished = false;
+            if (!st.done) top_up = std::max(top_up, std::max(1, st.max_iter - st.phase_iter));
+        }
+        if (all_finished) break;
+        if (guard > 16 * h->prm.iterations + 32) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
+        units(top_up, false); phase_end(0); units(half2, true); phase_end(1);
+    }
     for (int b = 0; b < B; ++b) *ws[members[b]]->h_state = bs.h_lm[b];
     return VISFS_BA_OK;
 }
@@ -899,8 +883,6 @@ void visfs_ba_destroy(visfs_ba_handle* h) {
     ws_release(h->ws);
     for (Workspace* w : h->batch) { ws_release(*w); delete w; }
     if (h->scratch.d_graphs) (void)hipFree(h->scratch.d_graphs);
-    if (h->scratch.d_states) (void)hipFree(h->scratch.d_states);
-    if (h->scratch.h_states) (void)hipHostFree(h->scratch.h_states);
     if (h->scratch.d_lm) (void)hipFree(h->scratch.d_lm);
     if (h->scratch.h_lm) (void)hipHostFree(h->scratch.h_lm);
     if (h->scratch.d_all) (void)hipFree(h->scratch.d_all);

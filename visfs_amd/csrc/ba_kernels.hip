@@ -2370,13 +2370,6 @@ void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, i
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s) {
     hipLaunchKernelGGL((k_small_optimize<Many>), dim3(1, B), dim3(SM_T), 0, s, Many{ gs }, solver, half);
 }
-// The words the host needs to drive a batch: (done, status, phase_iter, mode) of every window, contiguous.
-__global__ void k_gather_state(const DeviceGraph* gs, int B, int* out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const LmState* st = gs[b].st;
-    out[4 * b] = st->done; out[4 * b + 1] = st->status; out[4 * b + 2] = st->phase_iter; out[4 * b + 3] = st->mode;
-}
 // Every window's whole LmState, contiguous (one D2H copy instead of one per window).
 __global__ void k_gather_lm(const DeviceGraph* gs, int B, LmState* out) {
     const int b = blockIdx.x;
@@ -2387,9 +2380,6 @@ __global__ void k_gather_lm(const DeviceGraph* gs, int B, LmState* out) {
 }
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_lm, dim3(B), dim3(64), 0, s, gs, B, out);
-}
-void launch_gather_state(const DeviceGraph* gs, int B, int* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_state, dim3((B + 63) / 64), dim3(64), 0, s, gs, B, out);
 }
 
 bool small_path_fits(const DeviceGraph& g) {

@@ -38,7 +38,6 @@ void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int m
 void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s);
 void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
-void launch_gather_state(const DeviceGraph* gs, int B, int* out, hipStream_t s);
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s);
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
 
