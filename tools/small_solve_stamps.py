@@ -6,7 +6,7 @@ import numpy as np
 from visfs_amd import abi, backend, synth
 backend.LIB_PATH = os.path.join(ROOT, "visfs_amd", "lib", "libvisfs_ba_hip_stamps.so")
 lib = backend.load_library()
-for cfg, solver in (("PROD", 0), ("PROD", 2), ("C1", 0)):
+for cfg, solver in (("PROD", 0), ("PROD", 2), ("C1", 0), ("C1", 2)):
     w = synth.make_window(cfg); prm = abi.default_params(iterations=10, solver=solver)
     gb, *_ = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
     s = backend.Solver(prm); s.upload(gb)

@@ -772,9 +772,10 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
 // One wavefront, one chunk (<= 64 pairs of one block, MULTI: <= DeviceGraph::sch_chunk): shared by k_schur_partial and the
 // fused small-window kernel.
 template <bool MULTI>
-__device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& L, const int ch, const int lane, const double lambda, const double* __restrict__ pose) {
-    // one descriptor load, then the pair list and the two poses can be fetched together (no dependent index chain)
-    const int4 dsc = g.sch_desc[ch];
+__device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& L, const int ch, const int lane, const double lambda, const double* __restrict__ pose,
+                                            const int4 dsc, const int4 pr) {
+    // (dsc = sch_desc[ch] and pr = the lane's first pair come from the caller: neither depends on the LM state, so a kernel can
+    // have them in flight while its gate is still being read)
     const int e = dsc.x + lane, e_end = dsc.y;
     const bool diag = (dsc.z == dsc.w);
     const Rt Ti = pose_to_Rt(pose + POSE_STRIDE * dsc.z);
@@ -784,7 +785,6 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     int off0 = 0, len0 = 21, off1 = 0, len1 = 21;
     const bool have = e < e_end;
     // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
-    const int4 pr = have ? g.blk_pairs[e] : make_int4(0, 0, 0, 0);
     double G[36], gb[6];
     schur_pair<false>(g, L, pr, have, diag, Ti, Tj, lambda, G, gb);
     if (MULTI) {
@@ -813,12 +813,17 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
 }
 
+template <bool MULTI>
+__device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& L, const int ch, const int lane, const double lambda, const double* __restrict__ pose) {
+    const int4 dsc = g.sch_desc[ch];
+    const int e = dsc.x + lane;
+    schur_chunk<MULTI>(g, L, ch, lane, lambda, pose, dsc, e < dsc.y ? g.blk_pairs[e] : make_int4(0, 0, 0, 0));
+}
+
 template <bool MULTI, class Src>
 __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src src) {
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
-    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     const int lane = threadIdx.x & 63;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
     // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
@@ -829,7 +834,14 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int ch = wg * 4 + (threadIdx.x >> 6);
     if (ch >= g.n_sch) return;
-    schur_chunk<MULTI>(g, L, ch, lane, st->lambda, g.pose[st->sel]);
+    // the chunk descriptor and the lane's first pair do not depend on the LM state: fetch them BEFORE the gate, so the gate's own
+    // load (a cold L2 round trip at the head of every kernel) overlaps two levels of the index chain instead of preceding them
+    const int4 dsc = g.sch_desc[ch];
+    const int e0 = dsc.x + lane;
+    const int4 pr = e0 < dsc.y ? g.blk_pairs[e0] : make_int4(0, 0, 0, 0);
+    if (!(st->mode & MODE_TRIAL)) return;
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
+    schur_chunk<MULTI>(g, L, ch, lane, st->lambda, g.pose[st->sel], dsc, pr);
 }
 
 // k_schur_finalize: one wavefront per stored block:
@@ -837,6 +849,26 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
 //   b_s_i = b_p_i - ..., Hpp_ii / b_p_i (for computeScale) and Minv_i = S_ii^-1 (block-Jacobi preconditioner).
 // Poses without any active edge are outside g2o's active set: their block is pinned to I (dx = 0).
 // It also clears the hand-off words of the persistent PCG that follows (one zeroing per damped solve).
+// 36-lane Gauss-Jordan inverse of an SPD 6x6 block (no pivoting needed): lane 6 r + c holds entry (r, c) going in and the entry
+// of the inverse coming out; lanes 36..63 pass anything.
+__device__ __forceinline__ double gauss_jordan_6x6(const double val, const int lane) {
+    const int r = lane / 6, c = lane % 6;
+    double a = (lane < 36) ? val : 0.0;
+    double v = (lane < 36 && r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int rr = lane < 36 ? r : 0, cc = lane < 36 ? c : 0;
+        const double p = __shfl(a, k * 6 + k, 64);
+        const double rk_a = __shfl(a, k * 6 + cc, 64);
+        const double rk_v = __shfl(v, k * 6 + cc, 64);
+        const double ck = __shfl(a, rr * 6 + k, 64);
+        const double ip = 1.0 / p;
+        if (rr == k) { a = rk_a * ip; v = rk_v * ip; }
+        else { a -= ck * (rk_a * ip); v -= ck * (rk_v * ip); }
+    }
+    return v;
+}
+
 // One wavefront, one stored block of S: shared by k_schur_finalize and the fused small-window kernel.
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
     {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
@@ -878,20 +910,7 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
         g.bp[6 * (size_t)i + (lane - 36)] = hv;
         g.bs[6 * (size_t)i + (lane - 36)] = pin ? 0.0 : (hv - part);
     }
-    // 36-lane Gauss-Jordan inverse of the SPD diagonal block (no pivoting needed)
-    double a = (lane < 36) ? val : 0.0;
-    double v = on_diag ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int rr = lane < 36 ? r : 0, cc = lane < 36 ? c : 0;
-        const double p = __shfl(a, k * 6 + k, 64);
-        const double rk_a = __shfl(a, k * 6 + cc, 64);
-        const double rk_v = __shfl(v, k * 6 + cc, 64);
-        const double ck = __shfl(a, rr * 6 + k, 64);
-        const double ip = 1.0 / p;
-        if (rr == k) { a = rk_a * ip; v = rk_v * ip; }
-        else { a -= ck * (rk_a * ip); v -= ck * (rk_v * ip); }
-    }
+    const double v = gauss_jordan_6x6(val, lane);
     if (lane < 36) g.Minv[36 * (size_t)i + lane] = v;
     if (b == 0 && lane == 0) {
         st->pcg_res_in = st->pcg_residual;
@@ -1965,18 +1984,73 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
 #endif
     const int n6 = 6 * g.Npf;
     SS_STAMP(0);
-    for (int b = wave; b < g.n_blk; b += 8) schur_block(g, L, st, b, lane);
-    SS_STAMP(1);
+    // S, b_s and the Jacobi preconditioner straight into LDS — the arithmetic of schur_block (same sums, same order) laid out flat:
+    // a thread per (block, entry) sums the chunk partials with all its loads in flight, instead of a wave per block walking
+    // dependent loads block after block (that loop was 7.4 us of this 15 us kernel on the production window).
+    __shared__ double sHv[(SM_MAX_N6 / 6) * 42], sPt[(SM_MAX_N6 / 6) * 42];       // diagonal blocks: Hpp | b_p entries and their partial sums
+    __shared__ int sDiag[SM_MAX_N6 / 6];                                          // stored block id of (a, a)
     for (int t = tid; t < n6 * SM_LD; t += 512) sA[t] = 0.0;
     __syncthreads();
-    for (int t = tid; t < g.n_blk * 36; t += 512) {
-        const int b = t / 36, q = t - 36 * b, r = q / 6, c = q - 6 * r;
-        const int i = g.blk_i[b], j = g.blk_j[b];
-        const double v = g.S[t];
-        sA[(6 * i + r) * SM_LD + 6 * j + c] = v;
-        if (i != j) sA[(6 * j + c) * SM_LD + 6 * i + r] = v;
+    const double lambda = st->lambda;
+    for (int t = tid; t < g.n_blk * 42; t += 512) {
+        const int b = t / 42, q = t - 42 * b;
+        const int4 bd = g.blk_desc[2 * b];           // (first chunk, last + 1, first odometry entry, last + 1)
+        const int4 be = g.blk_desc[2 * b + 1];       // (i, j, first pose-major chunk of i, last + 1)
+        const int i = be.x, j = be.y;
+        const bool diag = (i == j);
+        if (!diag && q >= 36) continue;
+        double part = 0.0;
+#pragma unroll 4
+        for (int ch = bd.x; ch < bd.y; ++ch) part += g.sch_part[42 * (size_t)ch + q];
+        if (!diag) {
+            const int r = q / 6, c = q - 6 * r;
+            double base = 0.0;
+            for (int n = bd.z; n < bd.w; ++n) {
+                const int code = g.blk_odo[n];
+                base += L.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : q)];
+            }
+            const double v = base - part;
+            g.S[36 * (size_t)b + q] = v;
+            sA[(6 * i + r) * SM_LD + 6 * j + c] = v;
+            sA[(6 * j + c) * SM_LD + 6 * i + r] = v;
+        } else {
+            sHv[42 * i + q] = hpp_entry_r(g, L, q, be.z, be.w, bd.z, bd.w);
+            sPt[42 * i + q] = part;
+            if (q == 0) sDiag[i] = b;
+        }
     }
-    for (int t = tid; t < n6; t += 512) sb[t] = g.bs[t];
+    __syncthreads();
+    for (int t = tid; t < g.Npf * 42; t += 512) {
+        const int a = t / 42, q = t - 42 * a;
+        const double hv = sHv[t], part = sPt[t];
+        const double* hd = sHv + 42 * a;
+        // poses without any active edge are outside g2o's active set: their block is pinned to I (dx = 0)
+        const bool pin = hd[0] == 0.0 && hd[7] == 0.0 && hd[14] == 0.0 && hd[21] == 0.0 && hd[28] == 0.0 && hd[35] == 0.0;
+        if (q < 36) {
+            const int r = q / 6, c = q - 6 * r;
+            const double val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? lambda : 0.0) - part);
+            g.S[36 * (size_t)sDiag[a] + q] = val;
+            g.Hpp[36 * (size_t)a + q] = hv;
+            sA[(6 * a + r) * SM_LD + 6 * a + c] = val;
+        } else {
+            const double bsv = pin ? 0.0 : (hv - part);
+            g.bp[6 * (size_t)a + (q - 36)] = hv;
+            g.bs[6 * (size_t)a + (q - 36)] = bsv;
+            sb[6 * a + (q - 36)] = bsv;
+        }
+    }
+    if (tid == 0) {
+        st->pcg_res_in = st->pcg_residual;
+        st->n_active[1] += 1;
+        if (st->mode & MODE_LIN) st->n_active[0] += 1;
+    }
+    __syncthreads();
+    SS_STAMP(1);
+    for (int a = wave; a < g.Npf; a += 8) {                       // Minv_a = S_aa^-1 (block-Jacobi preconditioner)
+        const double v = gauss_jordan_6x6(lane < 36 ? sA[(6 * a + lane / 6) * SM_LD + 6 * a + lane % 6] : 0.0, lane);
+        if (lane < 36) g.Minv[36 * (size_t)a + lane] = v;
+    }
+    __threadfence_block();
     __syncthreads();
     SS_STAMP(2);
     if (wave == 0) {
