@@ -7,6 +7,7 @@
 // A synthetic stereo front end (a camera flying through a random point cloud) stands in for the tracker.  Per frame:
 // insert the signature → build the flat window (zero copy) → solve → apply the result → drop a signature.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
     double x = 0, yaw = 0;                                                       // planar robot: forward motion with a little yaw
     double wheel[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
     int solved = 0, culled = 0, blocked = 0;
+    std::vector<double> stepMs, solveMs;              // build + solve + apply, and the solve alone, per BA step
     double lastChi = 0;
     for (int f = 1; f <= frames; ++f) {
         const double dyaw = 0.02 * rng.normal(), step = 0.12 + 0.01 * rng.normal();
@@ -96,6 +98,7 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < sid.size(); ++k) { prevUv.push_back(suv[4 * k]); prevUv.push_back(suv[4 * k + 1]); }
 
         if (visfs_window_available(window)) {
+            const auto t0 = std::chrono::steady_clock::now();
             visfs_ba_window w;                                                    // pointers into the container's buffers: zero copy
             visfs_window_build(window, Trc, fx, fy, cx, cy, baseline, 2, 1, &w);
             std::vector<uint64_t> outIds(w.n_poses + 1), outF(w.n_refs + 1), outP(w.n_refs + 1), errorVertex(w.n_refs + 1);
@@ -103,20 +106,28 @@ int main(int argc, char** argv) {
             visfs_ba_result r{};
             r.pose_ids_out = outIds.data(); r.pose_Twr_out = outT.data();
             r.outlier_capacity = w.n_refs + 1; r.outlier_feature = outF.data(); r.outlier_pose = outP.data();
+            const auto t1 = std::chrono::steady_clock::now();
             const int status = visfs_ba_solve_window(ba, &w, &r);
+            const auto t2 = std::chrono::steady_clock::now();
             if (status != VISFS_BA_OK) { std::fprintf(stderr, "frame %d: status %d (%s)\n", f, status, visfs_ba_last_error(ba)); return 5; }
             if (r.n_poses_out == 6) {                                             // Estimator.cpp:275: only a full window is written back
                 int32_t nErr = 0;
                 visfs_window_apply(window, &r, errorVertex.data(), (int32_t)errorVertex.size(), &nErr);
                 ++solved; culled += r.n_outliers; blocked += nErr; lastChi = r.chi2_final;
             }
+            const auto t3 = std::chrono::steady_clock::now();
+            if (f >= 10) {                                                        // (the first calls pay allocation and module load)
+                stepMs.push_back(std::chrono::duration<double, std::milli>(t3 - t0).count());
+                solveMs.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
+            }
         }
         visfs_window_remove(window);
     }
     int32_t ns = 0, nf = 0, no = 0;
     visfs_window_counts(window, &ns, &nf, &no);
-    std::printf("{\"frames\": %d, \"solved\": %d, \"outliers\": %d, \"blocked\": %d, \"signatures\": %d, \"features\": %d, \"observations\": %d, \"last_chi2\": %.6g}\n",
-                frames, solved, culled, blocked, ns, nf, no, lastChi);
+    auto median = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    std::printf("{\"frames\": %d, \"solved\": %d, \"outliers\": %d, \"blocked\": %d, \"signatures\": %d, \"features\": %d, \"observations\": %d, \"last_chi2\": %.6g, \"ba_step_ms_median\": %.4f, \"solve_window_ms_median\": %.4f}\n",
+                frames, solved, culled, blocked, ns, nf, no, lastChi, median(stepMs), median(solveMs));
     visfs_ba_destroy(ba);
     visfs_window_destroy(window);
     return 0;
