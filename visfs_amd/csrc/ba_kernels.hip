@@ -1272,22 +1272,33 @@ __device__ __forceinline__ void chol_diag_block(const DeviceGraph& g, const int 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // left-looking: s_r = A[r][c] - sum_{k<c} L[r][k] L[c][k] with the lane's own row in registers and row c read from LDS as
-    // broadcasts (written there column by column), the pivot by a readlane, rsq + two Newton steps instead of sqrt + division:
-    // one wave barrier per column (the right-looking form with an IEEE sqrt / division pair cost 0.65 us per column)
+    // broadcasts, the pivot by a readlane, rsq + two Newton steps instead of sqrt + division (the right-looking form with an IEEE
+    // sqrt / division pair cost 0.65 us per column).  Two columns per step: column c + 1 needs column c only through
+    // L[c+1][c], a readlane from lane c + 1 — one LDS write -> fence -> barrier -> read round trip per PAIR of columns; every sum
+    // in the order of the one-column form, so the factor is bit-identical.
     bool bad = false;
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double s0 = a[c], s1 = 0.0;
+    for (int c = 0; c < CH_NB; c += 2) {
+        double s0 = a[c], s1 = 0.0, t0 = a[c + 1], t1 = 0.0;
 #pragma unroll
-        for (int k = 0; k + 1 < c; k += 2) { s0 -= a[k] * sL[c][k]; s1 -= a[k + 1] * sL[c][k + 1]; }
-        if (c & 1) s0 -= a[c - 1] * sL[c][c - 1];
+        for (int k = 0; k + 1 < c; k += 2) {
+            s0 -= a[k] * sL[c][k]; s1 -= a[k + 1] * sL[c][k + 1];
+            t0 -= a[k] * sL[c + 1][k]; t1 -= a[k + 1] * sL[c + 1][k + 1];
+        }
         const double sv = s0 + s1;
         const double p = readlane_f64(sv, c);
         if (!(p > 0.0) || !(p <= DBL_MAX)) bad = true;
         const double inv = fast_rsqrt(p);
         a[c] = (r >= c) ? sv * inv : 0.0;                              // r == c: p / sqrt(p) = sqrt(p)
-        if (act) sL[r][c] = a[c];
-        if (r == c && act) sInv[c] = inv;
+        t0 -= a[c] * readlane_f64(a[c], c + 1);                        // the term the one-column form adds last
+        const double tv = t0 + t1;
+        const double q = readlane_f64(tv, c + 1);
+        if (!(q > 0.0) || !(q <= DBL_MAX)) bad = true;
+        const double inv1 = fast_rsqrt(q);
+        a[c + 1] = (r >= c + 1) ? tv * inv1 : 0.0;
+        if (act) { sL[r][c] = a[c]; sL[r][c + 1] = a[c + 1]; }
+        if (act && r == c) sInv[c] = inv;
+        if (act && r == c + 1) sInv[c + 1] = inv1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1937,14 +1948,22 @@ __device__ __forceinline__ bool sm_cholesky_factor_reg(const int n, double* __re
 #pragma unroll
     for (int c = 0; c < N; ++c) a[c] = (act && c <= r && c < n) ? sA[r * SM_LD + c] : 0.0;
     bool failed = false;
+    // Two columns per step: column c + 1 needs column c only through L[c+1][c], which lane c + 1 holds in a register by then (one
+    // readlane) — so the LDS write -> fence -> barrier -> broadcast-read round trip (~200 of a column's ~640 fixed cycles) is
+    // paid once per PAIR of columns.  Sums are taken in the order of the one-column form: the factor is bit-identical.
+    // (Four columns per step: no faster at order 30, twice as slow at order 54 — eight accumulators beside the 64-entry row.)
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
+    for (int c = 0; c < N; c += 2) {
         if (c < n && !failed) {                                   // uniform
             const double* __restrict__ Ac = sA + c * SM_LD;
-            double s0 = a[c], s1 = 0.0;
+            const double* __restrict__ Ad = sA + (c + 1) * SM_LD;
+            const bool two = (c + 1 < n);                        // uniform
+            double s0 = a[c], s1 = 0.0, t0 = a[c + 1], t1 = 0.0;
 #pragma unroll
-            for (int k = 0; k + 1 < c; k += 2) { s0 -= a[k] * Ac[k]; s1 -= a[k + 1] * Ac[k + 1]; }
-            if (c & 1) s0 -= a[c - 1] * Ac[c - 1];
+            for (int k = 0; k + 1 < c; k += 2) {
+                s0 -= a[k] * Ac[k]; s1 -= a[k + 1] * Ac[k + 1];
+                t0 -= a[k] * Ad[k]; t1 -= a[k + 1] * Ad[k + 1];
+            }
             const double sv = s0 + s1;
             const double p = readlane_f64(sv, c);
             if (!(p > 0.0) || !(p <= DBL_MAX)) failed = true;
@@ -1952,6 +1971,17 @@ __device__ __forceinline__ bool sm_cholesky_factor_reg(const int n, double* __re
                 const double l = sv * fast_rsqrt(p);
                 a[c] = (r >= c) ? l : 0.0;
                 if (act && r >= c) sA[r * SM_LD + c] = l;
+                if (two) {
+                    t0 -= a[c] * readlane_f64(a[c], c + 1);     // L[r][c] L[c+1][c]: the term the one-column form adds last
+                    const double tv = t0 + t1;
+                    const double q = readlane_f64(tv, c + 1);
+                    if (!(q > 0.0) || !(q <= DBL_MAX)) failed = true;
+                    else {
+                        const double m = tv * fast_rsqrt(q);
+                        a[c + 1] = (r >= c + 1) ? m : 0.0;
+                        if (act && r >= c + 1) sA[r * SM_LD + c + 1] = m;
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
