@@ -49,6 +49,7 @@ struct Workspace {
     bool batch_member = false;                     // one of visfs_ba_solve_batch / visfs_ba_batch_upload's windows (shares its launches)
     bool fused = false;                            // the resident window runs on k_small_optimize
     bool spec = false;                             // units end with the speculative linearisation + LM decision launch
+    int extra_units[2] = { 0, 0 };                 // rejected trials per phase of the previous solve: units enqueued on top of `half`
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
@@ -615,9 +616,11 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
         if (which == 0) launch_phase_end(w.g, 0, 1, half2, w.stream);                               // :270-303
         else launch_phase_end(w.g, 1, 0, 0, w.stream);                                              // :315-318
     };
-    enqueue_units(half, true);                                                                      // :265
+    // (a window that rejected trials last time — an estimator's consecutive frames behave alike — gets that many units more up
+    // front: a gated no-op unit costs ~7 us, the state read it saves ~25 us plus the bubble behind it)
+    enqueue_units(half + w.extra_units[0], true);                                                   // :265
     phase_end(0);
-    enqueue_units(half2, true);
+    enqueue_units(half2 > 0 ? half2 + w.extra_units[1] : 0, true);
     phase_end(1);
     int rc = VISFS_BA_OK;
     for (int guard = 0;; ++guard) {
@@ -636,6 +639,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
         } else if (st.ended == 0) { phase_end(0); enqueue_units(half2, true); phase_end(1); }
         else phase_end(1);
     }
+    for (int ph = 0; ph < 2; ++ph) w.extra_units[ph] = std::min(10, std::max(0, w.h_state->trials_run[ph] - w.h_state->iterations_run[ph]));
     if (stats) fill_stats(*w.h_state, stats);
     if (w.prof_mask) {
         const LmState& st = *w.h_state;
