@@ -182,6 +182,20 @@ def main():
         "roofline_other_kernels": roofline_kernels,
         "kernel_us_per_step_calibration": {k: round(1e3 * v["total_ms"] / 3, 2) for k, v in calib.items()},
     }
+    if last is not None and args.solver == 2:
+        # whole-iteration view: bytes per LM iteration with the measured trials per iteration t and PCG iterations per
+        # solve k, against the cache-agnostic floor (bytes / 8 TB/s); rank 0's window stands for all (same shape)
+        its = max(1, last.iterations_run[0] + last.iterations_run[1])
+        tr = max(1, last.trials_run[0] + last.trials_run[1])
+        t, k = tr / its, last.pcg_iterations / tr
+        No, Nl, Np, nb = d["n_obs"], d["n_points"], d["n_poses"], d["n_blk"]
+        byts = 256 * No + 96 * Nl + 336 * Np + t * (408 * No + 264 * Nl + 160 * Np + 288 * nb * (1 + k) + 192 * k * Np)
+        rate = byts * (total_iters / elapsed) / 1e9
+        out["iteration_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_iteration": int(byts), "trials_per_iteration": round(t, 3),
+                                     "pcg_iterations_per_solve": round(k, 3), "achieved": round(rate, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(rate / 8000.0, 4), "floor_us_per_iteration": round(byts / 8e6, 2),
+                                     "window_us_per_iteration": round(1e6 * elapsed * world * B / total_iters, 2),
+                                     "aggregate_us_per_iteration_per_gpu": round(1e6 * elapsed * world / total_iters, 2)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, prm)
         # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
