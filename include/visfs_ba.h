@@ -245,6 +245,14 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
 /* Copies a stage buffer to host memory as fp64 in the layout documented above. */
 int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles);
 
+/* Host-only hook (no device needed): ONE optimize(n_iter) phase of the LM / Gauss-Newton control (K9, the device-side state
+ * machine's own functions compiled for the host) driven by scripted trial outcomes — trial t returns (temp_chi[t], scale[t] =
+ * computeScale() without the +1e-3, ok[t]); the last entry repeats if the schedule asks for more.  Fills stats->trace_*,
+ * iterations_run[0], trials_run[0], chi2_final (committed chi2); returns the trials consumed.  Checks the schedule of
+ * [g2o-upstream] OptimizationAlgorithmLevenberg::solve, incl. its failure paths, against the CPU checker. */
+int visfs_ba_hook_lm_script(int32_t gauss_newton, int32_t n_iter, double chi0, double max_diag0, int32_t n_trials,
+                            const double* temp_chi, const double* scale, const int32_t* ok, visfs_ba_stats* stats);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------ */
 /* Sizes of the resident graph and of the index structures built at upload. */
 typedef struct visfs_ba_graph_info {

@@ -1015,26 +1015,34 @@ int oracle_sys_fetch(oracle_sys* s, int32_t which, double* dst, size_t n) {
     return VISFS_BA_OK;
 }
 
-/* [g2o-upstream] SparseOptimizer::optimize(n) with OptimizationAlgorithmLevenberg / GaussNewton.
+/* [g2o-upstream] SparseOptimizer::optimize(n) with OptimizationAlgorithmLevenberg / GaussNewton, written over an
+ * abstract problem (linearise / damped trial / commit) so that the control flow exists ONCE: the solver drives it with the
+ * real system, oracle_lm_script() with scripted trial outcomes (known-answer tests of the schedule, incl. its failure paths).
  * Returns the number of outer iterations executed. */
-static int optimize_phase(oracle_sys* s, int n_iter, visfs_ba_stats* st, int phase) {
-    s->pcg_residual = -1.0;                 /* LinearSolverPCG::init() at algorithm->init() */
+typedef struct {
+    void (*begin)(void* ctx);                                                 /* algorithm->init(): LinearSolverPCG::init() */
+    void (*linearize)(void* ctx, double* chi, double* max_diag);              /* computeActiveErrors + buildSystem */
+    void (*trial)(void* ctx, double lambda, double* temp_chi, double* scale, int32_t* pcg_it, int32_t* ok);
+    void (*commit)(void* ctx);                                                /* discardTop: the trial becomes the estimate */
+    int gauss_newton;
+} lm_problem;
+
+static int lm_optimize_phase(const lm_problem* P, void* ctx, int n_iter, visfs_ba_stats* st, int phase) {
+    P->begin(ctx);
     double lambda = 0.0, ni = 2.0;
     int done = 0;
     for (int it = 0; it < n_iter; ++it) {
         double currentChi, maxDiag;
-        oracle_sys_linearize(s, &currentChi, &maxDiag);
+        P->linearize(ctx, &currentChi, &maxDiag);
         if (it == 0 && phase == 0 && st) st->chi2_initial = currentChi;
-        if (s->prm.trust_region == 1) {
-            /* Gauss-Newton: solve with lambda = 0, always accept */
-            int pit = 0;
-            const int ok = schur_solve(s, 0.0, &pit);
+        if (P->gauss_newton) {
+            /* OptimizationAlgorithmGaussNewton::solve: lambda = 0, always take the step.  (g2o calls update(x) even when
+             * solve() failed — x then holds whatever the failed solver left; restated as "no update") */
+            int32_t pit = 0, ok = 0;
+            double tc = 0.0, sc = 0.0;
+            P->trial(ctx, 0.0, &tc, &sc, &pit, &ok);
             if (st) { st->pcg_iterations += pit; st->trials_run[phase]++; }
-            if (ok) {
-                apply_update(s);
-                memcpy(s->pose, s->pose_trial, (size_t)s->Np * 56);
-                memcpy(s->pt, s->pt_trial, (size_t)s->Nl * 24);
-            }
+            if (ok) P->commit(ctx);
             ++done;
             if (st && st->n_trace < VISFS_BA_MAX_TRACE) { st->trace_lambda[st->n_trace] = 0.0; st->trace_chi2[st->n_trace] = currentChi; st->n_trace++; }
             if (!ok) break;                 /* Fail */
@@ -1044,11 +1052,11 @@ static int optimize_phase(oracle_sys* s, int n_iter, visfs_ba_stats* st, int pha
         double rho = 0.0, tempChi = currentChi;
         int qmax = 0;
         do {
-            int pit = 0, ok = 0;
+            int32_t pit = 0, ok = 0;
             double scale = 0.0;
-            oracle_sys_trial(s, lambda, &tempChi, &scale, &pit, &ok);
+            P->trial(ctx, lambda, &tempChi, &scale, &pit, &ok);
             if (st) { st->pcg_iterations += pit; st->trials_run[phase]++; }
-            if (!ok) tempChi = DBL_MAX;
+            if (!ok) { tempChi = DBL_MAX; scale = 0.0; }
             scale += 1e-3;
             rho = (currentChi - tempChi) / scale;
             if (rho > 0.0 && isfinite(tempChi)) {
@@ -1058,8 +1066,7 @@ static int optimize_phase(oracle_sys* s, int n_iter, visfs_ba_stats* st, int pha
                 lambda *= scaleFactor;
                 ni = 2.0;
                 currentChi = tempChi;
-                memcpy(s->pose, s->pose_trial, (size_t)s->Np * 56);   /* discardTop */
-                memcpy(s->pt, s->pt_trial, (size_t)s->Nl * 24);
+                P->commit(ctx);                                        /* discardTop */
             } else {
                 lambda *= ni;
                 ni *= 2.0;                                             /* pop: estimates unchanged */
@@ -1069,9 +1076,56 @@ static int optimize_phase(oracle_sys* s, int n_iter, visfs_ba_stats* st, int pha
         } while (rho < 0.0 && qmax < 10);
         ++done;
         if (st && st->n_trace < VISFS_BA_MAX_TRACE) { st->trace_lambda[st->n_trace] = lambda; st->trace_chi2[st->n_trace] = currentChi; st->n_trace++; }
-        if (qmax == 10 || rho == 0.0) break;                          /* Terminate */
+        if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) break;     /* Terminate (a non-finite lambda left the trial loop above) */
     }
     return done;
+}
+
+/* the real system behind lm_problem */
+static void sys_begin(void* c) { ((oracle_sys*)c)->pcg_residual = -1.0; }   /* LinearSolverPCG::init() at algorithm->init() */
+static void sys_linearize(void* c, double* chi, double* md) { oracle_sys_linearize((oracle_sys*)c, chi, md); }
+static void sys_trial(void* c, double lambda, double* tc, double* sc, int32_t* pit, int32_t* ok) {
+    oracle_sys* s = (oracle_sys*)c;
+    if (s->prm.trust_region == 1) {
+        /* Gauss-Newton needs neither the trial chi2 nor computeScale */
+        int it = 0;
+        const int k = schur_solve(s, 0.0, &it);
+        *pit = it; *ok = k;
+        if (k) apply_update(s);
+        return;
+    }
+    oracle_sys_trial(s, lambda, tc, sc, pit, ok);
+}
+static void sys_commit(void* c) {
+    oracle_sys* s = (oracle_sys*)c;
+    memcpy(s->pose, s->pose_trial, (size_t)s->Np * 56);
+    memcpy(s->pt, s->pt_trial, (size_t)s->Nl * 24);
+}
+static int optimize_phase(oracle_sys* s, int n_iter, visfs_ba_stats* st, int phase) {
+    const lm_problem P = { sys_begin, sys_linearize, sys_trial, sys_commit, s->prm.trust_region == 1 };
+    return lm_optimize_phase(&P, s, n_iter, st, phase);
+}
+
+/* Scripted problem: trial t of the phase returns (temp_chi[t], scale[t], ok[t]); the committed chi2 is what linearise reports. */
+typedef struct { int n, pos; const double* chi; const double* scale; const int32_t* ok; double committed, pending, max_diag; } lm_script;
+static void scr_begin(void* c) { (void)c; }
+static void scr_linearize(void* c, double* chi, double* md) { lm_script* q = (lm_script*)c; *chi = q->committed; *md = q->max_diag; }
+static void scr_trial(void* c, double lambda, double* tc, double* sc, int32_t* pit, int32_t* ok) {
+    lm_script* q = (lm_script*)c; (void)lambda;
+    const int t = q->pos < q->n ? q->pos : q->n - 1;
+    q->pos++;
+    *tc = q->chi[t]; *sc = q->scale[t]; *ok = q->ok[t]; *pit = 0;
+    q->pending = q->chi[t];
+}
+static void scr_commit(void* c) { lm_script* q = (lm_script*)c; q->committed = q->pending; }
+int oracle_lm_script(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi,
+                     const double* scale, const int32_t* ok, visfs_ba_stats* st) {
+    lm_script q = { n_trials, 0, temp_chi, scale, ok, chi0, chi0, max_diag0 };
+    const lm_problem P = { scr_begin, scr_linearize, scr_trial, scr_commit, gauss_newton };
+    memset(st, 0, sizeof(*st));
+    st->iterations_run[0] = lm_optimize_phase(&P, &q, n_iter, st, 0);
+    st->chi2_final = q.committed;
+    return q.pos;
 }
 
 int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* st, double* seconds) {

@@ -75,6 +75,13 @@ int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* stats, double* seconds);
 void oracle_sys_download(oracle_sys* s, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2);
 void oracle_sys_reset(oracle_sys* s);
 
+/* The LM / Gauss-Newton schedule ([g2o-upstream] OptimizationAlgorithmLevenberg::solve inside SparseOptimizer::optimize) run on
+ * SCRIPTED trial outcomes: trial t of one optimize(n_iter) call returns (temp_chi[t], scale[t] = computeScale() without the
+ * +1e-3, ok[t]); linearise reports the committed chi2 (chi0 at the start) and max_diag0.  Fills stats->trace_*, iterations_run[0],
+ * trials_run[0], chi2_final (committed chi2); returns the number of trials consumed.  Same control-flow function as the solver. */
+int oracle_lm_script(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi,
+                     const double* scale, const int32_t* ok, visfs_ba_stats* stats);
+
 /* localOptimize-equivalent on host buffers (pack → optimise → write-back). */
 int oracle_solve_window(const visfs_ba_params* params, const visfs_ba_window* w, visfs_ba_result* r, int num_threads);
 

@@ -48,6 +48,8 @@ def load(omp=False):
     lib.oracle_sys_optimize.restype = C.c_int
     lib.oracle_sys_download.argtypes = [C.c_void_p, _pd, _pd, C.POINTER(C.c_uint8), _pd]
     lib.oracle_sys_reset.argtypes = [C.c_void_p]
+    lib.oracle_lm_script.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _pd, _pd, C.POINTER(C.c_int32), C.POINTER(abi.Stats)]
+    lib.oracle_lm_script.restype = C.c_int
     lib.oracle_solve_window.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Window), C.POINTER(abi.Result), C.c_int]
     lib.oracle_solve_window.restype = C.c_int
     return lib

@@ -24,6 +24,7 @@ EXPORTS = [
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
     "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
+    "visfs_ba_hook_lm_script",
 ]
 
 _lib = None
@@ -81,6 +82,8 @@ def load_library():
     lib.visfs_ba_profile_enable.restype = C.c_int
     lib.visfs_ba_profile_read.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
     lib.visfs_ba_profile_read.restype = C.c_int
+    lib.visfs_ba_hook_lm_script.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _pd, _pd, C.POINTER(C.c_int32), C.POINTER(abi.Stats)]
+    lib.visfs_ba_hook_lm_script.restype = C.c_int
     if lib.visfs_ba_abi_version() != abi.ABI_VERSION:
         raise BackendError("ABI version mismatch between visfs_amd/abi.py and libvisfs_ba_hip.so")
     _lib = lib

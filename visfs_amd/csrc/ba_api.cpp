@@ -1345,6 +1345,15 @@ static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size
     return VISFS_BA_OK;
 }
 
+int visfs_ba_hook_lm_script(int32_t gauss_newton, int32_t n_iter, double chi0, double max_diag0, int32_t n_trials,
+                            const double* temp_chi, const double* scale, const int32_t* ok, visfs_ba_stats* stats) {
+    if (!temp_chi || !scale || !ok || !stats || n_trials < 1) return VISFS_BA_ERR_BAD_ARGUMENT;
+    LmState st;
+    const int used = lm_script_host(gauss_newton, n_iter, chi0, max_diag0, n_trials, temp_chi, scale, ok, &st);
+    fill_stats(st, stats);
+    return used;
+}
+
 int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {
     if (!h || !dst) return VISFS_BA_ERR_BAD_ARGUMENT;
     return guarded(h, [&]() { return stage_fetch_impl(h, which, dst, n_doubles); });

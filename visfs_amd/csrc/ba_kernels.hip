@@ -348,7 +348,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
 // The scalar half of [g2o-upstream] OptimizationAlgorithmLevenberg::solve (and the Gauss-Newton variant): one thread.
 // ok = the linear solve succeeded; chi / sc = robust chi2 at the trial state and computeScale's sum.
 // spec: the accepted trial's linearisation is already in the other buffer set (speculative linearise): flip lin_sel with sel.
-__device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc, const bool spec) {
+__host__ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc, const bool spec) {
     const int ph = st->phase;
     st->trials_run[ph] += 1;
     st->solver_failed = 0;
@@ -383,7 +383,7 @@ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const doub
         const double nl = lambda * st->ni;
         st->lambda = nl;
         st->ni *= 2.0;                              // pop: estimate unchanged
-        if (!(fabs(nl) <= DBL_MAX)) iteration_over = true;            // !isfinite(lambda): break before qmax++
+        if (!(fabs(nl) <= DBL_MAX)) { iteration_over = true; terminate = true; }   // !isfinite(lambda): break before qmax++, and solve() returns Terminate
         else {
             st->trial_q += 1;
             if (!(rho < 0.0) || st->trial_q >= 10) iteration_over = true;   // loop runs while rho < 0 && qmax < 10
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int 
 }
 
 // One thread: chi2 / max|diag H| of a fresh linearisation; computeLambdaInit on the first iteration of a phase ([g2o-upstream] tau = 1e-5).
-__device__ __noinline__ void lin_finalize_update(LmState* st, const double chi_total, const double md_total) {
+__host__ __device__ __noinline__ void lin_finalize_update(LmState* st, const double chi_total, const double md_total) {
     st->current_chi = chi_total;
     st->max_diag = md_total;
     if (st->phase_iter == 0) {
@@ -600,6 +600,31 @@ __device__ __noinline__ void lin_finalize_update(LmState* st, const double chi_t
         st->lambda = st->gauss_newton ? 0.0 : 1e-5 * md_total;
         st->ni = 2.0;
     }
+}
+
+// Test hook (visfs_ba_hook_lm_script): the LM state machine of ONE phase stepped on the host by the very functions the kernels
+// run (lin_finalize_update, lm_decide — compiled for both sides), on scripted trial outcomes.  No solve happens here: this checks
+// the control flow (accept / reject, lambda schedule, Terminate rules, failure paths) against the checker's restatement of
+// [g2o-upstream] OptimizationAlgorithmLevenberg::solve without a device.
+int lm_script_host(const int gauss_newton, const int n_iter, const double chi0, const double max_diag0, const int n_trials,
+                   const double* temp_chi, const double* scale, const int32_t* ok, LmState* st) {
+    *st = LmState{};
+    st->ni = 2.0; st->pcg_res_in = -1.0; st->pcg_residual = -1.0; st->spec_dst = 1;
+    st->max_iter = n_iter; st->gauss_newton = gauss_newton;
+    st->done = n_iter <= 0 ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL);
+    double committed = chi0;
+    int pos = 0;
+    for (int guard = 0; st->mode != 0 && guard < 100000; ++guard) {
+        // first unit of a phase: k_lin_finalize; later units take current_chi from the accepted trial (as the kernels do)
+        if ((st->mode & MODE_LIN) && st->phase_iter == 0) lin_finalize_update(st, committed, max_diag0);
+        const int t = pos < n_trials ? pos : n_trials - 1;
+        ++pos;
+        const int sel_before = st->sel;
+        lm_decide(st, ok[t] != 0, st->lambda, temp_chi[t], scale[t], false);
+        if (st->sel != sel_before) committed = temp_chi[t];
+    }
+    st->chi2_final = committed;
+    return pos;
 }
 
 // Single workgroup, launched in the FIRST unit of a phase (and by the stage hook): sums Hpp/b_p, reduces the

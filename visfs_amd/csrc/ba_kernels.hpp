@@ -40,5 +40,7 @@ void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, i
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s);
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
+// test hook: one phase of the LM state machine on the host, through the functions the kernels run, on scripted trial outcomes
+int lm_script_host(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi, const double* scale, const int32_t* ok, LmState* st);
 
 }  // namespace visfs_ba
