@@ -24,17 +24,36 @@ import numpy as np
 
 
 def algorithmic_bytes(kernel, d):
-    """SURVEY.md §8(d) per-unit bytes x units of one launch."""
-    No, Nl, Np, npairs, nblk = d["n_obs"], d["n_points"], d["n_poses"], d["n_pairs"], d["n_blk"]
+    """SURVEY.md §8(d) per-unit bytes x units of one launch, averaged over the launches of one solve: a launch
+    of phase p touches the d["edges"][p] stereo edges that are still in the active set (phase 2 runs without the culled ones), and
+    a solve has d["lin_launches"][p] linearisations and d["trial_launches"][p] damped solves in phase p."""
+    Nl, Np, nblk = d["n_points"], d["n_poses"], d["n_blk"]
+    edges, lin, tr = d["edges"], d["lin_launches"], d["trial_launches"]
+
+    def avg(weights, fn):
+        tot = sum(weights)
+        return sum(wt * fn(e) for wt, e in zip(weights, edges)) / tot if tot > 0 else fn(edges[0])
     if kernel == "k_linearize":      # stage A of §8d: 256 B/obs + 96 B/landmark + 336 B/pose
-        return 256 * No + 96 * Nl + 336 * Np
+        return avg(lin, lambda No: 256 * No + 96 * Nl + 336 * Np)
     if kernel == "k_schur_partial":  # stage B: 144 B/obs (Hpl) + 96 B/landmark + 288 B/stored block + 48 B/pose
-        return 144 * No + 96 * Nl + 288 * nblk + 48 * Np
+        return avg(tr, lambda No: 144 * No + 96 * Nl + 288 * nblk + 48 * Np)
     if kernel == "k_backsub":        # stages D+E: 144 + 112 + 8 B/obs, (72+24+24)+48 B/landmark, 112 B/pose
-        return 264 * No + 168 * Nl + 112 * Np
+        return avg(tr, lambda No: 264 * No + 168 * Nl + 112 * Np)
     if kernel == "k_pcg":            # stage C, k iterations in one launch: k * (288 B/block + 4*48 B/pose)
         return d["pcg_iters_per_launch"] * (288 * nblk + 192 * Np)
     raise KeyError(kernel)
+
+
+def phase_counts(d, st):
+    """Per-phase launch and edge counts of one solve from its visfs_ba_stats (ABI 3)."""
+    if st is None:
+        d["edges"] = [d["n_obs"], d["n_obs"]]; d["lin_launches"] = [1, 1]; d["trial_launches"] = [1, 1]; d["pcg_phase"] = [0, 0]
+        return d
+    d["edges"] = [int(st.n_active_edges[0]), int(st.n_active_edges[1])]
+    d["lin_launches"] = [int(st.iterations_run[0]), int(st.iterations_run[1])]
+    d["trial_launches"] = [int(st.trials_run[0]), int(st.trials_run[1])]
+    d["pcg_phase"] = [int(st.pcg_iterations_phase[0]), int(st.pcg_iterations_phase[1])]
+    return d
 
 
 def main():
@@ -42,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="C2", help="C1..C5 / PROD (BASELINE.json configs); C2 is the headline")
+    ap.add_argument("--config", default="C2", help="C1..C5 / PROD (BASELINE.json configs); C2 is the headline; C4R = C4 started from 1e-3 rad rotation error (phase 1 converges), C4C = C4 with the world origin at the trajectory centroid")
     ap.add_argument("--windows-per-gpu", type=int, default=1)
     ap.add_argument("--solver", type=int, default=2, help="Optimizer/Solver: 2 = PCG (headline), 0 = direct Cholesky")
     ap.add_argument("--iterations", type=int, default=20, help="Optimizer/Iterations (10+10, as the shipped launch files)")
@@ -56,8 +75,10 @@ def main():
     import torch
 
     rank, local_rank, world = vdist.env_rank()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # never a silent single-GPU line for a multi-GPU request (and never a re-exec of a process that may have touched the GPU)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     dev = local_rank if world > 1 else 0
     # rehearsal on a 1-GPU box: VISFS_BENCH_DEVICE pins every rank to one device, VISFS_BENCH_DIST_BACKEND=gloo replaces RCCL
     if os.environ.get("VISFS_BENCH_DEVICE") is not None:
@@ -122,7 +143,7 @@ def main():
     null_us = 1e3 * getattr(solvers[0], "null_pair_ms", 0.0)     # an empty event pair: the mechanism's own share of every duration
     cand = [k for k in data_kernels if calib.get(k, {}).get("active_launches", 0) > 0]
     dom = max(cand, key=lambda k: calib[k]["active_ms"]) if cand else None
-    # timed region: events only on the dominant kernel's launches (on the library's own stream), every 8th step
+    # timed region: no instrumentation at all (event bookkeeping is host work between launches)
     solvers[0].profile_enable(False)
     vdist.barrier(world, bar_dev)
     torch.cuda.synchronize()
@@ -130,9 +151,6 @@ def main():
     iters = 0
     last = None
     for k in range(args.steps):
-        # instrument every 8th step of the timed region only (event bookkeeping is host work between launches)
-        if dom:
-            solvers[0].profile_enable([dom] if k % 8 == 0 else False)
         n, last = step()
         iters += n
     torch.cuda.synchronize()
@@ -140,6 +158,16 @@ def main():
     t1 = time.perf_counter()
     elapsed = vdist.reduce_max(t1 - t0, world, red_dev)
     total_iters = vdist.reduce_sum(iters, world, red_dev)
+    # the dominant kernel's launch durations: the SAME steps once more, right behind the timed region, with a HIP-event pair
+    # attached to every launch of that kernel on the library's own stream (max(3, steps / 8) steps)
+    if dom:
+        solvers[0].profile_enable([dom])
+        for _ in range(max(3, args.steps // 8)):
+            step()
+        solvers[0].profile_enable(False)
+    # config 5 as north_star words it: after the timed region every rank's window results travel to every rank in ONE
+    # all_gather (RCCL over xGMI when the backend is nccl); rank 0 checks them against its own single-rank solves of the same windows
+    gathered = gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_dev, vdist, abi, synth, backend, torch)
     vdist.shutdown(world)                  # last collective done
 
     if rank != 0:
@@ -148,6 +176,7 @@ def main():
     d = descs[0]
     roofline = None
     d["pcg_iters_per_launch"] = (last.pcg_iterations / max(1, last.trials_run[0] + last.trials_run[1])) if last is not None else 0
+    phase_counts(d, last)
 
     def roof(kernel, p):
         # avg_launch_us: HIP events ATTACHED to the launch (hipExtLaunchKernelGGL start / stop events = the dispatch's own
@@ -180,19 +209,26 @@ def main():
                                   + (f"; windows of a rank share every launch (blockIdx.y = window)" if batched else "")},
         "roofline": roofline,
         "roofline_other_kernels": roofline_kernels,
+        "result_gather": gathered,
         "kernel_us_per_step_calibration": {k: round(1e3 * v["total_ms"] / 3, 2) for k, v in calib.items()},
     }
     if last is not None and args.solver == 2:
-        # whole-iteration view: bytes per LM iteration with the measured trials per iteration t and PCG iterations per
-        # solve k, against the cache-agnostic floor (bytes / 8 TB/s); rank 0's window stands for all (same shape)
+        # whole-iteration view: bytes of one solve = sum over its two phases of (iterations x linearise bytes + damped
+        # solves x (Schur + back-substitution + PCG bytes)), each phase with ITS active edge count (phase 2 runs without the edges the
+        # outlier pass moved to level 1), against the cache-agnostic floor (bytes / 8 TB/s); rank 0's window stands for all
         its = max(1, last.iterations_run[0] + last.iterations_run[1])
         tr = max(1, last.trials_run[0] + last.trials_run[1])
-        t, k = tr / its, last.pcg_iterations / tr
-        No, Nl, Np, nb = d["n_obs"], d["n_points"], d["n_poses"], d["n_blk"]
-        byts = 256 * No + 96 * Nl + 336 * Np + t * (408 * No + 264 * Nl + 160 * Np + 288 * nb * (1 + k) + 192 * k * Np)
+        Nl, Np, nb = d["n_points"], d["n_poses"], d["n_blk"]
+        solve_bytes = 0.0
+        for ph in range(2):
+            No_p, it_p, tr_p, k_p = d["edges"][ph], d["lin_launches"][ph], d["trial_launches"][ph], d["pcg_phase"][ph]
+            solve_bytes += it_p * (256 * No_p + 96 * Nl + 336 * Np) + tr_p * (408 * No_p + 264 * Nl + 160 * Np + 288 * nb) + k_p * (288 * nb + 192 * Np)
+        byts = solve_bytes / its
         rate = byts * (total_iters / elapsed) / 1e9
-        out["iteration_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_iteration": int(byts), "trials_per_iteration": round(t, 3),
-                                     "pcg_iterations_per_solve": round(k, 3), "achieved": round(rate, 1), "peak": 8000.0, "unit": "GB/s",
+        out["iteration_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_iteration": int(byts), "trials_per_iteration": round(tr / its, 3),
+                                     "pcg_iterations_per_solve": round(last.pcg_iterations / tr, 3),
+                                     "active_edges_per_phase": d["edges"], "iterations_per_phase": d["lin_launches"], "damped_solves_per_phase": d["trial_launches"],
+                                     "achieved": round(rate, 1), "peak": 8000.0, "unit": "GB/s",
                                      "frac": round(rate / 8000.0, 4), "floor_us_per_iteration": round(byts / 8e6, 2),
                                      "window_us_per_iteration": round(1e6 * elapsed * world * B / total_iters, 2),
                                      "aggregate_us_per_iteration_per_gpu": round(1e6 * elapsed * world / total_iters, 2)}
@@ -201,6 +237,38 @@ def main():
         # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
         out["max_pose_err_vs_oracle"] = parity_vs_oracle(args, prm, solvers[0])
     print(json.dumps(out))
+
+
+def gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_dev, vdist, abi, synth, backend, torch):
+    """One all_gather of every window's optimised poses ([B, Np, 7] fp64 per rank) over the bench's process group; rank 0 re-solves
+    the FIRST window of every rank itself (same chunking: as a batch member when the ranks ran batches) and compares bit for bit —
+    the kernels are run-to-run and device-to-device deterministic (fixed-order reductions, no floating-point atomics)."""
+    poses = []
+    for b in range(B):
+        pose = (solvers[0].batch_download(b) if batched else solvers[b].download())[0]
+        poses.append(pose)
+    local = torch.from_numpy(np.stack(poses, 0))
+    if world == 1:
+        return {"backend": None, "ranks_seen": [0], "windows": B, "bytes": int(local.numel() * 8), "checked_windows": 0, "bit_identical": None}
+    ids = vdist.gather_results(torch.tensor([[float(rank)]], dtype=torch.float64), world, red_dev).cpu().numpy().ravel()
+    allp = vdist.gather_results(local, world, red_dev).cpu().numpy()          # [world * B, Np, 7]
+    if rank != 0:
+        return None
+    same, checked = True, 0
+    for r in range(world):
+        w = synth.make_window(args.config, window_index=r * B)
+        gb, *_ = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+        s = backend.Solver(prm, device=dev)
+        if batched:
+            s.batch_upload([gb]); s.batch_reset(); s.batch_optimize(); ref = s.batch_download(0)[0]
+        else:
+            s.upload(gb); s.reset(); s.optimize(); ref = s.download()[0]
+        s.close()
+        same = same and bool(np.array_equal(ref, allp[r * B]))
+        checked += 1
+    import torch.distributed as dist
+    return {"backend": dist.get_backend(), "ranks_seen": [int(x) for x in ids], "windows": int(allp.shape[0]),
+            "bytes": int(allp.size * 8), "checked_windows": checked, "bit_identical": same}
 
 
 def pmc_traffic(config, kernel):
@@ -237,12 +305,29 @@ def cpu_baseline(args, prm):
         secs.append(sec); its = st.iterations_run[0] + st.iterations_run[1]; runs += 1
     s.close()
     med = float(np.median(secs))
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None                      # cgroup v2 CPU quota of this box, in cores (the GPU box gives 16 of its 256 hardware threads)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     out = {"value": round(its / med, 2), "unit": "BA iterations/s", "cores": 1, "kind": "port",
+           "cpu_model": cpu_model, "nproc": os.cpu_count(), "usable_cores": usable, "cgroup_cpu_quota_cores": quota,
            "sample": f"{runs} full solves of the same {args.config} window ({its} outer iterations each), median; "
                      f"g2o-algorithm restatement in C (oracle/), single thread, gcc -O3 x86-64-v3"}
     # SURVEY §8d also asks for the OpenMP build of the same restatement over the host cores (g2o's own default is serial)
     try:
-        nthr = min(os.cpu_count() or 1, 16)
+        # every core this process may use: the affinity mask, capped by the cgroup CPU quota (threads beyond the quota only get throttled)
+        nthr = max(1, int(min(usable, quota) if quota else usable))
         olib_omp = oracle_lib.load(omp=True)
         so = oracle_lib.OracleSystem(olib_omp, prm, gb, nthr)
         secs_o, t_budget = [], time.perf_counter() + 6.0
@@ -251,7 +336,8 @@ def cpu_baseline(args, prm):
             rc, st, sec = so.optimize()
             secs_o.append(sec)
         so.close()
-        out["openmp"] = {"value": round((st.iterations_run[0] + st.iterations_run[1]) / float(np.median(secs_o)), 2), "cores": nthr}
+        out["openmp"] = {"value": round((st.iterations_run[0] + st.iterations_run[1]) / float(np.median(secs_o)), 2), "cores": nthr,
+                         "note": "OpenMP build of the same restatement; threads = usable cores (affinity mask capped by the cgroup CPU quota)"}
     except Exception as e:      # the OpenMP library is optional
         out["openmp"] = {"error": str(e)[:80]}
     return out

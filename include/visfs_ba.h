@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VISFS_BA_ABI_VERSION 2
+#define VISFS_BA_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 /* The reference signals failure by returning an EMPTY pose map
@@ -167,6 +167,9 @@ typedef struct visfs_ba_stats {
     int32_t n_trace;              /* entries used below (outer iterations, both phases) */
     double  trace_lambda[VISFS_BA_MAX_TRACE];   /* lambda of the accepted (or last) trial */
     double  trace_chi2[VISFS_BA_MAX_TRACE];     /* robust chi2 after the iteration */
+    /* ABI 3: what the two phases actually worked on (measurement: a phase-2 launch touches only the edges left at level 0) */
+    int32_t n_active_edges[2];    /* stereo edges in the active set of phase 1 / phase 2 (level 0, not both ends fixed); [1] = [0] - n_outliers */
+    int32_t pcg_iterations_phase[2];   /* PCG iterations of the solves of phase 1 / phase 2 (sum = pcg_iterations) */
 } visfs_ba_stats;
 
 typedef struct visfs_ba_handle visfs_ba_handle;
@@ -245,6 +248,12 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
 /* Copies a stage buffer to host memory as fp64 in the layout documented above. */
 int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles);
 
+/* Stepping a solve by hand (tools/soak_diverge.py): make the last trial state the estimate (discardTop); start a phase
+ * (LinearSolverPCG::init(): the carried residual is forgotten); the outlier pass of Optimizer.cpp:283-303 on the estimate
+ * (marks edges with chi2 > delta as level 1, visible through visfs_ba_graph_download's obs_outlier). */
+int visfs_ba_stage_commit(visfs_ba_handle* h);
+int visfs_ba_stage_begin_phase(visfs_ba_handle* h);
+int visfs_ba_stage_mark_outliers(visfs_ba_handle* h);
 /* Host-only hook (no device needed): ONE optimize(n_iter) phase of the LM / Gauss-Newton control (K9, the device-side state
  * machine's own functions compiled for the host) driven by scripted trial outcomes — trial t returns (temp_chi[t], scale[t] =
  * computeScale() without the +1e-3, ok[t]); the last entry repeats if the schedule asks for more.  Fills stats->trace_*,

@@ -524,6 +524,7 @@ struct oracle_sys {
     float *grid_cost;
     int *pose_idx;              /* free index or -1 (hessianIndex) */
     int *lm_ptr;                /* CSR over obs by landmark */
+    int *po_ptr, *po_obs;       /* CSR over obs by FREE pose, ascending edge id (the OpenMP passes walk a pose's edges in the serial order) */
     /* estimates */
     double *pose, *pt, *pose_trial, *pt_trial;
     uint8_t *obs_level;         /* 0 active level, 1 outlier */
@@ -578,6 +579,12 @@ oracle_sys* oracle_sys_create(const visfs_ba_params* prm, const visfs_ba_graph* 
     s->lm_ptr = xcalloc((size_t)Nl + 1, sizeof(int));
     for (int k = 0; k < No; ++k) s->lm_ptr[s->obs_pt[k] + 1]++;
     for (int l = 0; l < Nl; ++l) s->lm_ptr[l + 1] += s->lm_ptr[l];
+    s->po_ptr = xcalloc((size_t)npf + 1, sizeof(int)); s->po_obs = xcalloc(No, sizeof(int));
+    for (int k = 0; k < No; ++k) { const int a = s->pose_idx[s->obs_pose[k]]; if (a >= 0) s->po_ptr[a + 1]++; }
+    for (int a = 0; a < npf; ++a) s->po_ptr[a + 1] += s->po_ptr[a];
+    { int* fill = xcalloc((size_t)npf + 1, sizeof(int)); memcpy(fill, s->po_ptr, ((size_t)npf + 1) * sizeof(int));
+      for (int k = 0; k < No; ++k) { const int a = s->pose_idx[s->obs_pose[k]]; if (a >= 0) s->po_obs[fill[a]++] = k; }
+      free(fill); }
     s->pose = xcalloc((size_t)Np * 7, 8); s->pt = xcalloc((size_t)Nl * 3, 8);
     s->pose_trial = xcalloc((size_t)Np * 7, 8); s->pt_trial = xcalloc((size_t)Nl * 3, 8);
     s->obs_level = xcalloc(No, 1); s->obs_edge_ok = xcalloc(No, 1);
@@ -608,7 +615,7 @@ void oracle_sys_reset(oracle_sys* s) {
 void oracle_sys_destroy(oracle_sys* s) {
     if (!s) return;
     free(s->pose0); free(s->pt0); free(s->pose_fixed); free(s->pt_fixed); free(s->obs_pt); free(s->obs_pose);
-    free(s->obs_uvr); free(s->odo_i); free(s->odo_j); free(s->odo_tq); free(s->pose_idx); free(s->lm_ptr);
+    free(s->obs_uvr); free(s->odo_i); free(s->odo_j); free(s->odo_tq); free(s->pose_idx); free(s->lm_ptr); free(s->po_ptr); free(s->po_obs);
     free(s->pose); free(s->pt); free(s->pose_trial); free(s->pt_trial); free(s->obs_level); free(s->obs_edge_ok);
     free(s->err); free(s->chi2); free(s->wgt); free(s->W); free(s->Hll); free(s->bl); free(s->Hpp); free(s->bp);
     free(s->odo_err); free(s->Dinv); free(s->S); free(s->bs); free(s->chol); free(s->dxp); free(s->dxl);
@@ -716,7 +723,26 @@ void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag) 
             }
         }
     }
-    /* pose pass: Hpp, bp (serial: deterministic summation in edge order) */
+    /* pose pass: Hpp, bp.  Every pose block sums its edges in edge order; with several threads the poses are shared out and each
+     * thread walks ITS poses' edges in that same order (pose-major lists), so the sums are bit-identical to the serial pass */
+    if (s->nthreads > 1) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(s->nthreads)
+#endif
+        for (int a = 0; a < s->npf; ++a) {
+            for (int n = s->po_ptr[a]; n < s->po_ptr[a + 1]; ++n) {
+                const int k = s->po_obs[n];
+                if (!edge_active(s, k)) continue;
+                const int ip = s->obs_pose[k];
+                double e[3], Jj[18];
+                oracle_stereo_edge(s->pose + 7 * ip, s->pt + 3 * s->obs_pt[k], s->obs_uvr + 3 * k, s->intr, e, NULL, Jj);
+                const double wo = s->wgt[k] * inv_var;
+                hpp_add(s, a, a, Jj, Jj, 3, wo);
+                double* b = s->bp + 6 * a;
+                for (int r = 0; r < 6; ++r) b[r] += -(Jj[r] * wo * e[0] + Jj[6 + r] * wo * e[1] + Jj[12 + r] * wo * e[2]);
+            }
+        }
+    } else
     for (int k = 0; k < s->No; ++k) {
         if (!edge_active(s, k)) continue;
         const int ip = s->obs_pose[k];
@@ -896,8 +922,9 @@ static int schur_solve(oracle_sys* s, double lambda, int* pcg_iters) {
         if (empty) for (int r = 0; r < 6; ++r) s->S[(size_t)(6 * b + r) * n + 6 * b + r] = 1.0;
     }
     const int nt = s->nthreads;
-    /* per-thread accumulation buffers would be needed for a parallel Schur; keep the reduction serial
-     * per landmark (g2o's default build) and parallelise only the per-landmark inverse. */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
+#endif
     for (int l = 0; l < Nl; ++l) {
         double* Di = s->Dinv + 6 * l;
         if (s->pt_fixed[l] || !landmark_has_active_edge(s, l)) { memset(Di, 0, 48); continue; }
@@ -905,7 +932,38 @@ static int schur_solve(oracle_sys* s, double lambda, int* pcg_iters) {
         h[0] += lambda; h[3] += lambda; h[5] += lambda;
         sym3_inv(h, Di);
     }
-    (void)nt;
+    if (nt > 1) {
+        /* block ROW i1 of the upper triangle and b_s[i1] belong to one thread, which walks pose i1's edges in edge (= landmark)
+         * order: every block receives its landmarks' terms in the order of the serial loop below — bit-identical, no per-thread
+         * copies of S to merge */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+#endif
+        for (int i1 = 0; i1 < s->npf; ++i1) {
+            for (int n1 = s->po_ptr[i1]; n1 < s->po_ptr[i1 + 1]; ++n1) {
+                const int k1 = s->po_obs[n1];
+                const int l = s->obs_pt[k1];
+                if (s->pt_fixed[l] || s->wgt[k1] == 0.0) continue;
+                const double* Di = s->Dinv + 6 * l;
+                const double D[9] = { Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5] };
+                double Ddb[3]; mat3_vec(D, s->bl + 3 * l, Ddb);
+                const double* B1 = s->W + 18 * k1;
+                double BD[18];
+                for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) BD[r * 3 + c] = B1[r * 3] * D[c] + B1[r * 3 + 1] * D[3 + c] + B1[r * 3 + 2] * D[6 + c];
+                for (int r = 0; r < 6; ++r) s->bs[6 * i1 + r] -= B1[r * 3] * Ddb[0] + B1[r * 3 + 1] * Ddb[1] + B1[r * 3 + 2] * Ddb[2];
+                for (int k2 = s->lm_ptr[l]; k2 < s->lm_ptr[l + 1]; ++k2) {
+                    const int i2 = s->pose_idx[s->obs_pose[k2]];
+                    if (i2 < i1 || s->wgt[k2] == 0.0) continue;
+                    if (i2 == i1 && k2 != k1) continue;
+                    const double* B2 = s->W + 18 * k2;
+                    double* H = s->S + (size_t)(6 * i1) * n + 6 * i2;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c)
+                            H[(size_t)r * n + c] -= BD[r * 3] * B2[c * 3] + BD[r * 3 + 1] * B2[c * 3 + 1] + BD[r * 3 + 2] * B2[c * 3 + 2];
+                }
+            }
+        }
+    } else
     for (int l = 0; l < Nl; ++l) {
         if (s->pt_fixed[l]) continue;
         const double* Di = s->Dinv + 6 * l;
@@ -1128,6 +1186,25 @@ int oracle_lm_script(int gauss_newton, int n_iter, double chi0, double max_diag0
     return q.pos;
 }
 
+/* Optimizer.cpp:283-303: chi2() > kernel->delta() (UNSQUARED) → level 1; s->chi2 holds computeActiveErrors' values */
+static int mark_outliers(oracle_sys* s) {
+    int n_out = 0;
+    for (int k = 0; k < s->No; ++k) {
+        if (s->obs_level[k] == 0 && s->obs_edge_ok[k] && s->chi2[k] > s->prm.robust_kernel_delta) {
+            s->obs_level[k] = 1; s->outlier[k] = 1; ++n_out;
+        }
+    }
+    return n_out;
+}
+/* stepping a solve by hand (tools/soak_diverge.py) */
+void oracle_sys_commit(oracle_sys* s) { sys_commit(s); }
+void oracle_sys_begin_phase(oracle_sys* s) { sys_begin(s); }
+int oracle_sys_mark_outliers(oracle_sys* s) {
+    (void)active_robust_chi2(s, s->pose, s->pt, 1);          /* computeActiveErrors at the estimate (:270) */
+    memcpy(s->final_chi2, s->chi2, (size_t)s->No * 8);
+    return s->prm.robust_kernel_delta > 0.0 ? mark_outliers(s) : 0;
+}
+
 int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* st, double* seconds) {
     visfs_ba_stats local;
     if (!st) st = &local;
@@ -1136,6 +1213,8 @@ int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* st, double* seconds) {
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const int half = s->prm.iterations / 2;
     st->iterations_run[0] = optimize_phase(s, half, st, 0);            /* Optimizer.cpp:265 */
+    { int n_ok = 0; for (int k = 0; k < s->No; ++k) n_ok += s->obs_edge_ok[k]; st->n_active_edges[0] = st->n_active_edges[1] = n_ok; }
+    st->pcg_iterations_phase[0] = st->pcg_iterations;
     /* :270-271 */
     double chi2 = active_robust_chi2(s, s->pose, s->pt, 1);
     if (half == 0) st->chi2_initial = chi2;
@@ -1145,19 +1224,15 @@ int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* st, double* seconds) {
     if (isnan(chi2)) status = VISFS_BA_ERR_NAN_CHI2;                   /* :272-275 */
     else if (chi2 > 1000000000000.0 || !isfinite(chi2)) status = VISFS_BA_ERR_HUGE_CHI2_1;  /* :277-280 */
     if (status == VISFS_BA_OK && s->prm.robust_kernel_delta > 0.0) {
-        /* :283-303: chi2() > kernel->delta() (UNSQUARED) → level 1 */
-        int n_out = 0;
-        for (int k = 0; k < s->No; ++k) {
-            if (s->obs_level[k] == 0 && s->obs_edge_ok[k] && s->chi2[k] > s->prm.robust_kernel_delta) {
-                s->obs_level[k] = 1; s->outlier[k] = 1; ++n_out;
-            }
-        }
+        const int n_out = mark_outliers(s);
         st->n_outliers = n_out;
+        st->n_active_edges[1] = st->n_active_edges[0] - n_out;
         st->iterations_run[1] = optimize_phase(s, half, st, 1);        /* :310-311 */
         /* :315 — activeRobustChi2 with the errors of the LAST evaluated state; restated at the committed state */
         st->chi2_final = active_robust_chi2(s, s->pose, s->pt, 0);
         if (st->chi2_final > 1000000000000.0) status = VISFS_BA_ERR_HUGE_CHI2_2;
     }
+    st->pcg_iterations_phase[1] = st->pcg_iterations - st->pcg_iterations_phase[0];
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     st->status = status;

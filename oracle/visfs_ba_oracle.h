@@ -75,6 +75,12 @@ int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* stats, double* seconds);
 void oracle_sys_download(oracle_sys* s, double* pose_tq, double* point_xyz, uint8_t* obs_outlier, double* obs_chi2);
 void oracle_sys_reset(oracle_sys* s);
 
+/* Stepping a solve by hand: discardTop (the trial becomes the estimate), algorithm->init() (PCG residual forgotten), the outlier
+ * pass of Optimizer.cpp:270-303 at the estimate (returns the number of edges moved to level 1). */
+void oracle_sys_commit(oracle_sys* s);
+void oracle_sys_begin_phase(oracle_sys* s);
+int oracle_sys_mark_outliers(oracle_sys* s);
+
 /* The LM / Gauss-Newton schedule ([g2o-upstream] OptimizationAlgorithmLevenberg::solve inside SparseOptimizer::optimize) run on
  * SCRIPTED trial outcomes: trial t of one optimize(n_iter) call returns (temp_chi[t], scale[t] = computeScale() without the
  * +1e-3, ok[t]); linearise reports the committed chi2 (chi0 at the start) and max_diag0.  Fills stats->trace_*, iterations_run[0],

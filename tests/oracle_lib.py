@@ -48,6 +48,9 @@ def load(omp=False):
     lib.oracle_sys_optimize.restype = C.c_int
     lib.oracle_sys_download.argtypes = [C.c_void_p, _pd, _pd, C.POINTER(C.c_uint8), _pd]
     lib.oracle_sys_reset.argtypes = [C.c_void_p]
+    for name in ("oracle_sys_commit", "oracle_sys_begin_phase", "oracle_sys_mark_outliers"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.oracle_sys_mark_outliers.restype = C.c_int
     lib.oracle_lm_script.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _pd, _pd, C.POINTER(C.c_int32), C.POINTER(abi.Stats)]
     lib.oracle_lm_script.restype = C.c_int
     lib.oracle_solve_window.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Window), C.POINTER(abi.Result), C.c_int]
@@ -84,6 +87,15 @@ class OracleSystem:
         chi, sc, it, ok = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
         self.lib.oracle_sys_trial(self.h, lam, C.byref(chi), C.byref(sc), C.byref(it), C.byref(ok))
         return chi.value, sc.value, it.value, ok.value
+
+    def commit(self):
+        self.lib.oracle_sys_commit(self.h)
+
+    def begin_phase(self):
+        self.lib.oracle_sys_begin_phase(self.h)
+
+    def mark_outliers(self):
+        return self.lib.oracle_sys_mark_outliers(self.h)
 
     def fetch(self, which):
         n6 = 6 * self.npf

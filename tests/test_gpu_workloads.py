@@ -1,0 +1,138 @@
+"""GPU parity tests of the BASELINE.json workloads that round 1 left without a `-m gpu` test, and of the residency rules of the
+persistent PCG (one grid at a time per device; a batched launch never carries more block rows than the device holds)."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from helpers import graph_of, rel_err
+from test_gpu_parity import check_optimize, make_pair
+from visfs_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c5_per_gpu_workload_eight_resident_c2_windows(olib):
+    """BASELINE config 5, one GPU's share: 8 independent C2-size windows resident side by side, solved by ONE sequence of batched
+    launches (visfs_ba_batch_upload / optimize, blockIdx.y = window).  Every window must come out bit-identical to its own solve
+    as a batch of one (same launch geometry class, same chunking), and one of them is checked against the CPU oracle."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=20, solver=2)
+    gbs = []
+    for i in range(8):
+        w = synth.make_window("C5", window_index=i)
+        wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+        gbs.append(gb)
+    s = backend.Solver(prm)
+    s.batch_upload(gbs)
+    s.batch_reset()
+    rc, stats = s.batch_optimize()
+    assert rc == abi.OK and all(st.status == abi.OK for st in stats)
+    assert all(st.iterations_run[0] + st.iterations_run[1] == 20 for st in stats)
+    got = [s.batch_download(i) for i in range(8)]
+    # (a) each window alone, as a batch of one
+    for i in (0, 3, 7):
+        s1 = backend.Solver(prm)
+        s1.batch_upload([gbs[i]]); s1.batch_reset()
+        rc1, st1 = s1.batch_optimize()
+        ref = s1.batch_download(0)
+        s1.close()
+        assert rc1 == abi.OK
+        assert all(np.array_equal(a, b) for a, b in zip(got[i], ref)), f"window {i} differs from its single solve"
+        assert list(st1[0].iterations_run) == list(stats[i].iterations_run) and st1[0].pcg_iterations == stats[i].pcg_iterations
+    # (b) the oracle on one of them: same LM trajectory, outliers, poses
+    o = oracle_lib.OracleSystem(olib, prm, gbs[5])
+    rco, sto, _ = o.optimize()
+    po, pto, outo, chio = o.download(); o.close()
+    assert rco == abi.OK and list(sto.iterations_run) == list(stats[5].iterations_run) and list(sto.trials_run) == list(stats[5].trials_run)
+    assert sto.pcg_iterations == stats[5].pcg_iterations
+    assert np.array_equal(outo, got[5][2])
+    assert rel_err(got[5][0], po) < 1e-6 and rel_err(got[5][1], pto) < 1e-6
+    # (c) a second batched run reproduces the first bit for bit
+    s.batch_reset(); s.batch_optimize()
+    assert all(all(np.array_equal(a, b) for a, b in zip(s.batch_download(i), got[i])) for i in range(8))
+    s.close()
+
+
+def test_c4_direct_solver_parity(olib):
+    """BASELINE config 4 with the reference-default linear solver (Optimizer/Solver=0, Parameters.h:185): the 1194 x 1194 reduced
+    camera system (padded to 1216: 38 panels) through the blocked Cholesky with the fp64-MFMA trailing update."""
+    o, s, gb = make_pair(olib, synth.make_window("C4"), iterations=10, solver=0)
+    assert s.describe()["n_free_poses"] == 199
+    check_optimize(o, s, pose_tol=1e-5)
+    a = s.download()
+    s.reset(); s.optimize()
+    assert all(np.array_equal(x, y) for x, y in zip(a, s.download()))          # run-to-run bitwise identical
+    s.close(); o.close()
+
+
+def test_two_handles_with_persistent_pcg_on_two_threads(olib):
+    """Two Optimizer instances on one device, both with Optimizer/Solver=2 on C4-size windows (199 block rows each), driven from
+    two threads at once: their persistent-PCG grids must not be interleaved on the device (each needs all its workgroups
+    resident).  Both must finish OK with the results of a sequential run."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("C4", window_index=i) for i in range(2)]
+    solvers, refs = [], []
+    for w in ws:
+        s = backend.Solver(prm)
+        gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+        s.upload(gb)
+        rc, st = s.optimize()
+        assert rc == abi.OK
+        refs.append(s.download())
+        solvers.append(s)
+    results = [None, None]
+
+    def run(k):
+        out = []
+        for _ in range(3):
+            solvers[k].reset()
+            rc, st = solvers[k].optimize()
+            out.append((rc, solvers[k].download()))
+        results[k] = out
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(2):
+        for rc, out in results[k]:
+            assert rc == abi.OK
+            assert all(np.array_equal(a, b) for a, b in zip(out, refs[k]))
+        solvers[k].close()
+
+
+def test_batch_above_the_residency_cap_splits_and_stays_bit_identical(olib, monkeypatch):
+    """A batched launch sequence may carry only as many PCG block rows as the device holds at once (occupancy query x CUs); a
+    larger batch is cut into several sequences.  VISFS_BA_PCG_CAPACITY forces a tiny cap: six 29-row windows then run as batches
+    of two, and every result equals the uncapped run."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=40 + i) for i in range(6)]
+    s = backend.Solver(prm)
+    ref = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    s.close()
+    monkeypatch.setenv("VISFS_BA_PCG_CAPACITY", "64")          # 64 // 29 = 2 windows per launch sequence
+    s = backend.Solver(prm)
+    got = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    s.close()
+    for a, b in zip(ref, got):
+        assert a.struct.status == b.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert a.struct.chi2_final == b.struct.chi2_final
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_one_wave_pcg_kernel_and_four_wave_kernel_agree(olib, monkeypatch, cfg):
+    """<= 64 free poses: k_pcg1 (one wavefront per block row, no LDS, no barrier) and k_pcg (four waves) run the same recurrences
+    with a different association of the mat-vec sums: same iteration counts, results equal to rounding, both in parity with the oracle."""
+    from test_gpu_parity import _solve_in_mode
+    w = synth.make_window(cfg)
+    _, rc1, st1, out1 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_PCG1="1"), iterations=20, solver=2)
+    _, rc0, st0, out0 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_PCG1="0"), iterations=20, solver=2)
+    assert rc0 == rc1 == abi.OK
+    assert list(st0.iterations_run) == list(st1.iterations_run) and list(st0.trials_run) == list(st1.trials_run)
+    assert st0.pcg_iterations == st1.pcg_iterations
+    assert np.array_equal(out0[2], out1[2])
+    assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10

@@ -20,9 +20,9 @@ for wg in (0, 24, 48):
     t_start = int(st[127]); t0 = int(st[0])
     print(f"wg {wg}: setup {(t0 - t_start) * 10} ns")
     k = 0
-    while 4 + 4 * k < 126 and st[4 + 4 * k] > st[0] and (k == 0 or st[4 + 4 * k] > st[4 * k]):
+    while 4 + 4 * k < 100 and st[4 + 4 * k] > st[0] and (k == 0 or st[4 + 4 * k] > st[4 * k]):
         a, b, c, d = (int(st[1 + 4 * k]), int(st[2 + 4 * k]), int(st[3 + 4 * k]), int(st[4 + 4 * k]))
         prev = t0 if k == 0 else int(st[4 * k])
-        print(f"   iter {k}: matvec+barrier {(a - prev) * 10:6d} ns | publish {(b - a) * 10:5d} | gather+barrier {(c - b) * 10:6d} | vector+barrier {(d - c) * 10:6d} | total {(d - prev) * 10}")
+        print(f"   iter {k}: matvec+barrier {(a - prev) * 10:6d} ns | publish {(b - a) * 10:5d} | gather+barrier {(c - b) * 10:6d} (extra sweeps {int(st[100 + k]) if k < 26 else -1}) | vector+barrier {(d - c) * 10:6d} | total {(d - prev) * 10}")
         k += 1
     s.close()

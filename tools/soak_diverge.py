@@ -1,0 +1,100 @@
+"""Where do the soak's divergent windows part ways?  
+
+For a seed of tests/test_gpu_random.random_case the GPU path and the CPU oracle are STEPPED side by side through the stage hooks
+(linearise -> damped / undamped solve -> commit, outlier pass between the phases) — the very trajectory `optimize` runs for an
+undamped Gauss-Newton window (Optimizer/TrustRegion=1: every step is taken).  After every stage the buffers of both sides are
+compared; the first stage whose relative difference exceeds 1e-9 is reported together with the 2-norm condition number of the
+reduced camera matrix S of that iteration and of the smallest landmark block (H_ll + lambda I) — the two inverses the iteration
+takes.  A difference that first appears in `dx_pose` / `dx_point` with cond(S) or cond(H_ll) >= 1e9 beside inputs (S, b_s, H_ll,
+b_l) that still agree to 1e-12 is rounding amplified by a near-singular system; anything else would be a bug.
+
+usage: python tools/soak_diverge.py 756 781 1102 1108 113 ..."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import oracle_lib
+import test_gpu_random as T
+from helpers import rel_err
+from visfs_amd import abi, backend
+
+LIN = [("chi2", abi.BUF_OBS_CHI2), ("weight", abi.BUF_OBS_WEIGHT), ("Hll", abi.BUF_HLL), ("bl", abi.BUF_BL), ("Hpp", abi.BUF_HPP), ("bp", abi.BUF_BP)]
+TRIAL = [("S", abi.BUF_S), ("bs", abi.BUF_BS), ("dx_pose", abi.BUF_DX_POSE), ("dx_point", abi.BUF_DX_POINT),
+         ("pose_trial", abi.BUF_POSE_TRIAL), ("point_trial", abi.BUF_POINT_TRIAL)]
+TOL = 1e-9
+
+
+def landmark_conds(o, lam):
+    """cond_2 of every free landmark's (H_ll + lambda I) that has an active edge (the oracle's values)."""
+    H = o.fetch(abi.BUF_HLL).reshape(-1, 6)
+    M = np.zeros((len(H), 3, 3))
+    M[:, 0, 0], M[:, 0, 1], M[:, 0, 2], M[:, 1, 1], M[:, 1, 2], M[:, 2, 2] = H[:, 0] + lam, H[:, 1], H[:, 2], H[:, 3] + lam, H[:, 4], H[:, 5] + lam
+    M[:, 1, 0], M[:, 2, 0], M[:, 2, 1] = M[:, 0, 1], M[:, 0, 2], M[:, 1, 2]
+    act = np.abs(H).sum(axis=1) > 0
+    if not act.any():
+        return 1.0
+    sv = np.linalg.svd(M[act], compute_uv=False)
+    with np.errstate(divide="ignore"):
+        return float(np.max(sv[:, 0] / sv[:, -1]))
+
+
+def step_case(olib, lib, seed):
+    w, kw = T.random_case(seed)
+    prm = abi.default_params(**kw)
+    if kw["trust_region"] != 1:
+        return f"seed {seed}: not a Gauss-Newton case ({kw}) — this tool steps the undamped trajectory only"
+    gb, *_ = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    o = oracle_lib.OracleSystem(olib, prm, gb)
+    s = backend.Solver(prm); s.upload(gb)
+    half = kw["iterations"] // 2
+    first, log = None, []
+    for phase in range(2):
+        o.begin_phase(); s.begin_phase()
+        for it in range(half):
+            oc, omd = o.linearize(); gc, gmd = s.linearize()
+            worst = [(name, rel_err(s.fetch(b), o.fetch(b))) for name, b in LIN]
+            ot, gt = o.trial(0.0), s.trial(0.0)
+            worst += [(name, rel_err(s.fetch(b), o.fetch(b))) for name, b in TRIAL]
+            S = o.fetch(abi.BUF_S); n6 = int(round(np.sqrt(S.size)))
+            condS = float(np.linalg.cond(S.reshape(n6, n6))) if n6 else 1.0
+            condL = landmark_conds(o, 0.0)
+            bad = [(n, e) for n, e in worst if not (e <= TOL)]
+            log.append(f"   phase {phase + 1} it {it}: chi2 {oc:.6g} | cond(S) {condS:.2e} cond(Hll) {condL:.2e} | solver ok o/g {ot[3]}/{gt[3]} | "
+                       + ("all stages <= 1e-9" if not bad else "FIRST > 1e-9: " + ", ".join(f"{n} {e:.1e}" for n, e in bad)))
+            if bad and first is None:
+                inputs = max(e for n, e in worst if n in ("S", "bs", "Hll", "bl", "Hpp", "bp"))
+                first = dict(phase=phase + 1, it=it, stages=bad, condS=condS, condL=condL, inputs=inputs, chi2=oc)
+            if not (ot[3] and gt[3]):
+                break
+            o.commit(); s.commit()
+        if phase == 0:
+            if kw["robust_kernel_delta"] > 0.0:
+                n_o = o.mark_outliers(); s.mark_outliers()
+                outo = o.download()[2]; outg = s.download()[2]
+                log.append(f"   outlier pass: oracle {n_o} edges, sets equal: {bool(np.array_equal(outo, outg))}")
+                if not np.array_equal(outo, outg) and first is None:
+                    first = dict(phase=1, it=half, stages=[("outlier set", float("nan"))], condS=float("nan"), condL=float("nan"), inputs=float("nan"), chi2=float("nan"))
+            else:
+                break
+    o.close(); s.close()
+    head = f"seed {seed} {kw}: "
+    if first is None:
+        head += "no stage differs by more than 1e-9 over the whole stepped trajectory"
+    else:
+        kind = "rounding amplified by a near-singular system" if (first["inputs"] <= 1e-11 and max(first["condS"], first["condL"]) >= 1e9) else "UNEXPLAINED"
+        head += (f"first difference > 1e-9 at phase {first['phase']} iteration {first['it']} in {[n for n, _ in first['stages']]}; inputs of that solve "
+                 f"agree to {first['inputs']:.1e}; cond(S) = {first['condS']:.2e}, max cond(Hll) = {first['condL']:.2e} -> {kind}")
+    return head + "\n" + "\n".join(log)
+
+
+def main():
+    olib = oracle_lib.load(); lib = backend.load_library()
+    for a in sys.argv[1:]:
+        print(step_case(olib, lib, int(a)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_TRACE = 64
 
 # status codes (include/visfs_ba.h)
@@ -111,7 +111,8 @@ class Stats(C.Structure):
                 ("pcg_iterations", C.c_int32), ("n_outliers", C.c_int32),
                 ("chi2_initial", C.c_double), ("chi2_phase1", C.c_double), ("chi2_final", C.c_double),
                 ("n_trace", C.c_int32), ("trace_lambda", C.c_double * MAX_TRACE),
-                ("trace_chi2", C.c_double * MAX_TRACE)]
+                ("trace_chi2", C.c_double * MAX_TRACE),
+                ("n_active_edges", C.c_int32 * 2), ("pcg_iterations_phase", C.c_int32 * 2)]
 
 
 def _ptr(a, ctype):

@@ -24,7 +24,7 @@ EXPORTS = [
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
     "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
-    "visfs_ba_hook_lm_script",
+    "visfs_ba_hook_lm_script", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
 ]
 
 _lib = None
@@ -82,6 +82,9 @@ def load_library():
     lib.visfs_ba_profile_enable.restype = C.c_int
     lib.visfs_ba_profile_read.argtypes = [C.c_void_p, C.POINTER(abi.Profile)]
     lib.visfs_ba_profile_read.restype = C.c_int
+    for name in ("visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+        getattr(lib, name).restype = C.c_int
     lib.visfs_ba_hook_lm_script.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _pd, _pd, C.POINTER(C.c_int32), C.POINTER(abi.Stats)]
     lib.visfs_ba_hook_lm_script.restype = C.c_int
     if lib.visfs_ba_abi_version() != abi.ABI_VERSION:
@@ -203,6 +206,15 @@ class Solver:
         chi, sc, it, ok = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
         self._check(self.lib.visfs_ba_stage_trial(self.h, lam, C.byref(chi), C.byref(sc), C.byref(it), C.byref(ok)), "stage_trial")
         return chi.value, sc.value, it.value, ok.value
+
+    def commit(self):
+        self._check(self.lib.visfs_ba_stage_commit(self.h), "stage_commit")
+
+    def begin_phase(self):
+        self._check(self.lib.visfs_ba_stage_begin_phase(self.h), "stage_begin_phase")
+
+    def mark_outliers(self):
+        self._check(self.lib.visfs_ba_stage_mark_outliers(self.h), "stage_mark_outliers")
 
     def fetch(self, which):
         n6 = 6 * self.npf

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -51,6 +52,9 @@ struct Workspace {
     bool spec = false;                             // units end with the speculative linearisation + LM decision launch
     int extra_units[2] = { 0, 0 };                 // rejected trials per phase of the previous solve: units enqueued on top of `half`
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
+    // VISFS_BA_GRAPH=1 (measurement): the up-front launch sequence of a solve captured once per resident graph and replayed
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_units[2] = { -1, -1 };
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
     int64_t n_pairs = 0;
@@ -148,6 +152,7 @@ void ws_release(Workspace& w) {
     if (w.h_base) (void)hipHostFree(w.h_base);
     if (w.h_state) (void)hipHostFree(w.h_state);
     for (hipEvent_t e : w.ev_pool) (void)hipEventDestroy(e);
+    if (w.graph_exec) (void)hipGraphExecDestroy(w.graph_exec);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     w = Workspace{};
 }
@@ -192,6 +197,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     }
     int rc = ws_init(h, w);
     if (rc != VISFS_BA_OK) return rc;
+    if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; w.graph_units[0] = w.graph_units[1] = -1; }   // kernel arguments change
 
     // buildIndexMapping: free poses in index (= id) order
     std::vector<int32_t> pose_free(Np), free_pose;
@@ -201,7 +207,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     for (int k = 0; k < No; ++k) lm_ptr[gr->obs_point[k] + 1]++;
     for (int l = 0; l < Nl; ++l) lm_ptr[l + 1] += lm_ptr[l];
     std::vector<uint8_t> obs_ok(std::max(No, 1));
-    for (int k = 0; k < No; ++k) obs_ok[k] = !(gr->pose_fixed[gr->obs_pose[k]] && gr->point_fixed[gr->obs_point[k]]);
+    int n_edges_ok = 0;
+    for (int k = 0; k < No; ++k) { obs_ok[k] = !(gr->pose_fixed[gr->obs_pose[k]] && gr->point_fixed[gr->obs_point[k]]); n_edges_ok += obs_ok[k]; }
 
     // pose-major permutation of the observations of free poses, cut into chunks
     std::vector<int32_t> cnt(Npf + 1, 0);
@@ -350,6 +357,14 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (pcg_lds + (size_t)288 * max_row <= budget) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
     }
 
+    // k_pcg1 (one wavefront per block row, <= 64 free poses): the block of S at (i, a) as a dense code table
+    const bool pcg1 = [&]() { const char* e = std::getenv("VISFS_BA_PCG1"); return prm.solver == 2 && Npf >= 1 && Npf <= 64 && !(e && e[0] == '0'); }();
+    std::vector<int32_t> pcg1_code;
+    if (pcg1) {
+        pcg1_code.assign((size_t)Npf * Npf, -1);
+        for (int a = 0; a < Npf; ++a)
+            for (int n = row_ptr[a]; n < row_ptr[a + 1]; ++n) pcg1_code[(size_t)a * Npf + row_col[n]] = row_blk[n];
+    }
     lap("pair count");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -395,6 +410,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.row_ptr = A.take<int32_t>(Npf + 1);
         g.row_col = A.take<int32_t>(std::max<size_t>(row_col.size(), 1));
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
+        g.pcg1_code = pcg1 ? A.take<int32_t>((size_t)Npf * Npf) : nullptr;
         g.laser_xyz = A.take<double>((size_t)std::max(Nz, 1) * 3);
         g.grid.cost = A.take<float>(std::max<size_t>(grid_cells, 1));
     };
@@ -498,6 +514,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (!blk_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.blk_odo), blk_odo.data(), blk_odo.size() * 4);
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
+        if (pcg1) std::memcpy(const_cast<int32_t*>(hg.pcg1_code), pcg1_code.data(), pcg1_code.size() * 4);
         if (Nz) {
             std::memcpy(const_cast<double*>(hg.laser_xyz), gr->laser_xyz, (size_t)Nz * 24);
             std::memcpy(const_cast<float*>(hg.grid.cost), gr->grid->correspondence_cost, grid_cells * 4);
@@ -511,7 +528,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     layout_dyn(dd, dg);
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_pose_obs = cnt[Npf];
-    dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group;
+    dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
@@ -585,6 +602,31 @@ void fill_stats(const LmState& st, visfs_ba_stats* out) {
     out->chi2_initial = st.chi2_initial; out->chi2_phase1 = st.chi2_phase1; out->chi2_final = st.chi2_final;
     out->n_trace = st.n_trace;
     for (int i = 0; i < st.n_trace && i < MAX_TRACE; ++i) { out->trace_lambda[i] = st.trace_lambda[i]; out->trace_chi2[i] = st.trace_chi2[i]; }
+    out->n_active_edges[0] = st.n_edges_ok; out->n_active_edges[1] = st.n_edges_ok - st.n_outliers;
+    const int p1 = st.ended >= 1 ? st.pcg_phase1 : st.pcg_total;
+    out->pcg_iterations_phase[0] = p1; out->pcg_iterations_phase[1] = st.pcg_total - p1;
+}
+
+// The persistent PCG (k_pcg / k_pcg1) only terminates when every workgroup of a window's grid is resident on the device.  Inside
+// one stream launches are serialised; two handles (or two threads of the legacy one-stream-per-window mode) could otherwise have
+// two partially resident grids starve each other until the bounded spins give up (VISFS_BA_ERR_DEVICE).  So every solve that
+// carries a persistent PCG holds this per-device lock from its first launch to its last state read.  Other PROCESSES sharing the
+// GPU are not covered: the library assumes exclusive use of the device for Optimizer/Solver=2 (include/visfs_ba.h).
+std::mutex& pcg_device_mutex(int device) {
+    static std::mutex m[64];
+    return m[(unsigned)device % 64u];
+}
+
+// Members of one batched launch sequence: rows x members workgroups of the persistent PCG must be resident together.
+int batch_members_per_launch(visfs_ba_handle* h, const std::vector<Workspace*>& ws, const std::vector<int>& all) {
+    LaunchDims d = dims_of(ws[all[0]]->g);
+    bool no_pcg = true;
+    for (int i : all) { d = dims_max(d, dims_of(ws[i]->g)); no_pcg = no_pcg && (ws[i]->small_solve || ws[i]->fused); }
+    if (no_pcg) return 4096;                               // single-workgroup solvers: no co-residency requirement
+    int cap = pcg_resident_capacity(d, true, h->device);
+    if (cap <= 0) cap = 256;                               // query failed: one 256-thread workgroup per CU is always admitted
+    { const char* e = std::getenv("VISFS_BA_PCG_CAPACITY"); if (e && std::atoi(e) > 0) cap = std::atoi(e); }   // tests: force a split
+    return std::max(1, cap / std::max(1, d.pcg_rows));
 }
 
 // Optimizer.cpp:261-318 on the resident graph.
@@ -592,6 +634,8 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     const int half = h->prm.iterations / 2;
+    std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
+    if (h->prm.solver == 2 && !w.small_solve && !w.fused) pcg_lock.lock();          // persistent PCG: one grid at a time per device
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
     { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     if (w.fused) {
@@ -618,10 +662,28 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     };
     // (a window that rejected trials last time — an estimator's consecutive frames behave alike — gets that many units more up
     // front: a gated no-op unit costs ~7 us, the state read it saves ~25 us plus the bubble behind it)
-    enqueue_units(half + w.extra_units[0], true);                                                   // :265
-    phase_end(0);
-    enqueue_units(half2 > 0 ? half2 + w.extra_units[1] : 0, true);
-    phase_end(1);
+    static const bool use_graph = []() { const char* e = std::getenv("VISFS_BA_GRAPH"); return e && e[0] == '1'; }();
+    const int n0 = half + w.extra_units[0], n1 = half2 > 0 ? half2 + w.extra_units[1] : 0;
+    if (use_graph && !w.prof_mask) {
+        // measurement variant: the same launches as one hipGraph, captured once per (resident graph, unit counts) and replayed
+        // (the reset launched above stays outside).  Eager launches are the default: see DESIGN.md §4 for the numbers.
+        if (!w.graph_exec || w.graph_units[0] != n0 || w.graph_units[1] != n1) {
+            if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
+            hipGraph_t gr = nullptr;
+            HIP_TRY(h, hipStreamBeginCapture(w.stream, hipStreamCaptureModeThreadLocal));
+            enqueue_units(n0, true); phase_end(0); enqueue_units(n1, true); phase_end(1);
+            HIP_TRY(h, hipStreamEndCapture(w.stream, &gr));
+            HIP_TRY(h, hipGraphInstantiate(&w.graph_exec, gr, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(gr);
+            w.graph_units[0] = n0; w.graph_units[1] = n1;
+        }
+        HIP_TRY(h, hipGraphLaunch(w.graph_exec, w.stream));
+    } else {
+        enqueue_units(n0, true);                                                                    // :265
+        phase_end(0);
+        enqueue_units(n1, true);
+        phase_end(1);
+    }
     int rc = VISFS_BA_OK;
     for (int guard = 0;; ++guard) {
         HIP_TRY(h, hipGetLastError());
@@ -811,6 +873,8 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         d = dims_max(d, dims_of(w.g));
         fused = fused && w.fused; small_solve = small_solve && w.small_solve;
     }
+    std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
+    if (!fused && !small_solve) pcg_lock.lock();                                    // persistent PCG: one grid at a time per device
     HIP_TRY(h, hipMemcpyAsync(bs.d_graphs, hg.data(), (size_t)B * sizeof(DeviceGraph), hipMemcpyHostToDevice, stream));
     const int half = h->prm.iterations / 2;
     launch_reset_batch(bs.d_graphs, B, d, half, h->prm.trust_region == 1, 0, stream);
@@ -1023,7 +1087,9 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
     for (int i = 0; i < n; ++i) if (!w[i] || !r[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
     // Independent windows (BASELINE config 5).  Host work (graph build, upload, write-back) runs on up to 8
     // threads, one workspace per window; the optimisation itself is ONE sequence of launches per group of windows with the
-    // same launch-geometry class, blockIdx.y = window (batch_optimize).  VISFS_BA_BATCH=0 falls back to one stream per lane.
+    // same launch-geometry class, blockIdx.y = window (batch_optimize).  Windows that cannot share launches (direct solver on
+    // reduced systems above 64 x 64, or VISFS_BA_BATCH=0) are optimised one after another on the calling thread, each on its own
+    // stream: their persistent-PCG / panel launches would gain nothing from overlapping and PCG grids must not (pcg_device_mutex).
     return guarded(h, [&]() -> int {
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         const int lanes = std::max(1, std::min<int>(n, 8));
@@ -1066,11 +1132,9 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
         std::vector<visfs_ba_stats> stats(n);
         int worst = VISFS_BA_OK;
         for (auto& kv : groups) {
-            // keep the persistent PCG grid of one launch within what the device holds comfortably
+            // the persistent PCG grid of one launch sequence must be resident as a whole: sized from the device's occupancy
             const std::vector<int>& all = kv.second;
-            int rows = 1;
-            for (int i : all) rows = std::max(rows, h->batch[i]->g.Npf);
-            const int per = std::max(1, 2048 / rows);
+            const int per = batch_members_per_launch(h, h->batch, all);
             for (size_t o = 0; o < all.size(); o += per) {
                 std::vector<int> members(all.begin() + o, all.begin() + std::min(all.size(), o + per));
                 const int rc = batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
@@ -1137,9 +1201,7 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
         int worst = VISFS_BA_OK;
         for (auto& kv : groups) {
             const std::vector<int>& all = kv.second;
-            int rows = 1;
-            for (int i : all) rows = std::max(rows, h->batch[i]->g.Npf);
-            const int per = std::max(1, 2048 / rows);
+            const int per = batch_members_per_launch(h, h->batch, all);
             for (size_t o = 0; o < all.size(); o += per) {
                 std::vector<int> members(all.begin() + o, all.begin() + std::min(all.size(), o + per));
                 const int rc = batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
@@ -1342,6 +1404,40 @@ static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size
             dst[(size_t)(6 * b + c) * n6 + 6 * a + r] += v;
         }
     }
+    return VISFS_BA_OK;
+}
+
+// Stage hooks for stepping a solve by hand (tools/soak_diverge.py): commit the last trial state, start a phase
+// (LinearSolverPCG::init()), run the outlier pass on the committed estimate.
+int visfs_ba_stage_commit(visfs_ba_handle* h) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    int rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    w.h_state->sel ^= 1;
+    HIP_TRY(h, hipMemcpyAsync(w.g.st, w.h_state, sizeof(LmState), hipMemcpyHostToDevice, w.stream));
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
+    return VISFS_BA_OK;
+}
+int visfs_ba_stage_begin_phase(visfs_ba_handle* h) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    int rc = ws_read_state(h, w);
+    if (rc != VISFS_BA_OK) return rc;
+    w.h_state->pcg_residual = -1.0; w.h_state->pcg_res_in = -1.0; w.h_state->status = 0;
+    HIP_TRY(h, hipMemcpyAsync(w.g.st, w.h_state, sizeof(LmState), hipMemcpyHostToDevice, w.stream));
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
+    return VISFS_BA_OK;
+}
+int visfs_ba_stage_mark_outliers(visfs_ba_handle* h) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    Workspace& w = h->ws;
+    if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
+    launch_eval_mark(w.g, w.stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(w.stream));
     return VISFS_BA_OK;
 }
 

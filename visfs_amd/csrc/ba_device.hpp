@@ -66,6 +66,8 @@ struct LmState {
     int32_t spec_src;       // ... the estimate buffer holding it (sel ^ 1 at that time)
     int32_t spec_dst;       // ... the linearisation buffer to fill (lin_sel ^ 1 at that time)
     int32_t ended;          // phase ends applied so far (0, 1, 2): k_eval / k_phase_end act only when the phase they close is done
+    int32_t pcg_phase1;     // pcg_total when phase 1 ended
+    int32_t n_edges_ok;     // stereo edges that can ever be active (not both ends fixed): the active set of phase 1
 };
 
 // The outputs of a linearisation that the Schur complement and the back-substitution consume.  Two sets: while the LM decision
@@ -92,6 +94,7 @@ struct DeviceGraph {
     int32_t pcg_lds_bytes;
     int32_t chol_np;        // padded order of the dense reduced camera matrix (direct solver)
     int32_t n_lin_a;        // workgroups of the landmark-major role
+    int32_t n_edges_ok;     // stereo edges whose two ends are not both fixed (the active set before the outlier pass)
     int32_t group;          // lanes per landmark (4/8/16/32/64)
     double fx, fy, cx, cy, bf;
     double inv_pixel_var, inv_odo_cov, huber_delta;
@@ -137,6 +140,8 @@ struct DeviceGraph {
     const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)
     const int32_t* row_col;     // [..] column block
     const int32_t* row_blk;     // [..] stored block id * 2 + transposed
+    const int32_t* pcg1_code;   // [Npf][Npf] stored block id * 2 + transposed of S(i, a), -1: no block — only for <= 64 free poses with PCG
+                                //   (k_pcg1: one wavefront per block row); nullptr otherwise
 
     // ---- estimates ----
     double* pose[2];            // [Np][8]

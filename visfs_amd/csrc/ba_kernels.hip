@@ -29,6 +29,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace visfs_ba {
 
@@ -1251,6 +1252,235 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     }
 }
 
+// ---- K6, reduced systems of <= 64 block rows: ONE WAVEFRONT per block row, everything in registers
+// Same algorithm, same hand-off (granules, Guideline 16 form R2) as k_pcg, laid out so that an iteration needs no LDS and no
+// barrier at all: lane a of EVERY wave owns block column a — its 6-blocks of r, d, x, its Minv block and the block S(i, a) of the
+// wave's own row i (zero when the row has no such block) all live in registers.  q_i = S_i d is 36 multiply-adds per lane and
+// one 6-value reduce-scatter over the wave (in-row DPP stages first, so only two values cross rows); the owners of the six sums
+// store the twelve granules; lane a then polls exactly the twelve granules of q_a (96 contiguous bytes) — what it needs for
+// its share of the vector recurrences, which every wave performs redundantly and bitwise identically (same data, same
+// instruction sequence), so all waves take the same branch at every convergence test.  The four-wave k_pcg paid three workgroup
+// barriers and six LDS round trips per iteration for the same arithmetic (stamped: 1.3 us of a 2.5 us iteration).
+// Upward halving reduce-scatter (masks 1, 2, 4, ... 32): like ReduceScatter, cheap in-row exchanges while the array is long.
+template <int N, int M>
+struct ReduceScatterUp {
+    static __device__ __forceinline__ void run(double* a, int lane, int& off, int& len) {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (lane & M) != 0;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const double lo = a[j];
+            const double hi = (j + H < N) ? a[j + H] : 0.0;
+            const double send = up ? lo : hi;
+            const double keep = up ? hi : lo;
+            a[j] = keep + xor_lane<M>(send);
+        }
+        if (up) { off += H; len = len > H ? len - H : 0; } else { len = len < H ? len : H; }
+        ReduceScatterUp<H, M * 2>::run(a, lane, off, len);
+    }
+};
+template <int N>
+struct ReduceScatterUp<N, 64> {
+    static __device__ __forceinline__ void run(double*, int, int&, int&) {}
+};
+
+// GV (gather variant, measured in profiles/r02_pcg1_gather_variants.log): 0 = twelve 8-byte loads per sweep, one sweep in flight;
+// 1 = six 16-byte loads (two granules each: every 8-byte half is one store of its producer); 2 = 1 + the next sweep is issued
+// before the previous one is checked (two sweeps in flight: the poll period halves without waiting less).
+template <class Src, int GV>
+__global__ __launch_bounds__(64) void k_pcg1(const Src src) {
+    const DeviceGraph& g = graph_of(src);
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    const int i0 = blockIdx.x;
+    if (i0 >= g.Npf) return;                          // a batched launch is sized for the largest window
+    const int lane = threadIdx.x;
+    const int Npf = g.Npf, n6 = 6 * Npf;
+    const bool own = lane < Npf;
+#ifdef VISFS_BA_STAMPS
+#define PCG1_STAMP(slot) do { if (lane == 0 && i0 == g.stamp_wg && (slot) < 100) g.stamps[(slot)] = wall_clock64(); } while (0)
+    if (lane == 0 && i0 == g.stamp_wg) g.stamps[127] = wall_clock64();
+#else
+#define PCG1_STAMP(slot) do { } while (0)
+#endif
+    // ---- set-up: S(i0, lane), Minv_lane, r = b_s; every load below is independent of the others
+    const int code = own ? g.pcg1_code[i0 * Npf + lane] : -1;
+    double Sr[36], mm[36], rr[6], dd[6], xx[6];
+    {
+        const double2* Sb = reinterpret_cast<const double2*>(g.S + 36 * (size_t)(code >= 0 ? (code >> 1) : 0));
+        const double2* Mb = reinterpret_cast<const double2*>(g.Minv + 36 * (size_t)(own ? lane : 0));
+        double sv[36];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const double2 v = (code >= 0) ? Sb[q] : make_double2(0.0, 0.0);
+            sv[2 * q] = v.x; sv[2 * q + 1] = v.y;
+            const double2 m = own ? Mb[q] : make_double2(0.0, 0.0);
+            mm[2 * q] = m.x; mm[2 * q + 1] = m.y;
+        }
+        const bool tr = (code & 1) != 0;              // the stored block is (lane, i0): use its transpose
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Sr[6 * r + c] = tr ? sv[6 * c + r] : sv[6 * r + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { rr[c] = own ? g.bs[6 * (own ? lane : 0) + c] : 0.0; xx[c] = 0.0; }
+    }
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v += mm[6 * r + c] * rr[c];
+        dd[r] = v;
+        part += rr[r] * v;
+    }
+    double dn = wave_sum(part);
+    double d0 = 1e-6 * dn;
+    {
+        const double res_in = st->pcg_res_in;
+        if (res_in > 0.0 && res_in > d0) d0 = res_in;
+    }
+    int iter = 0;
+    bool timeout = false;
+    PCG1_STAMP(0);
+    while (true) {
+        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
+        // ---- q_i0 = sum_a S(i0, a) d_a: six partial sums per lane, reduce-scattered over the wave
+        double y[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v += Sr[6 * r + c] * dd[c];
+            y[r] = v;
+        }
+        int off = 0, len = 6;
+        ReduceScatterUp<6, 1>::run(y, lane, off, len);
+        const unsigned epoch = (unsigned)iter + 1u;
+        unsigned long long* gr = g.granules + (size_t)(iter & 1) * (2 * n6);
+        PCG1_STAMP(1 + 4 * iter);
+        if (len >= 1) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(y[0]);
+            unsigned long long* o = gr + 2 * (6 * i0 + off);
+            st_granule(o, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull));
+            st_granule(o + 1, ((unsigned long long)epoch << 32) | (bits >> 32));
+        }
+        // ---- q_lane from the granules of block row `lane` (published by the wave of that row): sweep until every tag matches
+        PCG1_STAMP(2 + 4 * iter);
+        double qq[6];
+        {
+            const unsigned long long* gl = gr + 12 * (size_t)(own ? lane : 0);
+            unsigned long long w[12];
+            unsigned spins = 0;
+            if (GV == 0) {
+                while (true) {
+                    bool ok = true;
+                    if (own) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) w[k] = ld_granule(gl + k);
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) ok = ok && ((unsigned)(w[k] >> 32) == epoch);
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { timeout = true; break; }
+                }
+            } else {
+                // 16-byte write-through-coherent loads (sc1: served past this CU's L1) through a buffer descriptor over the granule array
+                typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.granules, 0, (int)(4 * n6 * 8), 0x00020000);
+                const int voff = (int)(((iter & 1) * (2 * n6) + 12 * (own ? lane : 0)) * 8);
+                auto sweep = [&](v4u_t (&v)[6]) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * k, 0, 16);
+                };
+                auto tags_ok = [&](const v4u_t (&v)[6]) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) ok = ok && (v[k].y == epoch) && (v[k].w == epoch);
+                    return ok || !own;
+                };
+                v4u_t a[6], b[6];
+                sweep(a);
+                if (GV == 2) {
+                    // two sweeps in flight: the next one is ISSUED before the previous one is checked (the sched_barrier pins that
+                    // order: the check then waits with vmcnt(6), not for the sweep just issued)
+                    while (true) {
+                        __builtin_amdgcn_s_sleep(4); sweep(b); __builtin_amdgcn_sched_barrier(0);
+                        if (__all(tags_ok(a))) break;
+                        __builtin_amdgcn_s_sleep(4); sweep(a); __builtin_amdgcn_sched_barrier(0);
+                        if (__all(tags_ok(b))) {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) a[k] = b[k];
+                            break;
+                        }
+                        if (++spins > (1u << 22)) { timeout = true; break; }
+                    }
+                } else {
+                    while (true) {
+                        if (__all(tags_ok(a))) break;
+                        __builtin_amdgcn_s_sleep(1); sweep(a);
+                        if (++spins > (1u << 22)) { timeout = true; break; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    w[2 * k] = ((unsigned long long)a[k].y << 32) | a[k].x;
+                    w[2 * k + 1] = ((unsigned long long)a[k].w << 32) | a[k].z;
+                }
+            }
+            if (timeout) break;
+#ifdef VISFS_BA_STAMPS
+            if (lane == 0 && i0 == g.stamp_wg && iter < 26) g.stamps[100 + iter] = spins;
+#endif
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                qq[c] = own ? __longlong_as_double((long long)((w[2 * c + 1] << 32) | (w[2 * c] & 0xffffffffull))) : 0.0;
+        }
+        PCG1_STAMP(3 + 4 * iter);
+        // ---- vector recurrences, identical in every wave
+        part = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) part += dd[c] * qq[c];
+        const double dq = wave_sum(part);
+        const double alpha = dn / dq;
+        part = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { xx[c] += alpha * dd[c]; rr[c] -= alpha * qq[c]; }
+        double sv[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v += mm[6 * r + c] * rr[c];
+            sv[r] = v;
+            part += rr[r] * v;
+        }
+        const double dnn = wave_sum(part);
+        const double beta = dnn / dn;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dd[c] = sv[c] + beta * dd[c];
+        dn = dnn;
+        PCG1_STAMP(4 + 4 * iter);
+        iter += 1;
+    }
+    if (timeout) { if (lane == 0) st->pcg_timeout = 1; return; }
+    // x is final: the lane owning this wave's block row stores it and does K8 (oplus); row 0 publishes the statistics
+    if (lane == i0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) g.x[6 * i0 + c] = xx[c];
+        const int ip = g.free_pose[i0];
+        const int sel = st->sel;
+        pose_oplus(g.pose[sel] + POSE_STRIDE * ip, xx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+    }
+    if (lane == 0 && i0 == 0) {
+        st->pcg_residual = 0.5 * dn;
+        st->pcg_iter = iter;
+        st->pcg_total += iter;
+        if (iter > st->pcg_max) st->pcg_max = iter;
+    }
+}
+
 // ================================================================= K6 (direct): blocked Cholesky of the reduced camera matrix
 // Optimizer/Solver 0, 1, 3 (CSparse / Cholmod / Eigen sparse Cholesky in the reference, Optimizer.cpp:76-91) all factor
 // S = L L^T and back-substitute; here S is assembled dense (n = 6 Npf padded to a multiple of 32 with an identity tail)
@@ -1736,6 +1966,7 @@ __device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st,
     st->ended = phase_just_done + 1;
     if (phase_just_done == 0) {
         st->chi2_phase1 = chi; st->chi2_final = chi;
+        st->pcg_phase1 = st->pcg_total;
         if (st->max_iter <= 0) st->chi2_initial = chi;        // optimize(0): nothing linearised
         if (chi != chi) st->status = 3;                                   // VISFS_BA_ERR_NAN_CHI2
         else if (chi > 1000000000000.0 || !(chi <= DBL_MAX)) st->status = 4; // VISFS_BA_ERR_HUGE_CHI2_1
@@ -1786,7 +2017,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
         if (restore) st->sel = 0;
         st->pcg_max = 0; st->pcg_timeout = 0;
-        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1; st->ended = 0;
+        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1; st->ended = 0; st->pcg_phase1 = 0; st->n_edges_ok = g.n_edges_ok;
         st->n_active[0] = st->n_active[1] = st->n_active[2] = st->n_active[3] = 0;
         st->phase = 0; st->max_iter = max_iter; st->phase_iter = 0; st->trial_q = 0;
         st->done = (max_iter <= 0) ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->solver_failed = 0;
@@ -2362,6 +2593,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.eval_blocks = (g.No + 255) / 256 + 1;
     d.reset_blocks = std::min(std::max((g.No + 255) / 256, 1), 1024);
     d.has_odo = (g.Ne > 0 || g.Nz > 0) ? 1 : 0;
+    d.pcg_one_wave = g.pcg1_code != nullptr ? 1 : 0;
     return d;
 }
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
@@ -2370,6 +2602,7 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.sch_wgs = std::max(a.sch_wgs, b.sch_wgs); d.fin_wgs = std::max(a.fin_wgs, b.fin_wgs); d.pcg_rows = std::max(a.pcg_rows, b.pcg_rows);
     d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
     d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
+    d.pcg_one_wave = a.pcg_one_wave & b.pcg_one_wave;
     return d;
 }
 static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)(12 * d.np + extra) * sizeof(double); }
@@ -2413,7 +2646,13 @@ static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B
 }
 template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    if (d.pcg_rows <= 64) TIMED_LAUNCH((k_pcg<1, true, Src, false>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    if (d.pcg_one_wave) {
+        static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 0; }();
+        if (gv == 2) TIMED_LAUNCH((k_pcg1<Src, 2>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
+        else if (gv == 1) TIMED_LAUNCH((k_pcg1<Src, 1>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
+        else TIMED_LAUNCH((k_pcg1<Src, 0>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
+    }
+    else if (d.pcg_rows <= 64) TIMED_LAUNCH((k_pcg<1, true, Src, false>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
     else TIMED_LAUNCH((k_pcg<1, true, Src, true>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
 }
 template <class Src>
@@ -2449,6 +2688,11 @@ void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s) { launch_backsu
 void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
     launch_phase_end_src(One{ g }, dims_of(g), 1, phase_just_done, mark, next_max_iter, s);
+}
+// stage hook: the outlier pass of Optimizer.cpp:283-303 on the committed estimate, ungated (k_eval alone: marks edges, no phase change)
+void launch_eval_mark(const DeviceGraph& g, hipStream_t s) {
+    const LaunchDims d = dims_of(g);
+    hipLaunchKernelGGL((k_eval<One>), dim3(d.eval_blocks), dim3(256), lds_poses(d, 8), s, One{ g }, 1, -1);
 }
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s) {
     hipLaunchKernelGGL((k_reset<One>), dim3(dims_of(g).reset_blocks), dim3(256), 0, s, One{ g }, max_iter, gauss_newton, restore);
@@ -2509,6 +2753,28 @@ __global__ void k_gather_lm(const DeviceGraph* gs, int B, LmState* out) {
 }
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_lm, dim3(B), dim3(64), 0, s, gs, B, out);
+}
+
+// How many workgroups of the persistent PCG kernel this launch geometry would use can be RESIDENT on the device at once
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units, capped at the hardware's 8 workgroup slots per CU for these
+// small workgroups).  The hand-off of k_pcg / k_pcg1 only terminates when every workgroup of a window's grid is resident, so a
+// batched launch must never carry more block rows than this (cdna_hip_programming.md §1: residency comes from the grid size alone).
+int pcg_resident_capacity(const LaunchDims& d, bool many, int device) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
+    int per_cu = 0;
+    hipError_t e;
+    if (d.pcg_one_wave) e = many ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg1<Many, 0>, 64, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg1<One, 0>, 64, 0);
+    else if (d.pcg_rows <= 64) e = many ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg<1, true, Many, false>, 256, (size_t)d.pcg_lds)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg<1, true, One, false>, 256, (size_t)d.pcg_lds);
+    else e = many ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg<1, true, Many, true>, 256, (size_t)d.pcg_lds)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg<1, true, One, true>, 256, (size_t)d.pcg_lds);
+    if (e != hipSuccess || per_cu <= 0) return 0;
+    // the API can over-report by one workgroup per CU for SGPR-heavy kernels (MI355X_MICROARCH.md, residency): keep one slot
+    // of margin wherever more than one is reported, and never count more than the 8 slots a CU has for such workgroups
+    per_cu = std::min(per_cu, 8);
+    if (per_cu > 1) per_cu -= 1;
+    return per_cu * cus;
 }
 
 bool small_path_fits(const DeviceGraph& g) {

@@ -9,11 +9,12 @@
 namespace visfs_ba {
 
 // Launch geometry of one window, or the element-wise maximum over a batch of windows (same lanes-per-landmark group).
-struct LaunchDims { int group, np, lin_blocks, backsub_blocks, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo; };
+struct LaunchDims { int group, np, lin_blocks, backsub_blocks, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave; };
 LaunchDims dims_of(const DeviceGraph& g);
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b);
 
 int configure_kernels(const DeviceGraph& g);
+int pcg_resident_capacity(const LaunchDims& d, bool many, int device);   // workgroups of the persistent PCG that fit on the device at once (0: query failed)
 void arm_launch_events(hipEvent_t start, hipEvent_t stop);             // measurement: attach an event pair to the next timed launch (this thread)
 bool launch_events_pending();                                        // ... still armed: no timed launch has consumed it
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s);        // upload: co-observation pair lists of the S blocks
@@ -40,6 +41,7 @@ void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, i
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s);
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
+void launch_eval_mark(const DeviceGraph& g, hipStream_t s);           // stage hook: outlier pass on the committed estimate, ungated
 // test hook: one phase of the LM state machine on the host, through the functions the kernels run, on scripted trial outcomes
 int lm_script_host(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi, const double* scale, const int32_t* ok, LmState* st);
 

@@ -18,6 +18,14 @@ CONFIGS = {
     "C2": dict(n_kf=50, n_lm=5000, n_obs=50000, odo=False, index=1),
     "C3": dict(n_kf=50, n_lm=5000, n_obs=50000, odo=True, index=2),   # C2 + 49 wheel-odometry edges (no IMU factor exists in the reference)
     "C4": dict(n_kf=200, n_lm=30000, n_obs=300000, odo=False, index=3),
+    # C4 with the world origin moved to the centroid of the trajectory (same measurements, same noise): the reference's pose
+    # Jacobian is the SE(3)-left form in Pc while its update leaves t unrotated — an approximation whose error grows
+    # with |t_cw|, i.e. with the distance of a key-frame from the world origin; 50 m of trajectory from the origin do not converge
+    "C4C": dict(n_kf=200, n_lm=30000, n_obs=300000, odo=False, index=3, centre=True),
+    # C4 started from 1e-3 rad (0.06 deg) of rotation error per pose instead of 1e-2: the update error of the a6 quirk is
+    # |d_theta x t_cw|, so at 25-50 m from the origin only small rotation corrections keep the LM steps acceptable — phase 1
+    # then converges in 10 accepted trials and the kernels see all 300 k edges (C4 itself: 69 % of the edges are culled)
+    "C4R": dict(n_kf=200, n_lm=30000, n_obs=300000, odo=False, index=3, pose_noise_r=1e-3),
     "C5": dict(n_kf=50, n_lm=5000, n_obs=50000, odo=False, index=4),  # per window; 64 windows in the batch
     # production-sized window (Parameters.h:161,148: 6 signatures, <=300 features)
     "PROD": dict(n_kf=6, n_lm=300, n_obs=1500, odo=True, index=5),
@@ -113,6 +121,7 @@ def make_window(config="C2", window_index=0, n_kf=None, n_lm=None, n_obs=None, o
     if n_obs is not None: cfg["n_obs"] = n_obs
     if odo is not None: cfg["odo"] = odo
     Np, Nl, No = cfg["n_kf"], cfg["n_lm"], cfg["n_obs"]
+    pose_noise_r = cfg.get("pose_noise_r", pose_noise_r)
     rng = SplitMix64((BASE_SEED + cfg["index"] + 1000003 * window_index) if seed is None else seed)
 
     # --- trajectory (planar robot): x = 0.25k, y = 0.5 sin(0.2k), yaw = 0.1 cos(0.2k)
@@ -196,6 +205,12 @@ def make_window(config="C2", window_index=0, n_kf=None, n_lm=None, n_obs=None, o
     fixed = rng.uniform(Nl) < fixed_frac
     P0 = P + np.where(fixed[:, None], 0.0, point_noise * rng.normal(3 * Nl).reshape(Nl, 3))
 
+    if cfg.get("centre"):
+        # a translation of the world: poses and landmarks move, measurements (and the random streams above) stay
+        c = Twr_true[:, :3, 3].mean(axis=0)
+        Twr_true = Twr_true.copy(); Twr_true[:, :3, 3] -= c
+        Twr0 = Twr0.copy(); Twr0[:, :3, 3] -= c
+        P = P - c; P0 = P0 - c
     w = dict(config=config, root_id=root_id, pose_ids=pose_ids, pose_Twr=Twr0.reshape(Np, 12),
              n_cameras=2, fx=FX, fy=FY, cx=CX, cy=CY, baseline=float(BASELINE_F), Trc=TRC.reshape(12),
              point_ids=np.arange(Nl, dtype=np.uint64), point_xyz=P0, point_fixed=fixed.astype(np.uint8),
