@@ -180,6 +180,9 @@ typedef struct visfs_ba_handle visfs_ba_handle;
 int visfs_ba_create(const visfs_ba_params* params, int device_index, visfs_ba_handle** out);
 void visfs_ba_destroy(visfs_ba_handle* h);
 const char* visfs_ba_last_error(const visfs_ba_handle* h);
+/* Why the calling thread's last visfs_ba_create failed ("" after a success): missing runtime or device, index out of range,
+ * wrong architecture, or a stream / pinned-memory allocation failure — with the HIP error text. */
+const char* visfs_ba_create_error(void);
 int visfs_ba_abi_version(void);
 
 /* Replaces one call of `Optimizer::localOptimize` (Optimizer.cpp:58-364): pack

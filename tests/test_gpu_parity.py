@@ -117,20 +117,30 @@ def test_pcg_register_block_variants(olib, n_kf, n_lm, n_obs):
     s.close(); o.close()
 
 
-def test_pcg_refuses_more_than_256_free_poses_but_direct_solves(olib):
-    """One PCG workgroup per block row must be co-resident (256 CUs): larger systems are refused for Solver=2, never hung;
-    the direct solver takes them."""
-    from visfs_amd import backend
-    w = synth.make_window("custom", n_kf=300, n_lm=1500, n_obs=9000, seed=17)
-    prm = abi.default_params(iterations=4, solver=2)
-    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
-    s = backend.Solver(prm)
-    with pytest.raises(backend.BackendError, match="256 free poses"):
-        s.upload(gb)
-    s.close()
-    o, s, gb = make_pair(olib, w, iterations=4, solver=0)
+@pytest.mark.parametrize("n_kf,solver", [(300, 2), (700, 2), (700, 0), (900, 2)])
+def test_windows_beyond_the_former_size_limits(olib, n_kf, solver):
+    """The reference API takes maps of any size (Optimizer.h:46-56).  More than 256 free poses: a PCG workgroup owns several
+    block rows of S (2 / 3 / 4 here) and an owner thread 2 or 4 six-blocks, the grid stays within one workgroup per CU.  More
+    than 840 poses (900): the landmark kernels read the poses from HBM instead of staging all of them as R|t in LDS.  Same
+    parity bar as every other window: stage buffers, LM trajectory, PCG iteration counts, outliers, final states."""
+    w = synth.make_window("custom", n_kf=n_kf, n_lm=5 * n_kf, n_obs=30 * n_kf, seed=17)
+    o, s, gb = make_pair(olib, w, iterations=4, solver=solver)
+    assert s.describe()["n_free_poses"] == n_kf - 1
+    check_stages(o, s)
     check_optimize(o, s, pose_tol=1e-5)
     s.close(); o.close()
+
+
+def test_pcg_refuses_only_what_it_cannot_hold(olib):
+    """Above 1024 free poses the persistent PCG is refused (never hung); the direct solver takes such windows."""
+    from visfs_amd import backend
+    w = synth.make_window("custom", n_kf=1030, n_lm=3000, n_obs=12000, seed=17)
+    prm = abi.default_params(iterations=2, solver=2)
+    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+    s = backend.Solver(prm)
+    with pytest.raises(backend.BackendError, match="1024 free poses"):
+        s.upload(gb)
+    s.close()
 
 
 def test_optimize_parity_default_iterations(olib):

@@ -24,7 +24,7 @@ EXPORTS = [
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
     "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
-    "visfs_ba_hook_lm_script", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
+    "visfs_ba_create_error", "visfs_ba_hook_lm_script", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
 ]
 
 _lib = None
@@ -49,6 +49,7 @@ def load_library():
     lib.visfs_ba_destroy.argtypes = [C.c_void_p]
     lib.visfs_ba_last_error.argtypes = [C.c_void_p]
     lib.visfs_ba_last_error.restype = C.c_char_p
+    lib.visfs_ba_create_error.restype = C.c_char_p
     lib.visfs_ba_solve_window.argtypes = [C.c_void_p, C.POINTER(abi.Window), C.POINTER(abi.Result)]
     lib.visfs_ba_solve_window.restype = C.c_int
     lib.visfs_ba_solve_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.Window)), C.POINTER(C.POINTER(abi.Result))]
@@ -106,7 +107,7 @@ class Solver:
         h = C.c_void_p()
         rc = self.lib.visfs_ba_create(C.byref(self.params), device, C.byref(h))
         if rc != abi.OK:
-            raise BackendError(f"visfs_ba_create failed with status {rc} (no MI355X / gfx950 device?)")
+            raise BackendError(f"visfs_ba_create failed with status {rc}: {self.lib.visfs_ba_create_error().decode()}")
         self.h = h
         self.gb = None
 

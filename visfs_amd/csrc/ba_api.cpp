@@ -173,7 +173,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     const visfs_ba_params& prm = h->prm;
     const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = gr->n_odo;
     if (Np < 1 || Nl < 0 || No < 0 || Ne < 0) return bad(h, "negative sizes");
-    if (Np > MAX_STAGED_POSES) { h->err = "more than 640 poses per window is not supported"; return VISFS_BA_ERR_UNSUPPORTED; }
     for (int k = 0; k < No; ++k) {
         const int p = gr->obs_point[k], c = gr->obs_pose[k];
         if (p < 0 || p >= Nl || c < 0 || c >= Np) return bad(h, "observation index out of range");
@@ -345,17 +344,20 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         blk_desc[2 * b] = make_int4(blk_chunk_ptr[b], blk_chunk_ptr[b + 1], dg ? pose_odo_ptr[a] : blk_odo_ptr[b], dg ? pose_odo_ptr[a + 1] : blk_odo_ptr[b + 1]);
         blk_desc[2 * b + 1] = make_int4(a, blk_j[b], pose_chunk_ptr[a], pose_chunk_ptr[a + 1]);
     }
-    if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 256 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
+    if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 1024 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
     int max_row = 0;
     for (int a = 0; a < Npf; ++a) max_row = std::max(max_row, row_ptr[a + 1] - row_ptr[a]);
-    // persistent PCG: LDS plan.  d, q, scalars, the row's column/code tables always; the own block row of S when it fits.
-    // Co-residency of the hand-off needs every workgroup resident: at most 256 workgroups, one per CU.
-    size_t pcg_lds = (size_t)(2 * 6 * Npf + 32 + 32) * 8 + (size_t)8 * max_row + 16;
-    int lds_minv = 0, lds_srow = 0;                      // Minv lives in registers (one block per thread) at every size
+    // persistent PCG: LDS plan.  d, q, scalars, the rows' column/code tables always; s = Minv r when an owner thread holds several
+    // blocks; the own block rows of S when they fit.  Co-residency of the hand-off needs every workgroup resident: one block row
+    // per workgroup up to 256 free poses, ceil(Npf / 256) rows per workgroup beyond (at most 256 workgroups, one per CU).
+    const int pcg_rpw = Npf > MAX_PCG_ONE_ROW_POSES ? (Npf + MAX_PCG_ONE_ROW_POSES - 1) / MAX_PCG_ONE_ROW_POSES : 1;
+    size_t pcg_lds = (size_t)(2 * 6 * Npf + 32 + 32 * pcg_rpw + (Npf > MAX_PCG_ONE_ROW_POSES ? 6 * Npf : 0)) * 8 + (size_t)8 * max_row * pcg_rpw + 16;
+    int lds_minv = 0, lds_srow = 0;                      // Minv: registers (one block per owner) or, beyond 256 free poses, read from HBM
     {
         const size_t budget = (size_t)150 * 1024;        // one workgroup per CU may own most of its 160 KiB
-        if (pcg_lds + (size_t)288 * max_row <= budget) { lds_srow = 1; pcg_lds += (size_t)288 * max_row; }
+        if (pcg_lds + (size_t)288 * max_row * pcg_rpw <= budget) { lds_srow = 1; pcg_lds += (size_t)288 * max_row * pcg_rpw; }
     }
+    if (prm.solver == 2 && pcg_lds > (size_t)160 * 1024) { h->err = "reduced camera system too large for the persistent PCG (LDS); use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
 
     // k_pcg1 (one wavefront per block row, <= 64 free poses): the block of S at (i, a) as a dense code table
     const bool pcg1 = [&]() { const char* e = std::getenv("VISFS_BA_PCG1"); return prm.solver == 2 && Npf >= 1 && Npf <= 64 && !(e && e[0] == '0'); }();
@@ -529,7 +531,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_pose_obs = cnt[Npf];
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
-    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
@@ -549,7 +551,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // speculative linearise: a rejected trial wastes one linearisation, an accepted one saves k_decide + a launch gap — worth it
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
     // members keep the gated form.
-    { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = e ? (e[0] == '1') : (!w.batch_member && No <= 150000); }
+    { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (!w.batch_member && No <= 150000)) && Np <= MAX_STAGED_POSES; }
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
@@ -927,19 +929,36 @@ void visfs_ba_default_params(visfs_ba_params* p) {
     p->pixel_variance = 1.5; p->odometry_covariance = 0.00005; p->laser_covariance = 0.1; p->robust_kernel_delta = 8.0;
 }
 
+// why the last visfs_ba_create of this thread failed (no handle exists to carry the message)
+static thread_local std::string tl_create_error;
+const char* visfs_ba_create_error(void) { return tl_create_error.c_str(); }
+
 int visfs_ba_create(const visfs_ba_params* params, int device_index, visfs_ba_handle** out) {
-    if (!out || !params) return VISFS_BA_ERR_BAD_ARGUMENT;
+    try { tl_create_error.clear(); } catch (...) {}
+    auto fail = [](int rc, const std::string& why) { try { tl_create_error = why; } catch (...) {} return rc; };
+    if (!out || !params) return fail(VISFS_BA_ERR_BAD_ARGUMENT, "null argument");
     *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_index < 0 || device_index >= n) return VISFS_BA_ERR_DEVICE;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) return VISFS_BA_ERR_DEVICE;
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VISFS_BA_ERR_DEVICE;     // kernels are built for gfx950 only
-    return guarded(nullptr, [&]() {
+    return guarded(nullptr, [&]() -> int {
+        int n = 0;
+        const hipError_t ec = hipGetDeviceCount(&n);
+        if (ec != hipSuccess) return fail(VISFS_BA_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(ec) + " (no HIP runtime / driver?)");
+        if (n <= 0) return fail(VISFS_BA_ERR_DEVICE, "no HIP device present");
+        if (device_index < 0 || device_index >= n)
+            return fail(VISFS_BA_ERR_BAD_ARGUMENT, "device index " + std::to_string(device_index) + " out of range: " + std::to_string(n) + " device(s) visible");
+        hipDeviceProp_t prop;
+        const hipError_t ep = hipGetDeviceProperties(&prop, device_index);
+        if (ep != hipSuccess) return fail(VISFS_BA_ERR_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(ep));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)                                     // kernels are built for gfx950 only
+            return fail(VISFS_BA_ERR_DEVICE, std::string("device ") + std::to_string(device_index) + " is " + prop.gcnArchName + ": the kernels are built for gfx950 (MI355X) only");
         visfs_ba_handle* h = new visfs_ba_handle();
         h->prm = *params;
         h->device = device_index;
-        if (ws_init(h, h->ws) != VISFS_BA_OK) { delete h; return (int)VISFS_BA_ERR_DEVICE; }
+        if (ws_init(h, h->ws) != VISFS_BA_OK) {
+            const std::string why = "resource allocation on device " + std::to_string(device_index) + " failed: " + h->err;
+            ws_release(h->ws);
+            delete h;
+            return fail(VISFS_BA_ERR_DEVICE, why);
+        }
         *out = h;
         return (int)VISFS_BA_OK;
     });
@@ -1124,7 +1143,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
         for (int i = 0; i < n; ++i) {
             if (!need[i]) continue;
             const Workspace& ws = *h->batch[i];
-            const bool batchable = batching && (h->prm.solver == 2 || ws.small_solve || ws.fused);
+            const bool batchable = batching && (h->prm.solver == 2 || ws.small_solve || ws.fused) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
@@ -1195,6 +1214,7 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
         for (int i = 0; i < n; ++i) {
             const Workspace& ws = *h->batch[i];
             if (!(h->prm.solver == 2 || ws.small_solve || ws.fused)) { h->err = "batched launches need Optimizer/Solver=2 or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
+            if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             const int cls = ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
         }

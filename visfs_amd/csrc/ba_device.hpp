@@ -20,8 +20,10 @@ namespace visfs_ba {
 constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
 constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
-constexpr int MAX_STAGED_POSES = 640; // 12 doubles each in LDS (60 KiB)
-constexpr int MAX_PCG_FREE_POSES = 256; // persistent PCG: one workgroup per block row, all co-resident (256 CUs, >= 1 workgroup each)
+constexpr int MAX_STAGED_POSES = 840; // poses staged as R|t in LDS (12 doubles each; k_backsub stages two sets: 24 * 840 * 8 B + scratch <= 160 KiB);
+                                      // larger windows take the kernels that read the poses from HBM (PoseSrc<false>)
+constexpr int MAX_PCG_ONE_ROW_POSES = 256; // persistent PCG with one workgroup per block row: all co-resident (256 CUs, >= 1 workgroup each)
+constexpr int MAX_PCG_FREE_POSES = 1024;   // beyond 256 free poses a workgroup owns several block rows (<= 256 workgroups) and an owner thread up to 4 blocks
 constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront and pass (DeviceGraph::sch_chunk = 64 x passes)
 // fused single-workgroup path (k_small_optimize): limits of a "small" window
 constexpr int SM_MAX_POSES = 16;      // R|t of every pose twice in LDS
@@ -91,6 +93,7 @@ struct DeviceGraph {
     int32_t pcg_lds_minv;   // persistent PCG keeps all Minv blocks in LDS
     int32_t pcg_lds_srow;   // ... and its own block row of S
     int32_t pcg_max_row;    // longest block row of S (blocks)
+    int32_t pcg_rows_per_wg; // block rows per PCG workgroup (1 up to 256 free poses)
     int32_t pcg_lds_bytes;
     int32_t chol_np;        // padded order of the dense reduced camera matrix (direct solver)
     int32_t n_lin_a;        // workgroups of the landmark-major role

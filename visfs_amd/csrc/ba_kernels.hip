@@ -167,6 +167,16 @@ __device__ __forceinline__ Rt load_Rt(const double* sRt, int i) {
     return T;
 }
 
+// Where a kernel finds pose i as R|t: staged in LDS by stage_poses (12 doubles per pose: the observation tiles gather from there), or —
+// windows with more poses than the LDS holds (MAX_STAGED_POSES) — converted on the fly from the estimate [tx ty tz qx qy qz qw] in HBM.
+template <bool STG> struct PoseSrc {
+    const double* p;
+    __device__ __forceinline__ Rt get(const int i) const {
+        if constexpr (STG) return load_Rt(p, i);
+        else return pose_to_Rt(p + POSE_STRIDE * i);
+    }
+};
+
 __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Intrinsics{ g.fx, g.fy, g.cx, g.cy, g.bf }; }
 
 // Where a kernel finds its window.  One: the DeviceGraph travels by value in the kernel arguments (single window).
@@ -174,6 +184,9 @@ __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Int
 // every window is gated by its own LmState, so the same launch serves windows at different points of their LM loops.
 struct One { DeviceGraph g; };
 struct Many { const DeviceGraph* gs; };
+// host side of the launchers: the by-value graph of a single window (a batch never reaches the callers of this: see staged())
+inline const DeviceGraph& graph_of_host(const One& s) { return s.g; }
+inline const DeviceGraph& graph_of_host(const Many&) { static const DeviceGraph none{}; return none; }
 __device__ __forceinline__ const DeviceGraph& graph_of(const One& s) { return s.g; }
 // The graph array of a batch is written by the host before the launches and never by a kernel: reading it through the constant
 // address space lets the compiler fetch the members with scalar loads into SGPRs (as it does for the by-value graph of One)
@@ -264,8 +277,8 @@ __device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k
 
 // Role A for one landmark handled by G lanes (sub = lane within the group): weights, chi2, tile seeds, Hll, b_l.
 // Shared by k_linearize<G> and the fused small-window kernel (G = 1: one thread per landmark).
-template <int G>
-__device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const double* sRt,
+template <int G, bool STG = true>
+__device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> P,
                                              const double* __restrict__ pt, const Intrinsics& K, const double iv, const double delta,
                                              double& chi_acc, double& md) {
     int k0 = 0, k1 = 0;
@@ -281,7 +294,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
     for (int q = 0; q < 9; ++q) hb[q] = 0.0;
     for (int k = k0 + sub; k < k1; k += G) {
         const int ip = g.obs_pose[k];
-        const Rt T = load_Rt(sRt, ip);
+        const Rt T = P.get(ip);
         const double u = g.obs_uvr[3 * k], v = g.obs_uvr[3 * k + 1], ur = g.obs_uvr[3 * k + 2];
         Vec3 pc;
         const Vec3 e = stereo_error(T, pw, u, v, ur, K, pc);
@@ -428,14 +441,14 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
 // accepted trial — the common case — finds its linearisation ready and only flips LmState::lin_sel; a rejected one leaves the
 // current set untouched.  The linearising workgroups read the snapshot k_backsub left (spec_go / spec_src / spec_dst), never a
 // field the decision writes, so the launch has no intra-kernel race.
-template <int G, class Src, bool SPEC>
+template <int G, class Src, bool SPEC, bool STG = true>
 __global__ __launch_bounds__(256) void k_linearize(const Src src) {
     constexpr bool spec = SPEC;
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sRt = smem;                       // [Np][12]
-    double* red = smem + 12 * g.Np;           // [4 * 27]
+    double* sRt = smem;                       // [Np][12] (STG)
+    double* red = smem + (STG ? 12 * g.Np : 0);   // [4 * 27]
     int sel, ls;
     if (spec) {
         if ((int)blockIdx.x == g.n_lin_a + g.n_chunks) { decide_role(g, st, red, true); return; }
@@ -448,8 +461,8 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
     sel = __builtin_amdgcn_readfirstlane(sel);          // wave-uniform: keeps the selected estimate pointers in SGPRs
     const double* __restrict__ pose = g.pose[sel];
     const double* __restrict__ pt = g.pt[sel];
-    stage_poses(pose, g.Np, sRt);
-    __syncthreads();
+    if (STG) { stage_poses(pose, g.Np, sRt); __syncthreads(); }
+    const PoseSrc<STG> P{ STG ? sRt : pose };
     const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();                     // after the staging: its pointer loads overlap the pose loads
     const Intrinsics K = intr_of(g);
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
         const int l = bid * LPW + tid / G, sub = tid % G;
         const bool lvalid = l < g.Nl;
         double chi_acc = 0.0, md = 0.0;
-        lin_landmark<G>(g, L, l, lvalid, sub, sRt, pt, K, iv, delta, chi_acc, md);
+        lin_landmark<G, STG>(g, L, l, lvalid, sub, P, pt, K, iv, delta, chi_acc, md);
         const double chi_tot = block_sum_256(chi_acc, red);
         const double md_tot = block_max_256(md, red);
         if (tid == 0) { g.lin_part[2 * bid] = chi_tot; g.lin_part[2 * bid + 1] = md_tot; }
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
         double acc[27];
 #pragma unroll
         for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-        if (begin + tid < end) pose_obs_terms(g, g.pose_obs[begin + tid], load_Rt(sRt, g.free_pose[a]), pt, K, iv, delta, acc);
+        if (begin + tid < end) pose_obs_terms(g, g.pose_obs[begin + tid], P.get(g.free_pose[a]), pt, K, iv, delta, acc);
         const int wave = tid >> 6, lane = tid & 63;
         int off = 0, len = 27;
         ReduceScatter<27, 32>::run(acc, lane, off, len);
@@ -982,21 +995,26 @@ __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long 
 // its Minv block in registers), and the two dot products of an iteration are workgroup reductions (wave butterfly + four LDS
 // partials in fixed order) — with wave 0 alone owning up to four blocks per lane and Minv in LDS the vector step cost 5 us
 // of an 8 us iteration at C4 (199 block rows) and the set-up 8.5 us.
-template <int BPL, bool MREG, class Src, bool WIDE>
+// MULTIROW (more than 256 free poses, WIDE with BPL = 2 or 4 blocks per thread, Minv read from HBM): a workgroup owns
+// DeviceGraph::pcg_rows_per_wg consecutive block rows, so that the grid never exceeds one workgroup per CU (co-residency).
+template <int BPL, bool MREG, class Src, bool WIDE, bool MULTIROW = false>
 __global__ __launch_bounds__(256) void k_pcg(const Src src) {
-    static_assert(!WIDE || (BPL == 1 && MREG), "WIDE: one block per thread, Minv in registers");
+    static_assert(!MREG || BPL == 1, "Minv in registers: one block per owner");
+    static_assert(!MULTIROW || WIDE, "several rows per workgroup only in the WIDE form");
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     if (!(st->mode & MODE_TRIAL)) return;
-    if ((int)blockIdx.x >= g.Npf) return;             // a batched launch is sized for the largest window
+    const int R = MULTIROW ? g.pcg_rows_per_wg : 1;   // block rows of S per workgroup
+    if ((int)blockIdx.x * R >= g.Npf) return;         // a batched launch is sized for the largest window
 #ifdef VISFS_BA_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == (unsigned)g.stamp_wg) g.stamps[127] = wall_clock64();
 #endif
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n6 = 6 * g.Npf;
-    constexpr int R = 1;                                              // one block row of S per workgroup (more rows per workgroup measured slower)
-    const int i0 = blockIdx.x, i1 = i0 + 1;
+    // (one block row per workgroup wherever the grid fits the device: more rows per workgroup measured slower)
+    const int i0 = blockIdx.x * R, i1 = (i0 + R < g.Npf) ? i0 + R : g.Npf;
+    constexpr int OWN_STRIDE = WIDE ? 256 : 64;                       // distance between the 6-blocks one owner thread holds
     double* sd = smem;                                                // d (every workgroup holds the full vector)
     double* sq = smem + n6;                                           // q of the current iteration
     double* sP = smem + 2 * n6;                                       // [32] scalars ([8..15]: partials of the WIDE reductions)
@@ -1030,14 +1048,16 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     }
     if (tid == 0) sP[2] = 0.0;                                         // hand-off timeout flag of the workgroup
     // ---- the owners of the vector recurrences (wave 0: lane = block; WIDE: thread = block).  r = b ; d = M^-1 r ; dn = r.d   (fixed order)
-    double rr_[BPL][6], dd_[BPL][6], xown[6], mm_[MREG ? 36 : 1];
+    double rr_[BPL][6], dd_[BPL][6], xx_[BPL][6], mm_[MREG ? 36 : 1];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) xown[c] = 0.0;
+    for (int k = 0; k < BPL; ++k)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xx_[k][c] = 0.0;
     double dn = 0.0, d0 = 0.0;
     if (vec) {
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
-            const int a = blk0 + 64 * k;
+            const int a = blk0 + OWN_STRIDE * k;
             const bool own = a < g.Npf;
 #pragma unroll
             for (int c = 0; c < 6; ++c) rr_[k][c] = own ? g.bs[6 * a + c] : 0.0;
@@ -1055,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
         if (vec) {
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = blk0 + 64 * k;
+                const int a = blk0 + OWN_STRIDE * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int r6 = 0; r6 < 6; ++r6) {
@@ -1181,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
             double part = 0.0;
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = blk0 + 64 * k;
+                const int a = blk0 + OWN_STRIDE * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1195,12 +1215,12 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
             part = 0.0;
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = blk0 + 64 * k;
+                const int a = blk0 + OWN_STRIDE * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     const double qv = (BPL == 1) ? qq[c] : (own ? sq[6 * a + c] : 0.0);
-                    if (a == i0) xown[c] += alpha * dd_[k][c];
+                    xx_[k][c] += alpha * dd_[k][c];
                     rr_[k][c] -= alpha * qv;
                 }
 #pragma unroll
@@ -1216,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
             const double beta = dnn / dn;
 #pragma unroll
             for (int k = 0; k < BPL; ++k) {
-                const int a = blk0 + 64 * k;
+                const int a = blk0 + OWN_STRIDE * k;
                 const bool own = a < g.Npf;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1234,14 +1254,18 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
         iter += 1;
     }
     if (timeout) { if (tid == 0) st->pcg_timeout = 1; return; }
-    // x is final: the lane owning this workgroup's block row stores it and does K8 (oplus); workgroup 0 publishes the statistics.
+    // x is final: the owner of each of this workgroup's block rows stores it and does K8 (oplus); workgroup 0 publishes the statistics.
     if (vec) {
-        if (WIDE ? (tid == i0) : (lane == (i0 & 63))) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) g.x[6 * i0 + c] = xown[c];
-            const int ip = g.free_pose[i0];
-            const int sel = st->sel;
-            pose_oplus(g.pose[sel] + POSE_STRIDE * ip, xown, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+        for (int k = 0; k < BPL; ++k) {
+            const int a = blk0 + OWN_STRIDE * k;
+            if (a >= i0 && a < i1 && (WIDE || MULTIROW || lane == (i0 & 63))) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) g.x[6 * a + c] = xx_[k][c];
+                const int ip = g.free_pose[a];
+                const int sel = st->sel;
+                pose_oplus(g.pose[sel] + POSE_STRIDE * ip, xx_[k], g.pose[sel ^ 1] + POSE_STRIDE * ip);
+            }
         }
         if (tid == 0 && blockIdx.x == 0) {
             st->pcg_residual = 0.5 * dn;
@@ -1757,8 +1781,8 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
 
 // K7 + trial chi2 for one landmark handled by G lanes: dl = (Hll + lambda I)^-1 (b_l - sum_i Hpl_il^T x_i), the trial point,
 // and the robust chi2 of its edges at the trial state.  sRt = trial poses, sRt0 = poses of the linearisation point.
-template <int G>
-__device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const double* sRt, const double* sRt0,
+template <int G, bool STG = true>
+__device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> Pt, const PoseSrc<STG> P0,
                                                  const double* __restrict__ pt, double* __restrict__ pt_t, const double lambda, const Intrinsics& K,
                                                  const double iv, const double delta, double& chi_acc, double& scale_acc) {
     int k0 = 0, k1 = 0;
@@ -1783,7 +1807,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
         // Hpl^T x through the tile structure W = [N ; [Pc]x N]:  W^T x = N^T (x_t - Pc x x_r)
         const Vec3 pcs{ s0.x, s0.y, s1.x };
         double N[9];
-        tile_core(load_Rt(sRt0, ipk).R, pcs, s1.y, K, N);
+        tile_core(P0.get(ipk).R, pcs, s1.y, K, N);
         const double* xp = g.x + 6 * (size_t)a;
         const double u0 = xp[0] - (pcs.y * xp[5] - pcs.z * xp[4]);
         const double u1 = xp[1] - (pcs.z * xp[3] - pcs.x * xp[5]);
@@ -1815,7 +1839,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
     // computeActiveErrors + activeRobustChi2 at the trial state
     for (int k = k0 + sub; k < k1; k += G) {
         if (L.obs_w[k] == 0.0) continue;
-        const Rt T = load_Rt(sRt, g.obs_pose[k]);
+        const Rt T = Pt.get(g.obs_pose[k]);
         Vec3 pc;
         const Vec3 e = stereo_error(T, pn, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
         const double c2 = chi2_of(e, iv);
@@ -1830,7 +1854,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // also linearises them there, into the set the speculative k_linearize is about to fill — k_odo_linearize (6.6 us, one
 // workgroup) leaves the unit.  The role is register-hungry (224 VGPRs), so this instantiation runs at two waves per SIMD: it is
 // used only where k_backsub is a single round of waves anyway (the speculative unit's size limit).
-template <int G, class Src, bool ODOSPEC>
+template <int G, class Src, bool ODOSPEC, bool STG = true>
 __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
@@ -1840,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     if (!go) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;
-    double* red = smem + 12 * g.Np;
+    double* red = smem + (STG ? 12 * g.Np : 0);
     const int sel = st->sel, ls = st->lin_sel;
     const double* __restrict__ pose_t = g.pose[sel ^ 1];      // trial poses (written by the solver epilogue)
     const double* __restrict__ pt = g.pt[sel];
@@ -1876,15 +1900,18 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
         return;
     }
     double* sRt0 = red + 8;                   // poses of the linearisation point (tiles are rebuilt there)
-    stage_poses(pose_t, g.Np, sRt);
-    stage_poses(g.pose[sel], g.Np, sRt0);
-    __syncthreads();
+    if (STG) {
+        stage_poses(pose_t, g.Np, sRt);
+        stage_poses(g.pose[sel], g.Np, sRt0);
+        __syncthreads();
+    }
+    const PoseSrc<STG> Pt{ STG ? sRt : pose_t }, P0{ STG ? sRt0 : (const double*)g.pose[sel] };
     const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();
     constexpr int LPW = 256 / G;
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
     double chi_acc = 0.0, scale_acc = 0.0;
-    backsub_landmark<G>(g, L, l, lvalid, sub, sRt, sRt0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
+    backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
     if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; }
@@ -1900,7 +1927,7 @@ __global__ __launch_bounds__(256) void k_decide(const Src src) {
 
 // ================================================================= K10: per-edge chi2, outlier marking
 // Optimizer.cpp:270-303: computeActiveErrors; edges with chi2() > kernel->delta() (UNSQUARED) go to level 1.
-template <class Src>
+template <class Src, bool STG = true>
 __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, const int phase_just_done) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
@@ -1909,11 +1936,11 @@ __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, con
     if (phase_just_done >= 0 && (!st->done || st->ended != phase_just_done)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;
-    double* red = smem + 12 * g.Np;
+    double* red = smem + (STG ? 12 * g.Np : 0);
     const int sel = st->sel;
     const double* __restrict__ pt = g.pt[sel];
-    stage_poses(g.pose[sel], g.Np, sRt);
-    __syncthreads();
+    if (STG) { stage_poses(g.pose[sel], g.Np, sRt); __syncthreads(); }
+    const PoseSrc<STG> P{ STG ? sRt : (const double*)g.pose[sel] };
     const Intrinsics K = intr_of(g);
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
     const int tid = threadIdx.x, bid = blockIdx.x;
@@ -1943,7 +1970,7 @@ __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, con
             double c2 = 0.0;
             if (active) {
                 const int l = g.obs_pt[k];
-                const Rt T = load_Rt(sRt, g.obs_pose[k]);
+                const Rt T = P.get(g.obs_pose[k]);
                 Vec3 pc;
                 const Vec3 e = stereo_error(T, Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] }, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
                 c2 = chi2_of(e, iv);
@@ -2401,7 +2428,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                 stage_poses(pose, g.Np, sRt);
                 __syncthreads();
                 double chi_acc = 0.0, md = 0.0;
-                for (int l = tid; l < g.Nl; l += SM_T) lin_landmark<1>(g, L, l, true, 0, sRt, pt, K, iv, delta, chi_acc, md);
+                for (int l = tid; l < g.Nl; l += SM_T) lin_landmark<1>(g, L, l, true, 0, PoseSrc<true>{ sRt }, pt, K, iv, delta, chi_acc, md);
                 SM_STAMP(1);
                 // pose-major pass: one wave per 64 observations of a LIN_CHUNK; the four partials of a chunk are added in
                 // role B's order, so hpp_part comes out bit-identical to k_linearize's
@@ -2497,7 +2524,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                 stage_poses(pose_t, g.Np, sRtT);
                 __syncthreads();
                 SM_STAMP(8);
-                for (int l = tid; l < g.Nl; l += SM_T) backsub_landmark<1>(g, L, l, true, 0, sRtT, sRt, pt, pt_t, lambda, K, iv, delta, chi_t, sc);
+                for (int l = tid; l < g.Nl; l += SM_T) backsub_landmark<1>(g, L, l, true, 0, PoseSrc<true>{ sRtT }, PoseSrc<true>{ sRt }, pt, pt_t, lambda, K, iv, delta, chi_t, sc);
                 SM_STAMP(9);
                 for (int e_ = tid; e_ < g.Ne; e_ += SM_T) {
                     const int i = g.odo_i[e_], j = g.odo_j[e_];
@@ -2605,18 +2632,40 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.pcg_one_wave = a.pcg_one_wave & b.pcg_one_wave;
     return d;
 }
-static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)(12 * d.np + extra) * sizeof(double); }
+// dynamic LDS of the kernels that stage every pose of the window as R|t (12 doubles each); windows beyond MAX_STAGED_POSES use the
+// instantiations that read the poses from HBM instead (STG = false) and need only the reduction scratch
+static inline bool staged(const LaunchDims& d) { return d.np <= MAX_STAGED_POSES; }
+static inline size_t lds_poses(const LaunchDims& d, int extra) { return (size_t)((staged(d) ? 12 * d.np : 0) + extra) * sizeof(double); }
+// more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel (gfx950 has 160 KiB per CU)
+template <class K> static inline void ensure_lds(K kern, size_t lds) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 
 template <int G, class Src>
 static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
-    if (LinSel<Src>::two_sets && spec) TIMED_LAUNCH((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds_poses(d, 4 * 27), s, src);
-    else TIMED_LAUNCH((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds_poses(d, 4 * 27), s, src);
+    const size_t lds = lds_poses(d, 4 * 27);
+    if (!staged(d)) {                                    // (never speculative, never batched: ba_api.cpp keeps such windows on the gated single-window unit)
+        TIMED_LAUNCH((k_linearize<G, One, false, false>), dim3(d.lin_blocks, B), dim3(256), lds, s, One{ graph_of_host(src) });
+        return;
+    }
+    if (LinSel<Src>::two_sets && spec) { ensure_lds(k_linearize<G, Src, LinSel<Src>::two_sets>, lds); TIMED_LAUNCH((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds, s, src); }
+    else { ensure_lds(k_linearize<G, Src, false>, lds); TIMED_LAUNCH((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds, s, src); }
 }
 template <int G, class Src>
 static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odospec, hipStream_t s) {
-    if (LinSel<Src>::two_sets && odospec)
-        TIMED_LAUNCH((k_backsub<G, Src, LinSel<Src>::two_sets>), dim3(d.backsub_blocks, B), dim3(256), (size_t)std::max(24 * d.np + 8, 128) * sizeof(double), s, src);
-    else TIMED_LAUNCH((k_backsub<G, Src, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)(24 * d.np + 8) * sizeof(double), s, src);
+    if (!staged(d)) {
+        TIMED_LAUNCH((k_backsub<G, One, false, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
+        return;
+    }
+    if (LinSel<Src>::two_sets && odospec) {
+        const size_t lds = (size_t)std::max(24 * d.np + 8, 128) * sizeof(double);
+        ensure_lds(k_backsub<G, Src, LinSel<Src>::two_sets>, lds);
+        TIMED_LAUNCH((k_backsub<G, Src, LinSel<Src>::two_sets>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
+    } else {
+        const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
+        ensure_lds(k_backsub<G, Src, false>, lds);
+        TIMED_LAUNCH((k_backsub<G, Src, false>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
+    }
 }
 template <class Src>
 static void launch_linearize_src(const Src& src, const LaunchDims& d, int B, int spec, hipStream_t s) {
@@ -2653,7 +2702,14 @@ static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream
         else TIMED_LAUNCH((k_pcg1<Src, 0>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
     }
     else if (d.pcg_rows <= 64) TIMED_LAUNCH((k_pcg<1, true, Src, false>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
-    else TIMED_LAUNCH((k_pcg<1, true, Src, true>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);      // Npf <= MAX_PCG_FREE_POSES = 256
+    else if (d.pcg_rows <= MAX_PCG_ONE_ROW_POSES) TIMED_LAUNCH((k_pcg<1, true, Src, true>), dim3(d.pcg_rows, B), dim3(256), (size_t)d.pcg_lds, s, src);
+    else {
+        // more than 256 free poses (single windows only): several block rows per workgroup, 2 or 4 blocks per owner thread
+        const DeviceGraph& g = graph_of_host(src);
+        const int wgs = (d.pcg_rows + g.pcg_rows_per_wg - 1) / g.pcg_rows_per_wg;
+        if (d.pcg_rows <= 512) { ensure_lds(k_pcg<2, false, One, true, true>, (size_t)d.pcg_lds); TIMED_LAUNCH((k_pcg<2, false, One, true, true>), dim3(wgs, B), dim3(256), (size_t)d.pcg_lds, s, One{ g }); }
+        else { ensure_lds(k_pcg<4, false, One, true, true>, (size_t)d.pcg_lds); TIMED_LAUNCH((k_pcg<4, false, One, true, true>), dim3(wgs, B), dim3(256), (size_t)d.pcg_lds, s, One{ g }); }
+    }
 }
 template <class Src>
 static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, int odospec, hipStream_t s) {
@@ -2667,7 +2723,8 @@ static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, int o
 }
 template <class Src>
 static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
-    hipLaunchKernelGGL((k_eval<Src>), dim3(d.eval_blocks, B), dim3(256), lds_poses(d, 8), s, src, mark, phase_just_done);
+    if (!staged(d)) hipLaunchKernelGGL((k_eval<One, false>), dim3(d.eval_blocks, B), dim3(256), lds_poses(d, 8), s, One{ graph_of_host(src) }, mark, phase_just_done);
+    else { ensure_lds(k_eval<Src>, lds_poses(d, 8)); hipLaunchKernelGGL((k_eval<Src>), dim3(d.eval_blocks, B), dim3(256), lds_poses(d, 8), s, src, mark, phase_just_done); }
     hipLaunchKernelGGL((k_phase_end<Src>), dim3(1, B), dim3(256), 0, s, src, phase_just_done, next_max_iter);
 }
 
@@ -2692,7 +2749,8 @@ void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int n
 // stage hook: the outlier pass of Optimizer.cpp:283-303 on the committed estimate, ungated (k_eval alone: marks edges, no phase change)
 void launch_eval_mark(const DeviceGraph& g, hipStream_t s) {
     const LaunchDims d = dims_of(g);
-    hipLaunchKernelGGL((k_eval<One>), dim3(d.eval_blocks), dim3(256), lds_poses(d, 8), s, One{ g }, 1, -1);
+    if (!staged(d)) hipLaunchKernelGGL((k_eval<One, false>), dim3(d.eval_blocks), dim3(256), lds_poses(d, 8), s, One{ g }, 1, -1);
+    else { ensure_lds(k_eval<One>, lds_poses(d, 8)); hipLaunchKernelGGL((k_eval<One>), dim3(d.eval_blocks), dim3(256), lds_poses(d, 8), s, One{ g }, 1, -1); }
 }
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s) {
     hipLaunchKernelGGL((k_reset<One>), dim3(dims_of(g).reset_blocks), dim3(256), 0, s, One{ g }, max_iter, gauss_newton, restore);
@@ -2784,8 +2842,8 @@ bool small_path_fits(const DeviceGraph& g) {
 bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= SM_MAX_N6; }
 
 int configure_kernels(const DeviceGraph& g) {
-    // dynamic LDS above 64 KiB needs an explicit opt-in (never the case with the limits in ba_device.hpp, kept for safety)
-    if (g.pcg_lds_bytes > 64 * 1024) {
+    // dynamic LDS above 64 KiB needs an explicit opt-in (the multi-row PCG kernels opt in at their launch: ensure_lds)
+    if (g.pcg_lds_bytes > 64 * 1024 && g.Npf <= MAX_PCG_ONE_ROW_POSES) {
         const void* f = g.Npf <= 64 ? reinterpret_cast<const void*>(k_pcg<1, true, One, false>) : reinterpret_cast<const void*>(k_pcg<1, true, One, true>);
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, g.pcg_lds_bytes) != hipSuccess) return -1;
     }

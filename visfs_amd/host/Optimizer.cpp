@@ -48,7 +48,9 @@ Optimizer::Optimizer(const ParametersMap& _parameters) :
     lastStatus_ = visfs_ba_create(&prm, device_, &handle_);
     if (lastStatus_ != VISFS_BA_OK) {
         handle_ = nullptr;
-        std::fprintf(stderr, "VISFS::Optimizer (MI355X backend): no gfx950 device %d — localOptimize will fail (there is no CPU fallback)\n", device_);
+        createError_ = visfs_ba_create_error();          // missing device, wrong architecture or an allocation failure: say which
+        std::fprintf(stderr, "VISFS::Optimizer (MI355X backend): cannot open device %d (status %d): %s — localOptimize will fail (there is no CPU fallback)\n",
+                     device_, lastStatus_, createError_.c_str());
     }
 }
 
@@ -56,7 +58,7 @@ Optimizer::~Optimizer() {
     if (handle_) visfs_ba_destroy(handle_);
 }
 
-const char* Optimizer::lastError() const { return handle_ ? visfs_ba_last_error(handle_) : "no device"; }
+const char* Optimizer::lastError() const { return handle_ ? visfs_ba_last_error(handle_) : createError_.c_str(); }
 
 std::map<std::size_t, Eigen::Isometry3d> Optimizer::localOptimize(
     std::size_t _rootId,

@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <map>
+#include <string>
 #include <memory>
 #include <tuple>
 #include <vector>
@@ -68,6 +69,7 @@ private:
     int device_;
     visfs_ba_handle* handle_;
     int lastStatus_;
+    std::string createError_;      // why visfs_ba_create failed (visfs_ba_create_error), kept for lastError()
 };
 
 }  // namespace Optimizer
