@@ -27,6 +27,16 @@ TRIAL = [("S", abi.BUF_S), ("bs", abi.BUF_BS), ("dx_pose", abi.BUF_DX_POSE), ("d
 TOL = 1e-9
 
 
+def safe_cond(M):
+    """2-norm condition number; inf for a matrix that already holds non-finite entries or whose SVD does not converge."""
+    if not np.isfinite(M).all():
+        return float("inf")
+    try:
+        return float(np.linalg.cond(M))
+    except np.linalg.LinAlgError:
+        return float("inf")
+
+
 def landmark_conds(o, lam):
     """cond_2 of every free landmark's (H_ll + lambda I) that has an active edge (the oracle's values)."""
     H = o.fetch(abi.BUF_HLL).reshape(-1, 6)
@@ -36,9 +46,14 @@ def landmark_conds(o, lam):
     act = np.abs(H).sum(axis=1) > 0
     if not act.any():
         return 1.0
-    sv = np.linalg.svd(M[act], compute_uv=False)
-    with np.errstate(divide="ignore"):
-        return float(np.max(sv[:, 0] / sv[:, -1]))
+    if not np.isfinite(M[act]).all():
+        return float("inf")
+    try:
+        sv = np.linalg.svd(M[act], compute_uv=False)
+    except np.linalg.LinAlgError:
+        return float("inf")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.nanmax(sv[:, 0] / sv[:, -1]))
 
 
 def step_case(olib, lib, seed):
@@ -59,8 +74,7 @@ def step_case(olib, lib, seed):
             ot, gt = o.trial(0.0), s.trial(0.0)
             worst += [(name, rel_err(s.fetch(b), o.fetch(b))) for name, b in TRIAL]
             S = o.fetch(abi.BUF_S); n6 = int(round(np.sqrt(S.size)))
-            condS = float(np.linalg.cond(S.reshape(n6, n6))) if n6 else 1.0
-            condL = landmark_conds(o, 0.0)
+            condS, condL = safe_cond(S.reshape(n6, n6)) if n6 else 1.0, landmark_conds(o, 0.0)
             bad = [(n, e) for n, e in worst if not (e <= TOL)]
             log.append(f"   phase {phase + 1} it {it}: chi2 {oc:.6g} | cond(S) {condS:.2e} cond(Hll) {condL:.2e} | solver ok o/g {ot[3]}/{gt[3]} | "
                        + ("all stages <= 1e-9" if not bad else "FIRST > 1e-9: " + ", ".join(f"{n} {e:.1e}" for n, e in bad)))
@@ -93,7 +107,10 @@ def step_case(olib, lib, seed):
 def main():
     olib = oracle_lib.load(); lib = backend.load_library()
     for a in sys.argv[1:]:
-        print(step_case(olib, lib, int(a)), flush=True)
+        try:
+            print(step_case(olib, lib, int(a)), flush=True)
+        except Exception as e:                       # keep going: one seed must not hide the others
+            print(f"seed {a}: tool error {type(e).__name__}: {e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,7 @@ struct Workspace {
     // VISFS_BA_GRAPH=1 (measurement): the up-front launch sequence of a solve captured once per resident graph and replayed
     hipGraphExec_t graph_exec = nullptr;
     int graph_units[2] = { -1, -1 };
+    int solves_since_upload = 0;
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
     int64_t n_pairs = 0;
@@ -197,6 +198,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     int rc = ws_init(h, w);
     if (rc != VISFS_BA_OK) return rc;
     if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; w.graph_units[0] = w.graph_units[1] = -1; }   // kernel arguments change
+    w.solves_since_upload = 0;
 
     // buildIndexMapping: free poses in index (= id) order
     std::vector<int32_t> pose_free(Np), free_pose;
@@ -450,7 +452,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.Minv = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.x = A.take<double>(std::max<size_t>(n6, 1));
         g.sch_part = A.take<double>((size_t)std::max(n_sch, 1) * 42);
-        g.granules = A.take<unsigned long long>(std::max<size_t>(4 * n6, 1));
+        g.granules = A.take<unsigned long long>(std::max<size_t>(4 * n6 + Npf, 1));        // + one placement word per block row (k_pcg1)
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
@@ -664,11 +666,16 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     };
     // (a window that rejected trials last time — an estimator's consecutive frames behave alike — gets that many units more up
     // front: a gated no-op unit costs ~7 us, the state read it saves ~25 us plus the bubble behind it)
-    static const bool use_graph = []() { const char* e = std::getenv("VISFS_BA_GRAPH"); return e && e[0] == '1'; }();
+    // hipGraph replay of the up-front launch sequence (VISFS_BA_GRAPH=0 disables, =1 captures at the first solve).  A graph holds the
+    // kernel arguments (the DeviceGraph travels by value) and the grid sizes, so it serves only RE-optimisations of the same
+    // resident graph with the same unit counts: by default it is captured when the same graph is optimised a second time, never
+    // for a window that is uploaded, solved once and replaced (visfs_ba_solve_window per frame).  Measured
+    // (profiles/r02_hipgraph_replay.log): C2 19.0 -> 19.4 k it/s (GPU-bound stream), PROD 23.5 -> 25.6 k it/s (small kernels:
+    // the eager host launch rate shows).
+    static const int graph_mode = []() { const char* e = std::getenv("VISFS_BA_GRAPH"); return e ? std::atoi(e) : 2; }();
     const int n0 = half + w.extra_units[0], n1 = half2 > 0 ? half2 + w.extra_units[1] : 0;
-    if (use_graph && !w.prof_mask) {
-        // measurement variant: the same launches as one hipGraph, captured once per (resident graph, unit counts) and replayed
-        // (the reset launched above stays outside).  Eager launches are the default: see DESIGN.md §4 for the numbers.
+    w.solves_since_upload += 1;
+    if (graph_mode != 0 && !w.prof_mask && (graph_mode == 1 || w.solves_since_upload >= 2)) {
         if (!w.graph_exec || w.graph_units[0] != n0 || w.graph_units[1] != n1) {
             if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
             hipGraph_t gr = nullptr;

@@ -911,7 +911,7 @@ __device__ __forceinline__ double gauss_jordan_6x6(const double val, const int l
 // One wavefront, one stored block of S: shared by k_schur_finalize and the fused small-window kernel.
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
     {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
-        const int nwords = 4 * 6 * g.Npf;
+        const int nwords = 4 * 6 * g.Npf + g.Npf;           // q granules of both parities + one placement word per block row
         for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
     }
     const double lambda = st->lambda;
@@ -983,6 +983,14 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
 // Granules are double-buffered on the iteration parity and zeroed by k_schur_finalize before every solve.
 // Residency: grid = Npf <= 256 workgroups of 4 waves: one per CU always fits, so the grid is co-resident on an otherwise
 // idle device; concurrent windows (visfs_ba_solve_batch) are limited so that the sum of their grids stays <= 256.
+// The XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID (hardware register 20), bits 3:0.
+__device__ __forceinline__ unsigned xcc_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (unsigned)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+#else
+    return 0u;
+#endif
+}
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1311,12 +1319,19 @@ struct ReduceScatterUp<N, 64> {
 // GV (gather variant, measured in profiles/r02_pcg1_gather_variants.log): 0 = twelve 8-byte loads per sweep, one sweep in flight;
 // 1 = six 16-byte loads (two granules each: every 8-byte half is one store of its producer); 2 = 1 + the next sweep is issued
 // before the previous one is checked (two sweeps in flight: the poll period halves without waiting less).
+// 3 = 2 + the XCD-LOCAL hand-off: the launch carries 8x the workgroups and only every 8th one works (blockIdx.x % 8 == window % 8),
+// which the dispatcher is OBSERVED to place on one XCD.  Nothing relies on that: iteration 0 runs the cross-XCD protocol and every
+// row publishes its HW_REG_XCC_ID with its q; only if ALL rows report the same XCD — a fact about this launch, read from the
+// hardware — do the later iterations publish with PLAIN stores (kept in that XCD's L2, the coherence point of its CUs) and keep
+// reading with sc1 loads (past the L1, served by that L2): an L2 round trip instead of a fabric one per hand-off.  Otherwise they
+// stay on the write-through path.  Both paths move the same bits; the choice is identical in every wave (same gathered words).
 template <class Src, int GV>
 __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
+    if (GV == 3 && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
     if (!(st->mode & MODE_TRIAL)) return;
-    const int i0 = blockIdx.x;
+    const int i0 = GV == 3 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (i0 >= g.Npf) return;                          // a batched launch is sized for the largest window
     const int lane = threadIdx.x;
     const int Npf = g.Npf, n6 = 6 * Npf;
@@ -1366,6 +1381,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     }
     int iter = 0;
     bool timeout = false;
+    bool xcd_local = false;                            // GV == 3: every row of this window runs on one XCD (decided after iteration 0)
     PCG1_STAMP(0);
     while (true) {
         if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
@@ -1386,9 +1402,12 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
         if (len >= 1) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(y[0]);
             unsigned long long* o = gr + 2 * (6 * i0 + off);
-            st_granule(o, ((unsigned long long)epoch << 32) | (bits & 0xffffffffull));
-            st_granule(o + 1, ((unsigned long long)epoch << 32) | (bits >> 32));
+            const unsigned long long g0 = ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), g1 = ((unsigned long long)epoch << 32) | (bits >> 32);
+            if (GV == 3 && xcd_local) { o[0] = g0; o[1] = g1; }            // plain stores: the line stays in this XCD's L2
+            else { st_granule(o, g0); st_granule(o + 1, g1); }
         }
+        if (GV == 3 && iter == 0 && lane == 0)                             // where this row runs (tag 1 = valid)
+            st_granule(g.granules + 4 * n6 + i0, (1ull << 32) | (unsigned long long)xcc_id());
         // ---- q_lane from the granules of block row `lane` (published by the wave of that row): sweep until every tag matches
         PCG1_STAMP(2 + 4 * iter);
         double qq[6];
@@ -1426,7 +1445,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
                 };
                 v4u_t a[6], b[6];
                 sweep(a);
-                if (GV == 2) {
+                if (GV >= 2) {
                     // two sweeps in flight: the next one is ISSUED before the previous one is checked (the sched_barrier pins that
                     // order: the check then waits with vmcnt(6), not for the sweep just issued)
                     while (true) {
@@ -1454,8 +1473,22 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
                 }
             }
             if (timeout) break;
+            if (GV == 3 && iter == 0) {
+                // the placement word of row `lane`: published before that row's q granules left, so usually there already
+                const unsigned long long* xp = g.granules + 4 * n6 + (own ? lane : 0);
+                unsigned long long xw = 0ull;
+                while (true) {
+                    if (own) xw = ld_granule(xp);
+                    if (__all(!own || (xw >> 32) == 1ull)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { timeout = true; break; }
+                }
+                if (timeout) break;
+                const unsigned x0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xw);      // row 0's XCD
+                xcd_local = __all(!own || (unsigned)xw == x0);
+            }
 #ifdef VISFS_BA_STAMPS
-            if (lane == 0 && i0 == g.stamp_wg && iter < 26) g.stamps[100 + iter] = spins;
+            if (lane == 0 && i0 == g.stamp_wg && iter < 26) g.stamps[100 + iter] = spins + (xcd_local ? 1000u : 0u);
 #endif
 #pragma unroll
             for (int c = 0; c < 6; ++c)
@@ -2697,7 +2730,10 @@ template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     if (d.pcg_one_wave) {
         static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 0; }();
-        if (gv == 2) TIMED_LAUNCH((k_pcg1<Src, 2>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
+        // the XCD-local form only for a window on its own: its <= 64 one-wave workgroups are resident even if the dispatcher packs
+        // them all onto one XCD (that is the intent); a batch on one XCD would not be (co-residency must not depend on placement)
+        if (gv == 3 && LinSel<Src>::two_sets) TIMED_LAUNCH((k_pcg1<One, 3>), dim3(8 * d.pcg_rows, B), dim3(64), 0, s, One{ graph_of_host(src) });
+        else if (gv >= 2) TIMED_LAUNCH((k_pcg1<Src, 2>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else if (gv == 1) TIMED_LAUNCH((k_pcg1<Src, 1>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else TIMED_LAUNCH((k_pcg1<Src, 0>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
     }
