@@ -124,15 +124,23 @@ def test_batch_above_the_residency_cap_splits_and_stays_bit_identical(olib, monk
 
 
 @pytest.mark.parametrize("cfg", ["C2", "C3"])
-def test_one_wave_pcg_kernel_and_four_wave_kernel_agree(olib, monkeypatch, cfg):
-    """<= 64 free poses: k_pcg1 (one wavefront per block row, no LDS, no barrier) and k_pcg (four waves) run the same recurrences
-    with a different association of the mat-vec sums: same iteration counts, results equal to rounding, both in parity with the oracle."""
+def test_the_three_pcg_kernels_agree(olib, monkeypatch, cfg):
+    """49 free poses, block rows of <= 21 blocks: k_pcg_cu (the whole solve in ONE workgroup, S in registers, no cross-workgroup
+    hand-off — the default for such systems), k_pcg1 (one wavefront per block row, granule hand-offs) and k_pcg (four waves per
+    block row) run the same recurrences with different associations of the mat-vec sums: same iteration counts, results equal to
+    rounding; the suite's oracle parity tests run on the default."""
     from test_gpu_parity import _solve_in_mode
     w = synth.make_window(cfg)
-    _, rc1, st1, out1 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_PCG1="1"), iterations=20, solver=2)
-    _, rc0, st0, out0 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_PCG1="0"), iterations=20, solver=2)
-    assert rc0 == rc1 == abi.OK
-    assert list(st0.iterations_run) == list(st1.iterations_run) and list(st0.trials_run) == list(st1.trials_run)
-    assert st0.pcg_iterations == st1.pcg_iterations
-    assert np.array_equal(out0[2], out1[2])
-    assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10
+    runs = {}
+    for name, env in (("cu", dict(VISFS_BA_PCG_CU="1")), ("one_wave", dict(VISFS_BA_PCG_CU="0", VISFS_BA_PCG1="1")),
+                      ("four_wave", dict(VISFS_BA_PCG_CU="0", VISFS_BA_PCG1="0"))):
+        info, rc, st, out = _solve_in_mode(monkeypatch, w, env, iterations=20, solver=2)
+        assert rc == abi.OK
+        runs[name] = (st, out)
+    st0, out0 = runs["four_wave"]
+    for name in ("cu", "one_wave"):
+        st1, out1 = runs[name]
+        assert list(st0.iterations_run) == list(st1.iterations_run) and list(st0.trials_run) == list(st1.trials_run), name
+        assert st0.pcg_iterations == st1.pcg_iterations, name
+        assert np.array_equal(out0[2], out1[2]), name
+        assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10, name

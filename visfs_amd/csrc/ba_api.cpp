@@ -199,6 +199,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     if (rc != VISFS_BA_OK) return rc;
     if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; w.graph_units[0] = w.graph_units[1] = -1; }   // kernel arguments change
     w.solves_since_upload = 0;
+    HIP_TRY(h, hipStreamSynchronize(w.stream));            // the previous upload's H2D copy reads the pinned staging arena filled below
 
     // buildIndexMapping: free poses in index (= id) order
     std::vector<int32_t> pose_free(Np), free_pose;
@@ -254,17 +255,40 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     std::vector<int32_t> pcount((size_t)Npf * Npf, 0);
     std::vector<uint8_t> has_odo((size_t)Npf * Npf, 0);
     int64_t pairs_seen = 0;
-    for (int l = 0; l < Nl; ++l) {
-        if (gr->point_fixed[l]) continue;
-        const int k_end = lm_ptr[l + 1];
-        for (int k1 = lm_ptr[l]; k1 < k_end; ++k1) {
-            const int a = obs_free[k1];
-            if (a < 0) continue;
-            int32_t* row = pcount.data() + (size_t)a * Npf;
-            for (int k2 = k1; k2 < k_end; ++k2) {
-                const int b = obs_free[k2];
-                if (b >= 0) { row[b]++; ++pairs_seen; }
+    {
+        // A landmark seen by the free poses {a_1 < ... < a_k} adds one pair to every block (a_i, a_j), i <= j.  Tracks are runs of
+        // consecutive key-frames almost always (a feature is tracked frame to frame and never re-acquired), so a landmark whose free
+        // poses form the contiguous range [s, e] only bumps run[s][e]; the blocks are then counted by one 2-D inclusion sum,
+        // pcount[a][b] = sum over s <= a, e >= b of run[s][e] — O(Nl + Npf^2) instead of O(sum k^2) (0.11 ms of a C2 upload, 0.64 ms
+        // at C4).  Landmarks with gaps in their track take the pairwise loop.
+        std::vector<int32_t> run((size_t)Npf * Npf, 0);
+        bool any_run = false;
+        for (int l = 0; l < Nl; ++l) {
+            if (gr->point_fixed[l]) continue;
+            const int k_end = lm_ptr[l + 1];
+            int first = -1, last = -1, cnt = 0;
+            for (int k = lm_ptr[l]; k < k_end; ++k) { const int a = obs_free[k]; if (a >= 0) { if (first < 0) first = a; last = a; ++cnt; } }
+            if (cnt == 0) continue;
+            pairs_seen += (int64_t)cnt * (cnt + 1) / 2;
+            if (last - first + 1 == cnt) { run[(size_t)first * Npf + last]++; any_run = true; continue; }     // (observations ascend by pose)
+            for (int k1 = lm_ptr[l]; k1 < k_end; ++k1) {
+                const int a = obs_free[k1];
+                if (a < 0) continue;
+                int32_t* row = pcount.data() + (size_t)a * Npf;
+                for (int k2 = k1; k2 < k_end; ++k2) { const int b = obs_free[k2]; if (b >= 0) row[b]++; }
             }
+        }
+        if (any_run) {
+            // in place: run[a][b] <- sum_{s <= a, e >= b} run[s][e]
+            for (int a = 0; a < Npf; ++a)
+                for (int b = Npf - 1; b >= 0; --b) {
+                    int64_t v = run[(size_t)a * Npf + b];
+                    if (a > 0) v += run[(size_t)(a - 1) * Npf + b];
+                    if (b + 1 < Npf) v += run[(size_t)a * Npf + b + 1];
+                    if (a > 0 && b + 1 < Npf) v -= run[(size_t)(a - 1) * Npf + b + 1];
+                    run[(size_t)a * Npf + b] = (int32_t)v;
+                }
+            for (int a = 0; a < Npf; ++a) for (int b = a; b < Npf; ++b) pcount[(size_t)a * Npf + b] += run[(size_t)a * Npf + b];
         }
     }
     if (pairs_seen > 0x7fffffff) { h->err = "window too large (pair list)"; return VISFS_BA_ERR_UNSUPPORTED; }
@@ -369,6 +393,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         for (int a = 0; a < Npf; ++a)
             for (int n = row_ptr[a]; n < row_ptr[a + 1]; ++n) pcg1_code[(size_t)a * Npf + row_col[n]] = row_blk[n];
     }
+    // k_pcg_cu: the whole PCG in one workgroup when every block row is short enough to sit in registers (3 threads per scalar row)
+    const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
+                                return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && !(e && e[0] == '0'); }();
     lap("pair count");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -533,7 +560,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_pose_obs = cnt[Npf];
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
-    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
@@ -564,8 +591,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     launch_reset(w.g, prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
     HIP_TRY(h, hipGetLastError());
     lap("enqueue");
-    HIP_TRY(h, hipStreamSynchronize(w.stream));            // staging arena is reused by the next upload
-    lap("h2d+sync");
+    // no synchronisation here: the launches that follow queue up behind the copy; the pinned staging arena is only reused by the
+    // NEXT upload, which drains the stream first (see the top of this function)
+    if (timing) { HIP_TRY(h, hipStreamSynchronize(w.stream)); lap("h2d+sync"); }
     w.loaded = true;
     return VISFS_BA_OK;
 }
@@ -625,7 +653,7 @@ std::mutex& pcg_device_mutex(int device) {
 int batch_members_per_launch(visfs_ba_handle* h, const std::vector<Workspace*>& ws, const std::vector<int>& all) {
     LaunchDims d = dims_of(ws[all[0]]->g);
     bool no_pcg = true;
-    for (int i : all) { d = dims_max(d, dims_of(ws[i]->g)); no_pcg = no_pcg && (ws[i]->small_solve || ws[i]->fused); }
+    for (int i : all) { d = dims_max(d, dims_of(ws[i]->g)); no_pcg = no_pcg && (ws[i]->small_solve || ws[i]->fused || ws[i]->g.pcg_cu); }
     if (no_pcg) return 4096;                               // single-workgroup solvers: no co-residency requirement
     int cap = pcg_resident_capacity(d, true, h->device);
     if (cap <= 0) cap = 256;                               // query failed: one 256-thread workgroup per CU is always admitted
@@ -639,7 +667,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     const int half = h->prm.iterations / 2;
     std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
-    if (h->prm.solver == 2 && !w.small_solve && !w.fused) pcg_lock.lock();          // persistent PCG: one grid at a time per device
+    if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lock.lock();   // persistent PCG: one grid at a time per device
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
     { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     if (w.fused) {
@@ -883,7 +911,7 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         fused = fused && w.fused; small_solve = small_solve && w.small_solve;
     }
     std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
-    if (!fused && !small_solve) pcg_lock.lock();                                    // persistent PCG: one grid at a time per device
+    if (!fused && !small_solve && !d.pcg_cu) pcg_lock.lock();                       // persistent PCG: one grid at a time per device
     HIP_TRY(h, hipMemcpyAsync(bs.d_graphs, hg.data(), (size_t)B * sizeof(DeviceGraph), hipMemcpyHostToDevice, stream));
     const int half = h->prm.iterations / 2;
     launch_reset_batch(bs.d_graphs, B, d, half, h->prm.trust_region == 1, 0, stream);
@@ -1152,7 +1180,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             const Workspace& ws = *h->batch[i];
             const bool batchable = batching && (h->prm.solver == 2 || ws.small_solve || ws.fused) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
-            const int cls = ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
+            const int cls = ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
         }
         std::vector<visfs_ba_stats> stats(n);
@@ -1222,7 +1250,7 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
             const Workspace& ws = *h->batch[i];
             if (!(h->prm.solver == 2 || ws.small_solve || ws.fused)) { h->err = "batched launches need Optimizer/Solver=2 or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
             if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
-            const int cls = ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
+            const int cls = ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
         }
         int worst = VISFS_BA_OK;

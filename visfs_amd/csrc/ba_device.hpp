@@ -94,6 +94,7 @@ struct DeviceGraph {
     int32_t pcg_lds_srow;   // ... and its own block row of S
     int32_t pcg_max_row;    // longest block row of S (blocks)
     int32_t pcg_rows_per_wg; // block rows per PCG workgroup (1 up to 256 free poses)
+    int32_t pcg_cu;         // 1: the reduced system is solved by ONE workgroup (k_pcg_cu: S in registers, no cross-workgroup hand-off)
     int32_t pcg_lds_bytes;
     int32_t chol_np;        // padded order of the dense reduced camera matrix (direct solver)
     int32_t n_lin_a;        // workgroups of the landmark-major role

@@ -1538,6 +1538,148 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     }
 }
 
+// ---- K6, reduced systems that fit ONE compute unit: no cross-workgroup hand-off at all
+// A hand-off between workgroups costs ~1.5 us per PCG iteration on this chip whatever the placement (stamped in k_pcg1: the same on
+// one XCD through its L2 as across XCDs, profiles/r02_pcg1_gather_variants.log) — two thirds of an iteration.  When every block row
+// of S has at most 3 * CU_K blocks and 3 threads per scalar row fit one workgroup (<= 56 free poses), ONE workgroup solves the whole
+// system: thread (row, h) keeps a third of its row's non-zeros in REGISTERS (CU_K six-value slices, transposed blocks read
+// transposed once), d lives in LDS, and an iteration is CU_K x 6 multiply-adds per thread, two shuffles to join the thirds, and
+// two workgroup reductions (wave butterfly + per-wave partials in fixed order) separated by barriers.  Same recurrences, tolerance
+// and residual carry-over as k_pcg ([g2o-upstream] LinearSolverPCG::solve); S, b_s and Minv come from k_schur_finalize.
+constexpr int CU_K = 7;                // blocks per thread: block rows of up to 21 blocks (C2 / C3: 19)
+constexpr int CU_KR = 6;               // ... of which in registers; the last slice lives in LDS (the kernel runs at 128 VGPRs: 16 waves per CU)
+constexpr int CU_RPW = 21;             // scalar rows per wavefront (63 of its 64 lanes)
+constexpr int CU_MAX_N6 = 16 * CU_RPW; // 336 scalar rows = 56 free poses in 16 wavefronts
+
+template <class Src>
+__global__ __launch_bounds__(1024) void k_pcg_cu(const Src src) {
+    const DeviceGraph& g = graph_of(src);
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    __shared__ __attribute__((aligned(16))) double sd[CU_MAX_N6 + 8], sr[CU_MAX_N6 + 8];
+    __shared__ __attribute__((aligned(16))) double sM[CU_MAX_N6 * 6];      // Minv rows
+    __shared__ double sPa[16], sPb[16];
+    __shared__ double sSl[(CU_K - CU_KR) * 6 * 1024];                       // [slice][c][thread]: conflict-free 8-byte reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int n6 = 6 * g.Npf;
+    const int row = wave * CU_RPW + lane / 3, h = lane % 3;
+    const bool act = lane < 63 && row < n6;
+    const bool owner = act && h == 0;
+    const int bi = act ? row / 6 : 0, r6 = act ? row % 6 : 0;
+    // ---- set-up: this thread's third of row `row` of S (blocks h, h + 3, ... of the block row), the Minv row and b_s
+    double Sv[CU_K][6];
+    int coff[CU_K];
+    {
+        // every load below is unconditional (indices clamped into the row's list, values masked afterwards): 42 independent
+        // loads in flight per thread instead of a chain of predicated ones
+        const int rb = g.row_ptr[bi], nb = g.row_ptr[bi + 1] - rb;
+        int col[CU_K], code[CU_K];
+#pragma unroll
+        for (int k = 0; k < CU_K; ++k) {
+            const int n = h + 3 * k, nc = n < nb ? n : nb - 1;          // (a free pose's block row holds at least its diagonal block)
+            col[k] = g.row_col[rb + nc]; code[k] = g.row_blk[rb + nc];
+        }
+#pragma unroll
+        for (int k = 0; k < CU_K; ++k) {
+            const double* Sb = g.S + 36 * (size_t)(code[k] >> 1);
+            const bool tr = (code[k] & 1) != 0;       // the stored block is (col, bi): its column r6 is this row
+            const int base = tr ? r6 : 6 * r6, step = tr ? 6 : 1;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Sv[k][c] = Sb[base + step * c];
+        }
+#pragma unroll
+        for (int k = 0; k < CU_K; ++k) {
+            const bool has = act && (h + 3 * k) < nb;
+            coff[k] = has ? 6 * col[k] : 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Sv[k][c] = has ? Sv[k][c] : 0.0;
+        }
+#pragma unroll
+        for (int k = CU_KR; k < CU_K; ++k)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sSl[((k - CU_KR) * 6 + c) * 1024 + tid] = Sv[k][c];     // own writes, own reads: no barrier needed
+    }
+    double rr = 0.0, dd = 0.0, xx = 0.0;
+    if (owner) {
+        rr = g.bs[row];
+        const double* M = g.Minv + 36 * (size_t)bi + 6 * r6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sM[6 * row + c] = M[c];
+        sr[row] = rr;
+    }
+    // sum over the workgroup, every thread gets it: wave butterfly, per-wave partials added in wave order (fixed)
+    auto wg_sum = [&](const double v, double* part) -> double {
+        const double ws = wave_sum(v);
+        if (lane == 0) part[wave] = ws;
+        __syncthreads();
+        double t = part[0];
+        for (int w = 1; w < nw; ++w) t += part[w];
+        return t;
+    };
+    auto minv_row = [&]() -> double {                 // (Minv r)[row] from the LDS copies (own writes of sM; sr behind a barrier)
+        const double* m = sM + 6 * row; const double* rv = sr + 6 * bi;
+        return ((((m[0] * rv[0] + m[1] * rv[1]) + m[2] * rv[2]) + m[3] * rv[3]) + m[4] * rv[4]) + m[5] * rv[5];
+    };
+    __syncthreads();
+    if (owner) dd = minv_row();
+    double dn = wg_sum(owner ? rr * dd : 0.0, sPa);
+    double d0 = 1e-6 * dn;
+    {
+        const double res_in = st->pcg_res_in;
+        if (res_in > 0.0 && res_in > d0) d0 = res_in;
+    }
+    if (owner) sd[row] = dd;
+    __syncthreads();
+    int iter = 0;
+    while (true) {
+        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
+        // ---- q = S d: a third of the row per thread, joined on the row's first lane
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < CU_K; ++k) {
+            const double* dv = sd + coff[k];
+            double sv[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sv[c] = (k < CU_KR) ? Sv[k][c] : sSl[((k - CU_KR) * 6 + c) * 1024 + tid];
+            acc += ((((sv[0] * dv[0] + sv[1] * dv[1]) + sv[2] * dv[2]) + sv[3] * dv[3]) + sv[4] * dv[4]) + sv[5] * dv[5];
+            // (the kernel sits at its 128-register budget with the row slices resident: keep the LDS reads of at most two slices
+            // in flight instead of letting all seven be hoisted, which spilled slices of S to scratch inside this loop)
+            if (k & 1) asm volatile("" ::: "memory");
+        }
+        const double a1 = __shfl_down(acc, 1, 64), a2 = __shfl_down(acc, 2, 64);
+        const double q = (acc + a1) + a2;             // meaningful on h == 0
+        const double dq = wg_sum(owner ? dd * q : 0.0, sPb);
+        const double alpha = dn / dq;
+        if (owner) { xx += alpha * dd; rr -= alpha * q; sr[row] = rr; }
+        __syncthreads();
+        double z = 0.0;
+        if (owner) z = minv_row();
+        const double dnn = wg_sum(owner ? rr * z : 0.0, sPa);
+        const double beta = dnn / dn;
+        if (owner) { dd = z + beta * dd; sd[row] = dd; }
+        __syncthreads();
+        dn = dnn;
+        iter += 1;
+    }
+    // x is final: K8 (oplus) by the first row of every block; thread 0 publishes the statistics
+    if (owner) { g.x[row] = xx; sr[row] = xx; }
+    __syncthreads();
+    if (owner && r6 == 0) {
+        double dx[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dx[c] = sr[row + c];
+        const int ip = g.free_pose[bi];
+        const int sel = st->sel;
+        pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+    }
+    if (tid == 0) {
+        st->pcg_residual = 0.5 * dn;
+        st->pcg_iter = iter;
+        st->pcg_total += iter;
+        if (iter > st->pcg_max) st->pcg_max = iter;
+    }
+}
+
 // ================================================================= K6 (direct): blocked Cholesky of the reduced camera matrix
 // Optimizer/Solver 0, 1, 3 (CSparse / Cholmod / Eigen sparse Cholesky in the reference, Optimizer.cpp:76-91) all factor
 // S = L L^T and back-substitute; here S is assembled dense (n = 6 Npf padded to a multiple of 32 with an identity tail)
@@ -2654,6 +2796,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.reset_blocks = std::min(std::max((g.No + 255) / 256, 1), 1024);
     d.has_odo = (g.Ne > 0 || g.Nz > 0) ? 1 : 0;
     d.pcg_one_wave = g.pcg1_code != nullptr ? 1 : 0;
+    d.pcg_cu = g.pcg_cu;
     return d;
 }
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
@@ -2663,6 +2806,7 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
     d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
     d.pcg_one_wave = a.pcg_one_wave & b.pcg_one_wave;
+    d.pcg_cu = a.pcg_cu & b.pcg_cu;
     return d;
 }
 // dynamic LDS of the kernels that stage every pose of the window as R|t (12 doubles each); windows beyond MAX_STAGED_POSES use the
@@ -2728,6 +2872,7 @@ static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B
 }
 template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    if (d.pcg_cu) { TIMED_LAUNCH((k_pcg_cu<Src>), dim3(1, B), dim3(64 * ((6 * d.pcg_rows + CU_RPW - 1) / CU_RPW)), 0, s, src); return; }
     if (d.pcg_one_wave) {
         static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 0; }();
         // the XCD-local form only for a window on its own: its <= 64 one-wave workgroups are resident even if the dispatcher packs
@@ -2874,6 +3019,8 @@ int pcg_resident_capacity(const LaunchDims& d, bool many, int device) {
 bool small_path_fits(const DeviceGraph& g) {
     return g.Np <= SM_MAX_POSES && 6 * g.Npf <= SM_MAX_N6 && g.Npf >= 1 && 4 * g.n_chunks <= SM_MAX_WCHUNKS && g.No <= SM_MAX_OBS && g.n_sch <= SM_MAX_SCH && g.sch_chunk == SCH_CHUNK;
 }
+
+bool pcg_cu_fits(int npf, int max_row) { return npf >= 1 && 6 * npf <= CU_MAX_N6 && max_row <= 3 * CU_K; }
 
 bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= SM_MAX_N6; }
 

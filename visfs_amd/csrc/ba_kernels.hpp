@@ -9,7 +9,7 @@
 namespace visfs_ba {
 
 // Launch geometry of one window, or the element-wise maximum over a batch of windows (same lanes-per-landmark group).
-struct LaunchDims { int group, np, lin_blocks, backsub_blocks, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave; };
+struct LaunchDims { int group, np, lin_blocks, backsub_blocks, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave, pcg_cu; };
 LaunchDims dims_of(const DeviceGraph& g);
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b);
 
@@ -30,6 +30,7 @@ void launch_backsub(const DeviceGraph& g, hipStream_t s);
 void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s);   // speculative unit with odometry / laser edges: also linearises them at the trial poses
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
+bool pcg_cu_fits(int npf, int max_row);                               // the reduced system fits the single-workgroup PCG (k_pcg_cu)
 bool small_solve_fits(const DeviceGraph& g);                         // 6 Npf <= 64: S is finalised and solved by one workgroup
 void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s);   // k_schur_finalize + solver + K8 in one launch
 bool small_path_fits(const DeviceGraph& g);                          // the window qualifies for the fused single-workgroup path
