@@ -144,23 +144,3 @@ def test_the_three_pcg_kernels_agree(olib, monkeypatch, cfg):
         assert st0.pcg_iterations == st1.pcg_iterations, name
         assert np.array_equal(out0[2], out1[2]), name
         assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10, name
-
-
-@pytest.mark.parametrize("cfg", ["C2", "C3", "RAGGED30"])
-def test_diagonal_blocks_finalised_in_the_schur_kernel_are_bit_identical(olib, monkeypatch, cfg):
-    """DeviceGraph::sch_dip (one-wave PCG path): k_schur_partial finalises the diagonal blocks of S itself and every PCG wavefront
-    sums the off-diagonal blocks of its own row, so k_schur_finalize is not launched.  Same sums in the same order: every output,
-    counter and trace entry must equal the three-kernel form (VISFS_BA_DIP=0) bit for bit."""
-    from test_gpu_parity import _solve_in_mode, _stats_tuple
-    from helpers import drop_refs
-    if cfg == "RAGGED30":
-        w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, odo=True, seed=11)
-        rng = np.random.default_rng(5)
-        w = drop_refs(w, rng.random(len(w["ref_feature"])) > 0.3)             # gaps in the tracks: pair counting by runs falls back per landmark
-    else:
-        w = synth.make_window(cfg)
-    info1, rc1, st1, out1 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_DIP="1"), iterations=20, solver=2)
-    info0, rc0, st0, out0 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_DIP="0"), iterations=20, solver=2)
-    assert rc0 == rc1 == abi.OK
-    assert _stats_tuple(st0) == _stats_tuple(st1)
-    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out0, out1))

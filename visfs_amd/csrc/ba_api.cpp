@@ -370,12 +370,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         blk_desc[2 * b] = make_int4(blk_chunk_ptr[b], blk_chunk_ptr[b + 1], dg ? pose_odo_ptr[a] : blk_odo_ptr[b], dg ? pose_odo_ptr[a + 1] : blk_odo_ptr[b + 1]);
         blk_desc[2 * b + 1] = make_int4(a, blk_j[b], pose_chunk_ptr[a], pose_chunk_ptr[a + 1]);
     }
-    // DIP: diagonal blocks finalised inside k_schur_partial (see ba_kernels.hip); used with the one-wave PCG (<= 64 free poses, PCG)
-    std::vector<int32_t> diag_blk(std::max(Npf, 1), 0), off_chunk;
-    for (int b = 0; b < n_blk; ++b) {
-        if (blk_i[b] == blk_j[b]) diag_blk[blk_i[b]] = b;
-        else for (int c = blk_chunk_ptr[b]; c < blk_chunk_ptr[b + 1]; ++c) off_chunk.push_back(c);
-    }
     if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 1024 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
     int max_row = 0;
     for (int a = 0; a < Npf; ++a) max_row = std::max(max_row, row_ptr[a + 1] - row_ptr[a]);
@@ -401,7 +395,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     }
     // k_pcg_cu: the whole PCG in one workgroup when every block row is short enough to sit in registers (3 threads per scalar row)
     const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
-                                return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && e && e[0] == '1'; }();   // opt-in: measured slower than k_pcg1 for one window (34.7 vs 21.6 us at C2)
+                                return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && e && e[0] == '1'; }();   // opt-in: measured slower than k_pcg1 for one window (34.7 vs 21.6 us per solve at C2, profiles/r02_pcg_cu_vs_handoff.log)
     lap("pair count");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -440,8 +434,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.blk_j = A.take<int32_t>(std::max(n_blk, 1));
         g.blk_ptr = A.take<int32_t>(n_blk + 1);
         g.blk_chunk_ptr = A.take<int32_t>(n_blk + 1);
-        g.diag_blk = A.take<int32_t>(std::max(Npf, 1));
-        g.off_chunk = A.take<int32_t>(std::max<size_t>(off_chunk.size(), 1));
         g.sch_desc = A.take<int4>(std::max(n_sch, 1));
         g.blk_desc = A.take<int4>(2 * (size_t)std::max(n_blk, 1));
         g.blk_odo_ptr = A.take<int32_t>(n_blk + 1);
@@ -547,8 +539,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (n_blk) { std::memcpy(const_cast<int32_t*>(hg.blk_i), blk_i.data(), (size_t)n_blk * 4); std::memcpy(const_cast<int32_t*>(hg.blk_j), blk_j.data(), (size_t)n_blk * 4); }
         std::memcpy(const_cast<int32_t*>(hg.blk_ptr), blk_ptr.data(), (size_t)(n_blk + 1) * 4);
         std::memcpy(const_cast<int32_t*>(hg.blk_chunk_ptr), blk_chunk_ptr.data(), (size_t)(n_blk + 1) * 4);
-        std::memcpy(const_cast<int32_t*>(hg.diag_blk), diag_blk.data(), diag_blk.size() * 4);
-        if (!off_chunk.empty()) std::memcpy(const_cast<int32_t*>(hg.off_chunk), off_chunk.data(), off_chunk.size() * 4);
         std::memcpy(const_cast<int4*>(hg.sch_desc), sch_desc.data(), sch_desc.size() * sizeof(int4));
         std::memcpy(const_cast<int4*>(hg.blk_desc), blk_desc.data(), blk_desc.size() * sizeof(int4));
         std::memcpy(const_cast<int32_t*>(hg.blk_odo_ptr), blk_odo_ptr.data(), (size_t)(n_blk + 1) * 4);
@@ -570,7 +560,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_pose_obs = cnt[Npf];
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
-    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.n_off = (int32_t)off_chunk.size(); dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
@@ -586,7 +576,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // opt-in (VISFS_BA_FUSED=1): one CU's fp64 rate makes the fused kernel slower than the multi-kernel path per window
     // (DESIGN.md §4); it pays only when many small windows run side by side
     { const char* e = std::getenv("VISFS_BA_SMALL_SOLVE"); w.small_solve = small_solve_fits(dg) && !(e && e[0] == '0'); }
-    { const char* e = std::getenv("VISFS_BA_DIP"); w.g.sch_dip = (pcg1 && !pcg_cu && !w.small_solve && !(e && e[0] == '0')) ? 1 : 0; }
     { const char* e = std::getenv("VISFS_BA_FUSED"); w.fused = small_path_fits(dg) && e && e[0] == '1'; }
     // speculative linearise: a rejected trial wastes one linearisation, an accepted one saves k_decide + a launch gap — worth it
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
@@ -626,7 +615,7 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     { ProfScope p(w, VISFS_BA_K_SCHUR, true); launch_schur_partial(w.g, w.stream); }
     if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, h->prm.solver, w.stream); }
     else {
-        if (!w.g.sch_dip) { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
+        { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
         if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }

@@ -90,9 +90,6 @@ struct DeviceGraph {
     int32_t n_blk;          // stored S blocks (i <= j)
     int32_t n_sch;          // Schur chunks (<= sch_chunk co-observation pairs of one block each)
     int32_t sch_chunk;      // 64 x passes: pairs per chunk (a lane adds its pairs of the later passes serially)
-    int32_t sch_dip;        // 1: k_schur_partial finalises the diagonal blocks itself (first Npf workgroups), k_pcg1 sums the off-diagonal
-                            //    blocks of its row, k_schur_finalize is not launched (one-wave PCG path)
-    int32_t n_off;          // Schur chunks of off-diagonal blocks (entries of off_chunk)
     int32_t pcg_lds_minv;   // persistent PCG keeps all Minv blocks in LDS
     int32_t pcg_lds_srow;   // ... and its own block row of S
     int32_t pcg_max_row;    // longest block row of S (blocks)
@@ -139,8 +136,6 @@ struct DeviceGraph {
     int4* blk_pairs;            // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark, in landmark order
                                 // per block; built on the device at upload (k_build_pairs) from the pose-major observation lists
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block
-    const int32_t* diag_blk;    // [Npf] stored block id of (a, a)
-    const int32_t* off_chunk;   // [n_off] Schur chunk ids of the off-diagonal blocks, in block order
     const int4* sch_desc;       // [n_sch] (first pair, last pair + 1, pose index of i, pose index of j): ONE load gives a wave all it needs
     const int4* blk_desc;       // [n_blk][2]: (first Schur chunk, last + 1, first odometry entry, last + 1) — entries of blk_odo for an
                                 //   off-diagonal block, of pose_odo for a diagonal one — and (i, j, first pose-major chunk of i, last + 1)

@@ -859,47 +859,20 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     schur_chunk<MULTI>(g, L, ch, lane, lambda, pose, dsc, e < dsc.y ? g.blk_pairs[e] : make_int4(0, 0, 0, 0));
 }
 
-// Forward declaration: the finalisation of one stored block (defined with k_schur_finalize below).
-__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane);
-
-// DIP ("diagonal in partial", DeviceGraph::sch_dip): the first Npf workgroups each own ONE diagonal block of S — its chunks are shared
-// out over the four waves (same chunk arithmetic, same partials in sch_part), and after a workgroup barrier wave 0 finalises the block
-// on the spot (schur_block: S_aa, H_pp, b_p, b_s, the pin rule and Minv_a = S_aa^-1).  The diagonal blocks are what EVERY row of the
-// PCG needs (Minv and b_s of all rows); with them done here, the off-diagonal blocks of a row are summed by the PCG wavefront that owns
-// the row (k_pcg1 OFFSUM) and k_schur_finalize leaves the unit: one launch and one kernel boundary less per damped solve.
 template <bool MULTI, class Src>
 __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int bx = blockIdx.x;
-    if (g.sch_dip) {
-        if (bx < g.Npf) {
-            // ---- diagonal role (dispatched first: these workgroups carry the most pairs)
-            if (!(st->mode & MODE_TRIAL)) return;
-            const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
-            const int b = g.diag_blk[bx];
-            const int c0 = g.blk_chunk_ptr[b], c1 = g.blk_chunk_ptr[b + 1];
-            const double lambda = st->lambda;
-            const double* pose = g.pose[st->sel];
-            for (int ch = c0 + wave; ch < c1; ch += 4) schur_chunk<MULTI>(g, L, ch, lane, lambda, pose);
-            __syncthreads();                                  // the partials of this block: written by this workgroup, read back by its wave 0
-            if (wave == 0) schur_block(g, L, st, b, lane);
-            return;
-        }
-        bx -= g.Npf;
-    }
+    const LmState* st = g.st;
+    const int lane = threadIdx.x & 63;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
     // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
-    // instead of eight (speed only; any placement is correct).  The share of this window is a multiple of 8 workgroups.
-    const int n_ch = g.sch_dip ? g.n_off : g.n_sch;
-    const int nwg = (((n_ch + 3) / 4) + 7) / 8 * 8;           // this window's share of the launch
-    if (bx >= nwg) return;
+    // instead of eight (speed only; any placement is correct).  gridDim.x is a multiple of 8.
+    const int nwg = (((g.n_sch + 3) / 4) + 7) / 8 * 8;        // this window's share of the launch (== gridDim.x for a single window)
+    if ((int)blockIdx.x >= nwg) return;
     const int per_xcd = nwg >> 3;
-    const int wg = (bx & 7) * per_xcd + (bx >> 3);
-    const int slot = wg * 4 + wave;
-    if (slot >= n_ch) return;
-    const int ch = g.sch_dip ? g.off_chunk[slot] : slot;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int ch = wg * 4 + (threadIdx.x >> 6);
+    if (ch >= g.n_sch) return;
     // the chunk descriptor and the lane's first pair do not depend on the LM state: fetch them BEFORE the gate, so the gate's own
     // load (a cold L2 round trip at the head of every kernel) overlaps two levels of the index chain instead of preceding them
     const int4 dsc = g.sch_desc[ch];
@@ -1352,11 +1325,7 @@ struct ReduceScatterUp<N, 64> {
 // hardware — do the later iterations publish with PLAIN stores (kept in that XCD's L2, the coherence point of its CUs) and keep
 // reading with sc1 loads (past the L1, served by that L2): an L2 round trip instead of a fabric one per hand-off.  Otherwise they
 // stay on the write-through path.  Both paths move the same bits; the choice is identical in every wave (same gathered words).
-// OFFSUM (with DeviceGraph::sch_dip): the diagonal blocks, Minv and b_s were finalised by k_schur_partial's diagonal role; this
-// wave sums the chunk partials of the OFF-diagonal blocks of its own row itself — the arithmetic of schur_block, entry by entry in the
-// same order, so S is bit-identical to what k_schur_finalize would have stored (the untransposed owner still stores the block for the
-// stage hooks) — and no k_schur_finalize launch precedes it.
-template <class Src, int GV, bool OFFSUM = false>
+template <class Src, int GV>
 __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
@@ -1380,42 +1349,12 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
         const double2* Sb = reinterpret_cast<const double2*>(g.S + 36 * (size_t)(code >= 0 ? (code >> 1) : 0));
         const double2* Mb = reinterpret_cast<const double2*>(g.Minv + 36 * (size_t)(own ? lane : 0));
         double sv[36];
-        const bool from_mem = OFFSUM ? (code >= 0 && lane == i0) : (code >= 0);       // OFFSUM: only the diagonal block is stored already
 #pragma unroll
         for (int q = 0; q < 18; ++q) {
-            const double2 v = from_mem ? Sb[q] : make_double2(0.0, 0.0);
+            const double2 v = (code >= 0) ? Sb[q] : make_double2(0.0, 0.0);
             sv[2 * q] = v.x; sv[2 * q + 1] = v.y;
             const double2 m = own ? Mb[q] : make_double2(0.0, 0.0);
             mm[2 * q] = m.x; mm[2 * q + 1] = m.y;
-        }
-        if (OFFSUM && code >= 0 && lane != i0) {
-            // S_b = (odometry blocks of this pose pair) - sum of the block's chunk partials, every entry summed in chunk order
-            const int b = code >> 1;
-            const int4 bd = g.blk_desc[2 * b];           // (first chunk, last + 1, first odometry entry, last + 1)
-            const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
-#pragma unroll
-            for (int q = 0; q < 36; ++q) sv[q] = 0.0;
-            for (int ch = bd.x; ch < bd.y; ++ch) {
-                const double2* pp = reinterpret_cast<const double2*>(g.sch_part + 42 * (size_t)ch);
-#pragma unroll
-                for (int q = 0; q < 18; ++q) { const double2 v = pp[q]; sv[2 * q] += v.x; sv[2 * q + 1] += v.y; }
-            }
-            double base[36];
-#pragma unroll
-            for (int q = 0; q < 36; ++q) base[q] = 0.0;
-            for (int n = bd.z; n < bd.w; ++n) {
-                const int c2 = g.blk_odo[n];
-                const double* ob = L.odo_blk + 120 * (size_t)(c2 >> 1) + 72;
-#pragma unroll
-                for (int q = 0; q < 36; ++q) base[q] += ob[(c2 & 1) ? ((q % 6) * 6 + q / 6) : q];
-            }
-#pragma unroll
-            for (int q = 0; q < 36; ++q) sv[q] = base[q] - sv[q];
-            if (!(code & 1)) {                            // the stored orientation: keep S in HBM complete (stage hooks, direct fetch)
-                double2* So = reinterpret_cast<double2*>(g.S + 36 * (size_t)b);
-#pragma unroll
-                for (int q = 0; q < 18; ++q) So[q] = make_double2(sv[2 * q], sv[2 * q + 1]);
-            }
         }
         const bool tr = (code & 1) != 0;              // the stored block is (lane, i0): use its transpose
 #pragma unroll
@@ -2848,8 +2787,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.np = g.Np;
     d.lin_blocks = g.n_lin_a + g.n_chunks;
     d.backsub_blocks = g.n_lin_a + 1;
-    d.sch_wgs = g.sch_dip ? g.Npf + (((g.n_off + 3) / 4) + 7) / 8 * 8 : (g.n_sch > 0 ? (((g.n_sch + 3) / 4) + 7) / 8 * 8 : 0);
-    d.dip = g.sch_dip;
+    d.sch_wgs = g.n_sch > 0 ? (((g.n_sch + 3) / 4) + 7) / 8 * 8 : 0;
     d.sch_multi = g.sch_chunk > 64 ? 1 : 0;
     d.fin_wgs = (g.n_blk + 3) / 4;
     d.pcg_rows = g.Npf;
@@ -2869,7 +2807,6 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
     d.pcg_one_wave = a.pcg_one_wave & b.pcg_one_wave;
     d.pcg_cu = a.pcg_cu & b.pcg_cu;
-    d.dip = a.dip & b.dip;
     return d;
 }
 // dynamic LDS of the kernels that stage every pose of the window as R|t (12 doubles each); windows beyond MAX_STAGED_POSES use the
@@ -2937,11 +2874,12 @@ template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     if (d.pcg_cu) { TIMED_LAUNCH((k_pcg_cu<Src>), dim3(1, B), dim3(64 * ((6 * d.pcg_rows + CU_RPW - 1) / CU_RPW)), 0, s, src); return; }
     if (d.pcg_one_wave) {
-        // gather variants 0 / 2 / 3 (profiles/r02_pcg1_gather_variants.log, r02_pcg1_xcd_local_variant.log) stay selectable for
-        // measurements without OFFSUM; the default is variant 1 (six 16-byte write-through-coherent loads per sweep)
+        // default: variant 1 (six 16-byte loads per sweep, one sweep in flight) — 21.4 us per C2 solve and 65.6 k it/s in 16-window
+        // batches against 21.2-25.5 / 59.4 k for variant 0 and 20.9 / 61.6 k for variant 2 (profiles/r02_pcg1_gather_variants.log)
         static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 1; }();
-        if (d.dip) TIMED_LAUNCH((k_pcg1<Src, 1, true>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
-        else if (gv == 3 && LinSel<Src>::two_sets) TIMED_LAUNCH((k_pcg1<One, 3>), dim3(8 * d.pcg_rows, B), dim3(64), 0, s, One{ graph_of_host(src) });
+        // the XCD-local form only for a window on its own: its <= 64 one-wave workgroups are resident even if the dispatcher packs
+        // them all onto one XCD (that is the intent); a batch on one XCD would not be (co-residency must not depend on placement)
+        if (gv == 3 && LinSel<Src>::two_sets) TIMED_LAUNCH((k_pcg1<One, 3>), dim3(8 * d.pcg_rows, B), dim3(64), 0, s, One{ graph_of_host(src) });
         else if (gv >= 2) TIMED_LAUNCH((k_pcg1<Src, 2>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else if (gv == 1) TIMED_LAUNCH((k_pcg1<Src, 1>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else TIMED_LAUNCH((k_pcg1<Src, 0>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
@@ -3036,7 +2974,7 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
     if (first) launch_lin_finalize_src(src, 0, B, s);
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
-    else { if (!d.dip) launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
+    else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
     launch_backsub_src(src, d, B, 0, s);
     hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
 }
