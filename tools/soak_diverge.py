@@ -75,11 +75,15 @@ def step_case(olib, lib, seed, force_solver=None):
         def err(name, b):
             # the gradient vectors (b_l, b_p, b_s) go to ZERO at a minimum while their terms do not: measured against their own
             # current size a converged iteration would show pure cancellation noise as a large relative error, so they are
-            # measured against their size at the first iteration of the phase
+            # measured against the largest size they have had so far in this phase
             a, ref = s.fetch(b), o.fetch(b)
             if name in ("bl", "bp", "bs"):
-                scale0.setdefault(name, max(float(np.abs(ref).max()) if ref.size else 0.0, 1e-300))
-                return float(np.abs(a - ref).max() / scale0[name]) if ref.size else 0.0
+                if not ref.size:
+                    return 0.0
+                if not (np.isfinite(a).all() and np.isfinite(ref).all()):
+                    return float("inf")
+                scale0[name] = max(scale0.get(name, 1e-300), float(np.abs(ref).max()))
+                return float(np.abs(a - ref).max() / scale0[name])
             return rel_err(a, ref)
         for it in range(half):
             oc, omd = o.linearize(); gc, gmd = s.linearize()

@@ -39,9 +39,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise BackendError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("VISFS_BA_LIB", LIB_PATH)        # A/B measurement builds (tools/build_variant.sh); the default is the product library
+    if not os.path.exists(path):
+        raise BackendError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
     lib.visfs_ba_abi_version.restype = C.c_int
     lib.visfs_ba_default_params.argtypes = [C.POINTER(abi.Params)]
     lib.visfs_ba_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(C.c_void_p)]
