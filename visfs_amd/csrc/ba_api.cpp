@@ -456,7 +456,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         for (int k = 0; k < 2; ++k) {                       // the two linearisation sets: same layout, constant distance
             LinBuf& L = g.lin[k];
             L.obs_w = A.take<double>(std::max(No, 1));
-            L.obs_pcw = A.take<double>((size_t)std::max(No, 1) * TILE_REC);
+            L.obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
             L.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
             L.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
             L.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);

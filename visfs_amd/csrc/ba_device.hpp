@@ -17,10 +17,6 @@
 
 namespace visfs_ba {
 
-#ifndef VISFS_BA_TILE_N
-#define VISFS_BA_TILE_N 1
-#endif
-constexpr int TILE_REC = VISFS_BA_TILE_N ? 12 : 4;   // doubles per observation in LinBuf::obs_pcw
 constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
 constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
@@ -80,11 +76,7 @@ struct LmState {
 // on a trial is taken, the trial state is already being linearised into the other set ("speculative linearise").
 struct LinBuf {
     double* obs_w;              // [No]      rho' (0: inactive)
-    double* obs_pcw;            // [No][TILE_REC] tile record of an observation: the 3x3 core N = (rho' Omega A^T A) R of its H_pl tile
-                                //   W = [N ; [Pc]x N] (9; all zero when the edge has no tile) and Pc = R Pw + t (3).  Built once per linearisation;
-                                //   the Schur gather and the back-substitution read it instead of rebuilding N per use (a pair product
-                                //   spent 120 of its 430 fp64 instructions on the two tile_core calls).  VISFS_BA_TILE_N=0 (A/B builds):
-                                //   the 32-byte seed (Pc, rho' / sigma^2) of round 1, N rebuilt wherever it is consumed.
+    double* obs_pcw;            // [No][4]   tile seed: Pc = R Pw + t (3) and the effective weight rho' / sigma^2 (0: no Hpl tile)
     double* Hll;                // [Nl][6]
     double* bl;                 // [Nl][3]
     double* hpp_part;           // [n_chunks][27] 21 upper + 6 b

@@ -325,17 +325,10 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
             }
             if (pfree && lfree) wo_tile = wo;
         }
-        // the tile record (ba_device.hpp, LinBuf::obs_pcw): the 3x3 core N of the H_pl tile and Pc — or the 32-byte seed of round 1
-        double2* seed = reinterpret_cast<double2*>(L.obs_pcw + TILE_REC * (size_t)k);
-        if (VISFS_BA_TILE_N) {
-            double Nc[9];
-            tile_core(T.R, pc, wo_tile, K, Nc);
-            seed[0] = make_double2(Nc[0], Nc[1]); seed[1] = make_double2(Nc[2], Nc[3]); seed[2] = make_double2(Nc[4], Nc[5]);
-            seed[3] = make_double2(Nc[6], Nc[7]); seed[4] = make_double2(Nc[8], pc.x); seed[5] = make_double2(pc.y, pc.z);
-        } else {
-            seed[0] = make_double2(pc.x, pc.y);
-            seed[1] = make_double2(pc.z, wo_tile);
-        }
+        // the 32-byte tile seed (Hpl is rebuilt from it where it is consumed)
+        double2* seed = reinterpret_cast<double2*>(L.obs_pcw + 4 * (size_t)k);
+        seed[0] = make_double2(pc.x, pc.y);
+        seed[1] = make_double2(pc.z, wo_tile);
         if (g.debug) {
             double Wv[18];
             hpl_tile(T, pc, wo_tile, K, Wv);
@@ -759,30 +752,15 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
         for (int r = 0; r < 6; ++r) gb[r] = 0.0;
     }
     const double* H = L.Hll + 6 * (size_t)pr.z;
-    const double2* sa = reinterpret_cast<const double2*>(L.obs_pcw + TILE_REC * (size_t)pr.x);
-    const double2* sb = reinterpret_cast<const double2*>(L.obs_pcw + TILE_REC * (size_t)pr.y);
+    const double2* sa = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.x);
+    const double2* sb = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.y);
+    const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
+    const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
+    const Intrinsics K = intr_of(g);
+    const Vec3 pa{ a0.x, a0.y, a1.x }, pb{ b0.x, b0.y, b1.x };
     double Na[9], Nb[9];
-    Vec3 pa, pb;
-    if (VISFS_BA_TILE_N) {
-        // the records of the two observations: N (9) and Pc (3), six 16-byte loads each (a lane without a pair: zeros)
-        double ra[12], rb[12];
-        const double2 z2 = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { const double2 v = have ? sa[q] : z2; ra[2 * q] = v.x; ra[2 * q + 1] = v.y; }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { const double2 v = (have && !diag) ? sb[q] : make_double2(ra[2 * q], ra[2 * q + 1]); rb[2 * q] = v.x; rb[2 * q + 1] = v.y; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { Na[q] = ra[q]; Nb[q] = rb[q]; }
-        pa = Vec3{ ra[9], ra[10], ra[11] }; pb = Vec3{ rb[9], rb[10], rb[11] };
-        (void)Ti; (void)Tj;
-    } else {
-        const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
-        const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
-        const Intrinsics K = intr_of(g);
-        pa = Vec3{ a0.x, a0.y, a1.x }; pb = Vec3{ b0.x, b0.y, b1.x };
-        tile_core(Ti.R, pa, a1.y, K, Na);
-        tile_core(Tj.R, pb, b1.y, K, Nb);
-    }
+    tile_core(Ti.R, pa, a1.y, K, Na);
+    tile_core(Tj.R, pb, b1.y, K, Nb);
     double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
     if (have) {
         h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
@@ -1999,19 +1977,12 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
         const int ipk = g.obs_pose[k];
         const int a = g.pose_free[ipk];
         if (a < 0 || !lfree) continue;
-        const double2* seed = reinterpret_cast<const double2*>(L.obs_pcw + TILE_REC * (size_t)k);
+        const double2* seed = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)k);
+        const double2 s0 = seed[0], s1 = seed[1];
         // Hpl^T x through the tile structure W = [N ; [Pc]x N]:  W^T x = N^T (x_t - Pc x x_r)
-        Vec3 pcs;
+        const Vec3 pcs{ s0.x, s0.y, s1.x };
         double N[9];
-        if (VISFS_BA_TILE_N) {
-            const double2 r0 = seed[0], r1 = seed[1], r2 = seed[2], r3 = seed[3], r4 = seed[4], r5 = seed[5];
-            N[0] = r0.x; N[1] = r0.y; N[2] = r1.x; N[3] = r1.y; N[4] = r2.x; N[5] = r2.y; N[6] = r3.x; N[7] = r3.y; N[8] = r4.x;
-            pcs = Vec3{ r4.y, r5.x, r5.y };
-        } else {
-            const double2 s0 = seed[0], s1 = seed[1];
-            pcs = Vec3{ s0.x, s0.y, s1.x };
-            tile_core(P0.get(ipk).R, pcs, s1.y, K, N);
-        }
+        tile_core(P0.get(ipk).R, pcs, s1.y, K, N);
         const double* xp = g.x + 6 * (size_t)a;
         const double u0 = xp[0] - (pcs.y * xp[5] - pcs.z * xp[4]);
         const double u1 = xp[1] - (pcs.z * xp[3] - pcs.x * xp[5]);
