@@ -56,6 +56,7 @@ struct Workspace {
     hipGraphExec_t graph_exec = nullptr;
     int graph_units[2] = { -1, -1 };
     int solves_since_upload = 0;
+    bool upload_in_flight = false;                 // ws_upload no longer drains its stream: whoever uses the graph from ANOTHER stream must (batch_optimize)
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
     int64_t n_pairs = 0;
@@ -418,6 +419,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.pt_fixed = A.take<uint8_t>(std::max(Nl, 1));
         g.obs_pose = A.take<int32_t>(std::max(No, 1));
         g.obs_pt = A.take<int32_t>(std::max(No, 1));
+        g.obs_ppos = A.take<int32_t>(std::max(No, 1));
         g.obs_uvr = A.take<double>((size_t)std::max(No, 1) * 3);
         g.obs_ok = A.take<uint8_t>(std::max(No, 1));
         g.lm_ptr = A.take<int32_t>(Nl + 1);
@@ -457,6 +459,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
             LinBuf& L = g.lin[k];
             L.obs_w = A.take<double>(std::max(No, 1));
             L.obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
+            L.pose_pcw = A.take<double>(pose_obs.size() * 4);
             L.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
             L.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
             L.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
@@ -521,6 +524,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (No) {
             std::memcpy(const_cast<int32_t*>(hg.obs_pose), gr->obs_pose, (size_t)No * 4);
             std::memcpy(const_cast<int32_t*>(hg.obs_pt), gr->obs_point, (size_t)No * 4);
+            { int32_t* pp = const_cast<int32_t*>(hg.obs_ppos);
+              for (int k = 0; k < No; ++k) pp[k] = -1;
+              for (int t = 0; t < cnt[Npf]; ++t) pp[pose_obs[t]] = t; }
             std::memcpy(const_cast<double*>(hg.obs_uvr), gr->obs_uvr, (size_t)No * 24);
             std::memcpy(const_cast<uint8_t*>(hg.obs_ok), obs_ok.data(), No);
         }
@@ -594,6 +600,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // no synchronisation here: the launches that follow queue up behind the copy; the pinned staging arena is only reused by the
     // NEXT upload, which drains the stream first (see the top of this function)
     if (timing) { HIP_TRY(h, hipStreamSynchronize(w.stream)); lap("h2d+sync"); }
+    w.upload_in_flight = true;
     w.loaded = true;
     return VISFS_BA_OK;
 }
@@ -899,6 +906,11 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&bs.d_lm), (size_t)B * sizeof(LmState)));
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&bs.h_lm), (size_t)B * sizeof(LmState), hipHostMallocDefault));
         bs.cap_states = B;
+    }
+    // the members were uploaded on their own streams and the batch runs on `stream`: their copies and index kernels must be done
+    for (int b = 0; b < B; ++b) {
+        Workspace& w = *ws[members[b]];
+        if (w.upload_in_flight) { HIP_TRY(h, hipStreamSynchronize(w.stream)); w.upload_in_flight = false; }
     }
     std::vector<DeviceGraph>& hg = bs.host_graphs;
     hg.resize(B);
@@ -1216,6 +1228,8 @@ int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* c
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         h->n_batch = 0;
         for (int i = 0; i < n; ++i) { const int rc = ws_upload(h, *h->batch[i], graphs[i]); if (rc != VISFS_BA_OK) return rc; }
+        // the resident batch is reset and optimised on the handle's stream: drain the per-window upload streams once, here
+        for (int i = 0; i < n; ++i) { HIP_TRY(h, hipStreamSynchronize(h->batch[i]->stream)); h->batch[i]->upload_in_flight = false; }
         // every graph once more as one array: visfs_ba_batch_reset is then a single launch
         BatchScratch& bs = h->scratch;
         if (bs.cap_all < (size_t)n) {

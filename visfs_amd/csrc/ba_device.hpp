@@ -17,6 +17,9 @@
 
 namespace visfs_ba {
 
+#ifndef VISFS_BA_POSE_SEEDS
+#define VISFS_BA_POSE_SEEDS 1        // 0: A/B builds — the Schur gather reads the landmark-major seeds (round 1)
+#endif
 constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
 constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)
@@ -77,6 +80,10 @@ struct LmState {
 struct LinBuf {
     double* obs_w;              // [No]      rho' (0: inactive)
     double* obs_pcw;            // [No][4]   tile seed: Pc = R Pw + t (3) and the effective weight rho' / sigma^2 (0: no Hpl tile)
+    double* pose_pcw;           // [n_pose_obs][4] the same seeds once more in POSE-MAJOR order (position in DeviceGraph::pose_obs): the pairs of a
+                                //   Schur block (i, j) walk the landmarks common to poses i and j in ascending order, i.e. nearly consecutive
+                                //   entries of both poses' lists — the gather's four seed loads per pair become coalesced (landmark-major they
+                                //   hit 64 different cache lines per wave instruction; the kernel is bound by its loads, profiles/r02_tile_records_ab.log)
     double* Hll;                // [Nl][6]
     double* bl;                 // [Nl][3]
     double* hpp_part;           // [n_chunks][27] 21 upper + 6 b
@@ -117,6 +124,7 @@ struct DeviceGraph {
     const uint8_t* pt_fixed;    // [Nl]
     const int32_t* obs_pose;    // [No]
     const int32_t* obs_pt;      // [No]
+    const int32_t* obs_ppos;    // [No] position of the observation in pose_obs (pose-major order), -1 for observations of fixed poses
     const double* obs_uvr;      // [No][3]
     const uint8_t* obs_ok;      // [No] !(pose fixed && point fixed)
     const int32_t* lm_ptr;      // [Nl+1]
@@ -133,7 +141,7 @@ struct DeviceGraph {
     const int32_t* blk_j;       // [n_blk] (col), j >= i
     const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
     int32_t* pose_lm;           // [n_pose_obs] landmark of each entry of pose_obs (ascending within a pose); built on the device at upload
-    int4* blk_pairs;            // (tile of pose i, tile of pose j, landmark, 0): co-observations of one landmark, in landmark order
+    int4* blk_pairs;            // (tile of pose i, tile of pose j, landmark, 0) — tiles as pose-major positions: co-observations of one landmark, in landmark order
                                 // per block; built on the device at upload (k_build_pairs) from the pose-major observation lists
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block
     const int4* sch_desc;       // [n_sch] (first pair, last pair + 1, pose index of i, pose index of j): ONE load gives a wave all it needs
@@ -215,6 +223,7 @@ inline LinBuf lin_of(const DeviceGraph& g, int k) {
     LinBuf L;
     L.obs_w = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].obs_w) + off));
     L.obs_pcw = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].obs_pcw) + off));
+    L.pose_pcw = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].pose_pcw) + off));
     L.Hll = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].Hll) + off));
     L.bl = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].bl) + off));
     L.hpp_part = sgpr_ptr(reinterpret_cast<double*>(reinterpret_cast<char*>(g.lin[0].hpp_part) + off));

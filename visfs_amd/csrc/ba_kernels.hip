@@ -329,6 +329,14 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
         double2* seed = reinterpret_cast<double2*>(L.obs_pcw + 4 * (size_t)k);
         seed[0] = make_double2(pc.x, pc.y);
         seed[1] = make_double2(pc.z, wo_tile);
+        if (VISFS_BA_POSE_SEEDS) {
+            const int pp = g.obs_ppos[k];             // the pose-major copy the Schur gather reads (coalesced there)
+            if (pp >= 0) {
+                double2* ps = reinterpret_cast<double2*>(L.pose_pcw + 4 * (size_t)pp);
+                ps[0] = make_double2(pc.x, pc.y);
+                ps[1] = make_double2(pc.z, wo_tile);
+            }
+        }
         if (g.debug) {
             double Wv[18];
             hpl_tile(T, pc, wo_tile, K, Wv);
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
         for (int u = 0; u < U; ++u) {
             const int t = t0 + 64 * u + lane;
             cand[u] = false; k1[u] = 0; l[u] = 0; lo[u] = sB;
-            if (t < eA) { k1[u] = g.pose_obs[t]; l[u] = g.pose_lm[t]; cand[u] = !g.pt_fixed[l[u]]; }
+            if (t < eA) { k1[u] = VISFS_BA_POSE_SEEDS ? t : g.pose_obs[t]; l[u] = g.pose_lm[t]; cand[u] = !g.pt_fixed[l[u]]; }
         }
         // lower bound of l in pose j's landmark list, branch-free: lo ends at the first entry >= l
         if (i != j) {
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
         for (int u = 0; u < U; ++u) {
             bool m = cand[u];
             int k2 = k1[u];
-            if (i != j) { m = m && lo[u] < eB && g.pose_lm[lo[u]] == l[u]; if (m) k2 = g.pose_obs[lo[u]]; }
+            if (i != j) { m = m && lo[u] < eB && g.pose_lm[lo[u]] == l[u]; if (m) k2 = VISFS_BA_POSE_SEEDS ? lo[u] : g.pose_obs[lo[u]]; }
             const unsigned long long mask = __ballot(m);
             if (m) {
                 const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
@@ -752,8 +760,9 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
         for (int r = 0; r < 6; ++r) gb[r] = 0.0;
     }
     const double* H = L.Hll + 6 * (size_t)pr.z;
-    const double2* sa = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.x);
-    const double2* sb = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)pr.y);
+    const double* seeds = VISFS_BA_POSE_SEEDS ? L.pose_pcw : L.obs_pcw;            // pair tiles are pose-major positions / observation ids
+    const double2* sa = reinterpret_cast<const double2*>(seeds + 4 * (size_t)pr.x);
+    const double2* sb = reinterpret_cast<const double2*>(seeds + 4 * (size_t)pr.y);
     const double2 a0 = have ? sa[0] : make_double2(0.0, 0.0), a1 = have ? sa[1] : make_double2(1.0, 0.0);
     const double2 b0 = (have && !diag) ? sb[0] : a0, b1 = (have && !diag) ? sb[1] : a1;
     const Intrinsics K = intr_of(g);
