@@ -280,8 +280,13 @@ def pmc_traffic(config, kernel):
     if not files:
         return None
     try:
-        d = json.load(open(files[-1]))
-        return round(d[config][kernel]["traffic_bytes"])
+        d = json.load(open(files[-1]))[config]
+        # the PCG class is one of three kernels by window size (k_pcg1: <= 64 free poses, k_pcg beyond, k_pcg_cu opt-in)
+        names = [kernel] + (["k_pcg1", "k_pcg_cu"] if kernel == "k_pcg" else [])
+        for n in names:
+            if n in d:
+                return round(d[n]["traffic_bytes"])
+        return None
     except (KeyError, ValueError):
         return None
 
