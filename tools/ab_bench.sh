@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of the HIP library over the bench configurations (one gpurun call): tools/ab_bench.sh <tag> <variant-lib-name>
 # default = visfs_amd/lib/libvisfs_ba_hip.so, variant = visfs_amd/lib/libvisfs_ba_hip_<name>.so (tools/build_variant.sh).
-O=gpurun_out; TAG=$1; VAR=$2
+O=gpurun_out; TAG=$1; shift; VAR="$@"
 mkdir -p $O
 for V in default $VAR; do
   if [ $V != default ]; then export VISFS_BA_LIB=$PWD/visfs_amd/lib/libvisfs_ba_hip_$V.so; else unset VISFS_BA_LIB; fi

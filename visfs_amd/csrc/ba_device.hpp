@@ -20,6 +20,9 @@ namespace visfs_ba {
 #ifndef VISFS_BA_POSE_SEEDS
 #define VISFS_BA_POSE_SEEDS 1        // 0: A/B builds — the Schur gather reads the landmark-major seeds (round 1)
 #endif
+#ifndef VISFS_BA_RS_SWAP
+#define VISFS_BA_RS_SWAP 1           // 0: A/B builds — the reduce-scatters select send / keep and move one of them (round 1)
+#endif
 constexpr int LIN_CHUNK = 256;        // observations per pose-major workgroup
 constexpr int MAX_TRACE = 64;         // == VISFS_BA_MAX_TRACE
 constexpr int POSE_STRIDE = 8;        // doubles per pose in HBM (7 used; 64-byte rows)

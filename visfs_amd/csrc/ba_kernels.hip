@@ -107,6 +107,40 @@ __device__ __forceinline__ double fast_rsqrt(const double x) {
 // shuffles instead of N*log2(W).  At stage M a lane with bit M clear keeps the low half of its array and
 // receives its partner's low half; a lane with the bit set does the same with the high halves.  On return
 // a[j] holds the group sum of original element off + j for j < len (other slots are padding).
+// One exchange of the halving reduce-scatter for the partner lane ^ M:  (up ? hi : lo) + the partner's (up ? hi : lo), where
+// up = this lane has bit M set.  The textbook form selects send / keep (four v_cndmask per double) and moves `send` across;
+// across rows the gfx950 swaps do the selecting themselves — v_permlane32_swap (v_permlane16_swap) exchanges the upper half
+// (odd rows) of its first operand with the lower half (even rows) of its second, so after swap(lo, hi) a lower lane holds
+// {own lo, partner's lo} and an upper lane {partner's hi, own hi}: the sum of the two registers is the result in every lane, with
+// no select and no LDS crossbar trip.  Inside a row (M = 8, 4) two bank-masked DPP moves per word build the same two registers.
+// The two addends are the same as in the select form (IEEE addition commutes): results are bit-identical to it.
+template <int M>
+__device__ __forceinline__ double halves_exchange_sum(const double lo, const double hi, const bool up) {
+    if constexpr (VISFS_BA_RS_SWAP && (M == 32 || M == 16)) {
+        v2u_t w0, w1;
+        if constexpr (M == 32) {
+            w0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(lo), (unsigned)__double2loint(hi), false, false);
+            w1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(lo), (unsigned)__double2hiint(hi), false, false);
+        } else {
+            w0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(lo), (unsigned)__double2loint(hi), false, false);
+            w1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(lo), (unsigned)__double2hiint(hi), false, false);
+        }
+        return __hiloint2double((int)w1.x, (int)w0.x) + __hiloint2double((int)w1.y, (int)w0.y);
+    } else if constexpr (VISFS_BA_RS_SWAP && (M == 8 || M == 4)) {
+        // X: upper lanes take the partner's hi, lower lanes keep their lo;  Y: lower lanes take the partner's lo, upper keep their hi
+        constexpr int UP_CTRL = (M == 8) ? 0x128 : 0x124, LO_CTRL = (M == 8) ? 0x128 : 0x12C;     // row_ror:8 | row_ror:4 / row_ror:12
+        constexpr int UP_BANKS = (M == 8) ? 0xC : 0xA, LO_BANKS = (M == 8) ? 0x3 : 0x5;
+        const unsigned l0 = (unsigned)__double2loint(lo), l1 = (unsigned)__double2hiint(lo), h0 = (unsigned)__double2loint(hi), h1 = (unsigned)__double2hiint(hi);
+        const unsigned x0 = __builtin_amdgcn_update_dpp(l0, h0, UP_CTRL, 0xF, UP_BANKS, false), x1 = __builtin_amdgcn_update_dpp(l1, h1, UP_CTRL, 0xF, UP_BANKS, false);
+        const unsigned y0 = __builtin_amdgcn_update_dpp(h0, l0, LO_CTRL, 0xF, LO_BANKS, false), y1 = __builtin_amdgcn_update_dpp(h1, l1, LO_CTRL, 0xF, LO_BANKS, false);
+        return __hiloint2double((int)x1, (int)x0) + __hiloint2double((int)y1, (int)y0);
+    } else {
+        const double send = up ? lo : hi;
+        const double keep = up ? hi : lo;
+        return keep + xor_lane<M>(send);
+    }
+}
+
 template <int N, int M>
 struct ReduceScatter {
     static __device__ __forceinline__ void run(double* a, int lane, int& off, int& len) {
@@ -116,9 +150,7 @@ struct ReduceScatter {
         for (int j = 0; j < H; ++j) {
             const double lo = a[j];
             const double hi = (j + H < N) ? a[j + H] : 0.0;
-            const double send = up ? lo : hi;
-            const double keep = up ? hi : lo;
-            a[j] = keep + xor_lane<M>(send);
+            a[j] = halves_exchange_sum<M>(lo, hi, up);
         }
         if (up) { off += H; len = len > H ? len - H : 0; } else { len = len < H ? len : H; }
         ReduceScatter<H, M / 2>::run(a, lane, off, len);
@@ -659,7 +691,7 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
     if (!(st->mode & MODE_LIN)) return;
     if (!force && st->phase_iter != 0) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
-    __shared__ double red[1024];
+    __shared__ double red[32];
     const int tid = threadIdx.x;
     double md = 0.0;
     for (int t = tid; t < g.Npf * 42; t += 1024) {
@@ -671,16 +703,16 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
     double chi = 0.0;
     const int nparts = g.n_lin_a + 1;
     for (int w = tid; w < nparts; w += 1024) { chi += g.lin_part[2 * w]; md = fmax(md, g.lin_part[2 * w + 1]); }
-    red[tid] = chi;
+    // two workgroup reductions through the wave butterflies and 16 per-wave partials each (fixed order): ONE barrier instead of the
+    // twenty of two log-step LDS trees
+    const double wchi = wave_sum(chi), wmd = wave_max(md);
+    if ((tid & 63) == 0) { red[tid >> 6] = wchi; red[16 + (tid >> 6)] = wmd; }
     __syncthreads();
-    for (int s = 512; s >= 1; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    const double chi_total = red[0];
-    __syncthreads();
-    red[tid] = md;
-    __syncthreads();
-    for (int s = 512; s >= 1; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
-    const double md_total = red[0];
-    if (tid == 0) lin_finalize_update(st, chi_total, md_total);
+    if (tid == 0) {
+        double chi_total = red[0], md_total = red[16];
+        for (int w = 1; w < 16; ++w) { chi_total += red[w]; md_total = fmax(md_total, red[16 + w]); }
+        lin_finalize_update(st, chi_total, md_total);
+    }
 }
 
 // ================================================================= upload: co-observation pair lists of the S blocks
@@ -918,20 +950,21 @@ __device__ __forceinline__ double gauss_jordan_6x6(const double val, const int l
 }
 
 // One wavefront, one stored block of S: shared by k_schur_finalize and the fused small-window kernel.
-__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
+// (bd, be = blk_desc[2 b], blk_desc[2 b + 1] come from the caller: they do not depend on the LM state, so a kernel can have them in
+// flight while its gate is still being read)
+__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be) {
     {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
         const int nwords = 4 * 6 * g.Npf + g.Npf;           // q granules of both parities + one placement word per block row
         for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
     }
     const double lambda = st->lambda;
-    const int4 bd = g.blk_desc[2 * b];           // (first chunk, last + 1, first odometry entry, last + 1)
-    const int4 be = g.blk_desc[2 * b + 1];       // (i, j, first pose-major chunk of i, last + 1)
     const int i = be.x, j = be.y;
     const bool diag = (i == j);
     const int r = lane / 6, c = lane % 6;    // meaningful for lane < 36
     double part = 0.0;
     if (lane < 42) {
-#pragma unroll 4
+        // (eight chunk partials in flight per round: a diagonal block of C2 has eight 128-pair chunks; the adds stay in chunk order)
+#pragma unroll 8
         for (int ch = bd.x; ch < bd.y; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
     }
     if (!diag) {
@@ -967,16 +1000,22 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     }
 }
 
+__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
+    schur_block(g, L, st, b, lane, g.blk_desc[2 * b], g.blk_desc[2 * b + 1]);     // (first chunk, last + 1, first odometry entry, last + 1), (i, j, first pose-major chunk of i, last + 1)
+}
+
 template <class Src>
 __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
-    if (!(st->mode & MODE_TRIAL)) return;
-    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= g.n_blk) return;
-    schur_block(g, L, st, b, lane);
+    // the block descriptors first, the gate after: one cold-L2 round trip instead of two at the head of the kernel
+    const int4 bd = g.blk_desc[2 * b], be = g.blk_desc[2 * b + 1];
+    if (!(st->mode & MODE_TRIAL)) return;
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
+    schur_block(g, L, st, b, lane, bd, be);
 }
 
 // ================================================================= K6: block-Jacobi PCG on S, persistent
@@ -1312,9 +1351,7 @@ struct ReduceScatterUp {
         for (int j = 0; j < H; ++j) {
             const double lo = a[j];
             const double hi = (j + H < N) ? a[j + H] : 0.0;
-            const double send = up ? lo : hi;
-            const double keep = up ? hi : lo;
-            a[j] = keep + xor_lane<M>(send);
+            a[j] = halves_exchange_sum<M>(lo, hi, up);
         }
         if (up) { off += H; len = len > H ? len - H : 0; } else { len = len < H ? len : H; }
         ReduceScatterUp<H, M * 2>::run(a, lane, off, len);
