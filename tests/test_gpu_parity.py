@@ -579,6 +579,38 @@ def test_speculative_unit_equals_gated_unit(olib, monkeypatch, case):
         assert sum(st0.trials_run) > sum(st0.iterations_run)          # the window really rejects trials
 
 
+@pytest.mark.parametrize("case", ["C1", "LASER", "HARD", "GN", "C3"])
+def test_decision_on_board_backsub_equals_separate_decide_launch(olib, monkeypatch, case):
+    """The gated unit (batched windows, large windows, VISFS_BA_SPEC=0): one workgroup of k_backsub waits for the partial sums of all
+    the others (hand-off words, the data is the flag) and takes the LM decision; round 1 launched k_decide for it.  Same sums in
+    the same order: every output, counter and trace entry must be bit-identical, rejected trials and failed solves included."""
+    kw = dict(iterations=20, solver=2)
+    if case == "LASER":
+        w = synth.make_laser_window(with_visual=True, n_points=400)
+    elif case == "HARD":
+        w = hard_window()
+    elif case == "GN":
+        w = synth.make_window("C1"); kw["trust_region"] = 1
+    else:
+        w = synth.make_window(case)
+    _, rc0, st0, out0 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="0", VISFS_BA_DECIDE_FUSED="0"), **kw)
+    _, rc1, st1, out1 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="0", VISFS_BA_DECIDE_FUSED="1"), **kw)
+    assert rc0 == rc1 == abi.OK
+    assert _stats_tuple(st0) == _stats_tuple(st1)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out0, out1))
+    # twice on the same resident graph: the launch tags keep counting across solves (stale hand-off words never match)
+    from visfs_amd import backend
+    prm = abi.default_params(**kw)
+    s = backend.Solver(prm)
+    gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s.upload(gb)
+    for _ in range(3):
+        s.reset(); rc, st = s.optimize()
+        assert rc == abi.OK and _stats_tuple(st) == _stats_tuple(st0)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(s.download(), out0))
+    s.close()
+
+
 def test_schur_chunk_passes_agree_to_rounding(olib, monkeypatch):
     # 64 / 128 / 192 pairs per chunk: same sums in a different association
     w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11)

@@ -30,7 +30,8 @@ template <int M> __device__ void check_halves(unsigned* out, int slot) {
     const int lane = threadIdx.x;
     const unsigned lo = 1000u + 7u * lane, hi = 500000u + 11u * lane;
     const bool up = (lane & M) != 0;
-    const unsigned want = (up ? hi : lo) + __shfl_xor(up ? hi : lo, M, 64);
+    const unsigned plo = __shfl_xor(lo, M, 64), phi = __shfl_xor(hi, M, 64);
+    const unsigned want = up ? hi + phi : lo + plo;
     unsigned x, y;
     if constexpr (M == 32) { v2u r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false); x = r.x; y = r.y; }
     else if constexpr (M == 16) { v2u r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false); x = r.x; y = r.y; }

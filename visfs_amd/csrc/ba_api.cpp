@@ -50,6 +50,7 @@ struct Workspace {
     bool batch_member = false;                     // one of visfs_ba_solve_batch / visfs_ba_batch_upload's windows (shares its launches)
     bool fused = false;                            // the resident window runs on k_small_optimize
     bool spec = false;                             // units end with the speculative linearisation + LM decision launch
+    bool fused_decide = true;                      // gated units: k_backsub carries the LM decision (VISFS_BA_DECIDE_FUSED=0: k_decide, A/B runs and tests)
     int extra_units[2] = { 0, 0 };                 // rejected trials per phase of the previous solve: units enqueued on top of `half`
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
     // VISFS_BA_GRAPH=1 (measurement): the up-front launch sequence of a solve captured once per resident graph and replayed
@@ -485,6 +486,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.granules = A.take<unsigned long long>(std::max<size_t>(4 * n6 + Npf, 1));        // + one placement word per block row (k_pcg1)
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
+        g.trial_gran = A.take<unsigned long long>((size_t)n_parts * 4);
         g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
         g.chol_f = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
         g.chol_y = A.take<double>(chol_np);
@@ -587,6 +589,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
     // members keep the gated form.
     { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (!w.batch_member && No <= 150000)) && Np <= MAX_STAGED_POSES; }
+    { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = !(e && e[0] == '0'); }
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
@@ -626,9 +629,13 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
         if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }
-    { ProfScope p(w, VISFS_BA_K_BACKSUB, true); if (w.spec && (w.g.Ne > 0 || w.g.Nz > 0)) launch_backsub_odospec(w.g, w.stream); else launch_backsub(w.g, w.stream); }
+    const bool fused_decide = w.fused_decide;     // the gated unit: the LM decision rides on k_backsub
+    {   ProfScope p(w, VISFS_BA_K_BACKSUB, true);
+        if (w.spec && (w.g.Ne > 0 || w.g.Nz > 0)) launch_backsub_odospec(w.g, w.stream);
+        else if (!w.spec && fused_decide) launch_backsub_decide(w.g, w.stream);
+        else launch_backsub(w.g, w.stream); }
     if (w.spec) { ProfScope p(w, VISFS_BA_K_LINEARIZE, true); launch_linearize_decide(w.g, w.stream); }
-    else { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
+    else if (!fused_decide) { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
 }
 
 void fill_stats(const LmState& st, visfs_ba_stats* out) {
@@ -734,7 +741,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
         rc = ws_read_state(h, w);
         if (rc != VISFS_BA_OK) return rc;
         const LmState& st = *w.h_state;
-        if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
+        if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "a device-side hand-off (persistent PCG / LM decision) timed out"; return VISFS_BA_ERR_DEVICE; }
         if (st.ended >= 2 || st.status != 0) break;                                                // finished, or aborted by a chi2 guard
         if (guard > 16 * h->prm.iterations + 32) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
         if (!st.done) {
@@ -752,7 +759,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
         w.active[VISFS_BA_K_LINEARIZE] += w.spec ? st.n_active[3] + (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0) : st.n_active[0];
         w.active[VISFS_BA_K_LIN_FINALIZE] += (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0);
         w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_SCHUR_FINALIZE] += st.n_active[1];
-        if (!w.spec) w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
+        if (!w.spec && !w.fused_decide) w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
         w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT] += st.n_active[1];
         w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
         w.active[VISFS_BA_K_PHASE_END] += 2; w.active[VISFS_BA_K_RESET] += 1;
@@ -915,12 +922,12 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     std::vector<DeviceGraph>& hg = bs.host_graphs;
     hg.resize(B);
     LaunchDims d = dims_of(ws[members[0]]->g);
-    bool fused = true, small_solve = true;
+    bool fused = true, small_solve = true, fused_decide = true;
     for (int b = 0; b < B; ++b) {
         const Workspace& w = *ws[members[b]];
         hg[b] = w.g;
         d = dims_max(d, dims_of(w.g));
-        fused = fused && w.fused; small_solve = small_solve && w.small_solve;
+        fused = fused && w.fused; small_solve = small_solve && w.small_solve; fused_decide = fused_decide && w.fused_decide;
     }
     std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
     if (!fused && !small_solve && !d.pcg_cu) pcg_lock.lock();                       // persistent PCG: one grid at a time per device
@@ -934,7 +941,7 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     // come back in ONE copy; windows that rejected trials are topped up from what comes back.  Every launch is gated per window,
     // so the same sequence is safe for windows at different points of the schedule.
     const int half2 = (h->prm.robust_kernel_delta > 0.0) ? half : 0;                                // :310-311
-    auto units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, stream); first = false; } };
+    auto units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, fused_decide, stream); first = false; } };
     auto phase_end = [&](int which) {
         if (which == 0) launch_phase_end_batch(bs.d_graphs, B, d, 0, 1, half2, stream);             // :270-303
         else launch_phase_end_batch(bs.d_graphs, B, d, 1, 0, 0, stream);                            // :315-318
@@ -950,7 +957,7 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         int top_up = 0;
         for (int b = 0; b < B; ++b) {
             const LmState& st = bs.h_lm[b];
-            if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "persistent PCG hand-off timed out"; return VISFS_BA_ERR_DEVICE; }
+            if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "a device-side hand-off (persistent PCG / LM decision) timed out"; return VISFS_BA_ERR_DEVICE; }
             if (st.ended >= 2 || st.status != 0) continue;
             all_finished = false;
             if (!st.done) top_up = std::max(top_up, std::max(1, st.max_iter - st.phase_iter));

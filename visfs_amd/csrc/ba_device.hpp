@@ -76,6 +76,8 @@ struct LmState {
     int32_t ended;          // phase ends applied so far (0, 1, 2): k_eval / k_phase_end act only when the phase they close is done
     int32_t pcg_phase1;     // pcg_total when phase 1 ended
     int32_t n_edges_ok;     // stereo edges that can ever be active (not both ends fixed): the active set of phase 1
+    uint32_t decide_epoch;  // tag of the last k_backsub launch that carried the LM decision; never reset (k_reset leaves it): stale
+                            // hand-off words of an earlier launch or solve can then never match the tag a launch waits for
 };
 
 // The outputs of a linearisation that the Schur complement and the back-substitution consume.  Two sets: while the LM decision
@@ -185,6 +187,7 @@ struct DeviceGraph {
     unsigned long long* granules; // [2][2*6Npf] {epoch:32 | half of a double:32} hand-off words of the persistent PCG
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
+    unsigned long long* trial_gran; // [n_lin_a + 1][4] the same two sums as {epoch:32 | half:32} hand-off words (k_backsub with the LM decision on board)
     double* chol_f;             // [chol_np][chol_np] the Cholesky factor L (direct solver), separate from the matrix being updated
     double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)
     double* chol_y;             // [chol_np]

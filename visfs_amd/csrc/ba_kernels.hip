@@ -474,6 +474,47 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
     lm_decide(st, ok, lambda, chi, sc, spec);
 }
 
+// The decision on board k_backsub (DEC): the trial's partial sums travel as hand-off words {tag:32 | half of a double:32}, written
+// with write-through stores and polled with sc1 loads — the data is the flag (cdna_hip_programming.md §6 Guideline 16, form R2,
+// as in the persistent PCG), so no fence and no second launch separate the last partial from the decision.  tag = the launch's
+// number in LmState::decide_epoch, which only the deciding workgroup advances, at the very end.
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p);
+__device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v);
+__device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w, const unsigned ep, const double chi, const double sc) {
+    unsigned long long* o = g.trial_gran + 4 * (size_t)w;
+    const unsigned long long e = (unsigned long long)ep << 32;
+    st_granule(o, e | (unsigned)__double2loint(chi)); st_granule(o + 1, e | (unsigned)__double2hiint(chi));
+    st_granule(o + 2, e | (unsigned)__double2loint(sc)); st_granule(o + 3, e | (unsigned)__double2hiint(sc));
+}
+// One workgroup (256 threads): wait for the partials of every other workgroup of this launch, add them in decide_role's order and
+// step the LM state machine.  It touches LmState only after every workgroup has published, i.e. after every workgroup has read
+// its gate and its lambda / sel.  A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
+__device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, double* red) {
+    const int tid = threadIdx.x;
+    const double lambda = st->lambda;
+    double chi = 0.0, sc = 0.0;
+    int bad = 0;
+    for (int w = tid; w < g.n_lin_a + 1; w += 256) {
+        const unsigned long long* p = g.trial_gran + 4 * (size_t)w;
+        unsigned long long a = 0, b = 0, c = 0, d = 0;
+        for (int spin = 0;; ++spin) {
+            a = ld_granule(p); b = ld_granule(p + 1); c = ld_granule(p + 2); d = ld_granule(p + 3);
+            if ((unsigned)(a >> 32) == ep && (unsigned)(b >> 32) == ep && (unsigned)(c >> 32) == ep && (unsigned)(d >> 32) == ep) break;
+            if (spin > (1 << 21)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (ok) { chi += __hiloint2double((int)(unsigned)b, (int)(unsigned)a); sc += __hiloint2double((int)(unsigned)d, (int)(unsigned)c); }
+    }
+    if (ok) for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
+    chi = block_sum_256(chi, red);
+    sc = block_sum_256(sc, red);
+    bad = __syncthreads_or(bad);
+    if (tid != 0) return;
+    if (bad) st->pcg_timeout = 1;
+    lm_decide(st, ok && !bad, lambda, chi, sc, false);
+    st->decide_epoch = ep;
+}
+
 // ================================================================= K1/K2/K4: linearise the stereo edges
 // spec = 0: linearise the committed estimate (first unit of a phase, stage hooks, large windows) when the gate says so.
 // spec = 1 ("speculative linearise", the last launch of a unit): the trial state that k_backsub has just completed is
@@ -963,8 +1004,8 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     const int r = lane / 6, c = lane % 6;    // meaningful for lane < 36
     double part = 0.0;
     if (lane < 42) {
-        // (eight chunk partials in flight per round: a diagonal block of C2 has eight 128-pair chunks; the adds stay in chunk order)
-#pragma unroll 8
+        // (unroll 8 measured slower than 4: a C2 block has ~5 two-pass chunks, most of them would run in the remainder loop)
+#pragma unroll 4
         for (int ch = bd.x; ch < bd.y; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
     }
     if (!diag) {
@@ -2075,15 +2116,26 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // also linearises them there, into the set the speculative k_linearize is about to fill — k_odo_linearize (6.6 us, one
 // workgroup) leaves the unit.  The role is register-hungry (224 VGPRs), so this instantiation runs at two waves per SIMD: it is
 // used only where k_backsub is a single round of waves anyway (the speculative unit's size limit).
-template <int G, class Src, bool ODOSPEC, bool STG = true>
+// DEC (the gated unit: batched windows, large windows, Optimizer without the speculative unit): workgroup n_lin_a + 1 of the launch
+// takes the LM decision on the trial (decide_gather_role) — k_decide (6.3 us + a launch gap per unit) leaves the sequence.
+template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false>
 __global__ __launch_bounds__(256) void k_backsub(const Src src) {
+    static_assert(!(DEC && ODOSPEC), "the decision rides on the gated unit only");
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
-    const bool go = (st->mode & MODE_TRIAL) && !st->solver_failed && !st->pcg_timeout;
-    // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
-    if (LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
-    if (!go) return;
+    const bool trial = (st->mode & MODE_TRIAL) != 0;
+    const bool go = trial && !st->solver_failed && !st->pcg_timeout;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    unsigned ep = 0;
+    if (DEC) {
+        ep = st->decide_epoch + 1u;
+        if ((int)blockIdx.x == g.n_lin_a + 1) { if (trial) decide_gather_role(g, st, ep, go, smem); return; }
+        // a failed solve: nothing to compute, but the deciding workgroup must not change the gate before every workgroup has read it
+        if (trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, ep, 0.0, 0.0);
+    }
+    // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
+    if (!DEC && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
+    if (!go) return;
     double* sRt = smem;
     double* red = smem + (STG ? 12 * g.Np : 0);
     const int sel = st->sel, ls = st->lin_sel;
@@ -2112,7 +2164,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
             chi_acc += e * (g.inv_laser_cov * e);
         }
         const double chi_tot = block_sum_256(chi_acc, red);
-        if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; }
+        if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, 0.0); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; } }
         if (ODOSPEC) {
             __syncthreads();
             const LinSel<Src> lspec(g, ls ^ 1);                      // == spec_dst of the snapshot above
@@ -2135,7 +2187,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
-    if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; }
+    if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
 }
 
 // ================================================================= K9: Levenberg-Marquardt control (lm_decide / decide_role: above k_linearize)
@@ -2874,16 +2926,22 @@ static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, h
     if (LinSel<Src>::two_sets && spec) { ensure_lds(k_linearize<G, Src, LinSel<Src>::two_sets>, lds); TIMED_LAUNCH((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds, s, src); }
     else { ensure_lds(k_linearize<G, Src, false>, lds); TIMED_LAUNCH((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds, s, src); }
 }
+// dec: the launch carries the LM decision (one workgroup more; k_decide is then not launched)
 template <int G, class Src>
-static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odospec, hipStream_t s) {
+static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odospec, int dec, hipStream_t s) {
     if (!staged(d)) {
-        TIMED_LAUNCH((k_backsub<G, One, false, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
+        if (dec) TIMED_LAUNCH((k_backsub<G, One, false, false, true>), dim3(d.backsub_blocks + 1, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
+        else TIMED_LAUNCH((k_backsub<G, One, false, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
         return;
     }
     if (LinSel<Src>::two_sets && odospec) {
         const size_t lds = (size_t)std::max(24 * d.np + 8, 128) * sizeof(double);
         ensure_lds(k_backsub<G, Src, LinSel<Src>::two_sets>, lds);
         TIMED_LAUNCH((k_backsub<G, Src, LinSel<Src>::two_sets>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
+    } else if (dec) {
+        const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
+        ensure_lds(k_backsub<G, Src, false, true, true>, lds);
+        TIMED_LAUNCH((k_backsub<G, Src, false, true, true>), dim3(d.backsub_blocks + 1, B), dim3(256), lds, s, src);
     } else {
         const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
         ensure_lds(k_backsub<G, Src, false>, lds);
@@ -2941,13 +2999,13 @@ static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream
     }
 }
 template <class Src>
-static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, int odospec, hipStream_t s) {
+static void launch_backsub_src(const Src& src, const LaunchDims& d, int B, int odospec, int dec, hipStream_t s) {
     switch (d.group) {
-        case 4: launch_backsub_t<4>(src, d, B, odospec, s); break;
-        case 8: launch_backsub_t<8>(src, d, B, odospec, s); break;
-        case 16: launch_backsub_t<16>(src, d, B, odospec, s); break;
-        case 32: launch_backsub_t<32>(src, d, B, odospec, s); break;
-        default: launch_backsub_t<64>(src, d, B, odospec, s); break;
+        case 4: launch_backsub_t<4>(src, d, B, odospec, dec, s); break;
+        case 8: launch_backsub_t<8>(src, d, B, odospec, dec, s); break;
+        case 16: launch_backsub_t<16>(src, d, B, odospec, dec, s); break;
+        case 32: launch_backsub_t<32>(src, d, B, odospec, dec, s); break;
+        default: launch_backsub_t<64>(src, d, B, odospec, dec, s); break;
     }
 }
 template <class Src>
@@ -2969,8 +3027,9 @@ void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) { launc
 void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_src(One{ g }, dims_of(g), 1, s); }
 void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) { launch_schur_finalize_src(One{ g }, dims_of(g), 1, s); }
 void launch_pcg(const DeviceGraph& g, hipStream_t s) { launch_pcg_src(One{ g }, dims_of(g), 1, s); }
-void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 0, s); }
-void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 1, s); }
+void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 0, 0, s); }
+void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 1, 0, s); }
+void launch_backsub_decide(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 0, 1, s); }
 void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
     launch_phase_end_src(One{ g }, dims_of(g), 1, phase_just_done, mark, next_max_iter, s);
@@ -3014,15 +3073,16 @@ void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int m
     hipLaunchKernelGGL((k_reset<Many>), dim3(d.reset_blocks, B), dim3(256), 0, s, Many{ gs }, max_iter, gauss_newton, restore);
 }
 // One unit of the LM state machine for every window of the batch (PCG or, for reduced systems <= 64 x 64, k_small_solve).
-void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s) {
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, hipStream_t s) {
     const Many src{ gs };
     launch_linearize_src(src, d, B, 0, s);             // batched windows keep the gated unit (LinSel<Many>: set 0 only)
     if (first) launch_lin_finalize_src(src, 0, B, s);
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
     else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
-    launch_backsub_src(src, d, B, 0, s);
-    hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
+    // the LM decision rides on k_backsub (fused_decide = false: the separate k_decide launch of round 1, for A/B runs)
+    launch_backsub_src(src, d, B, 0, fused_decide ? 1 : 0, s);
+    if (!fused_decide) hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
 }
 void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
     launch_phase_end_src(Many{ gs }, d, B, phase_just_done, mark, next_max_iter, s);

@@ -28,6 +28,7 @@ void launch_pcg(const DeviceGraph& g, hipStream_t s);                // persiste
 void launch_direct(const DeviceGraph& g, hipStream_t s);             // dense assemble + Cholesky
 void launch_backsub(const DeviceGraph& g, hipStream_t s);
 void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s);   // speculative unit with odometry / laser edges: also linearises them at the trial poses
+void launch_backsub_decide(const DeviceGraph& g, hipStream_t s);    // gated unit: the launch also takes the LM decision (no k_decide)
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
 bool pcg_cu_fits(int npf, int max_row);                               // the reduced system fits the single-workgroup PCG (k_pcg_cu)
@@ -37,7 +38,7 @@ bool small_path_fits(const DeviceGraph& g);                          // the wind
 void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s);   // both phases + outlier pass in one launch
 // batches of independent windows: gs = B DeviceGraphs in HBM, blockIdx.y = window
 void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int max_iter, int gauss_newton, int restore, hipStream_t s);
-void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, hipStream_t s);
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, hipStream_t s);
 void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s);
