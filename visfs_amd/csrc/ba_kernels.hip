@@ -474,10 +474,12 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
     lm_decide(st, ok, lambda, chi, sc, spec);
 }
 
-// The decision on board k_backsub (DEC): the trial's partial sums travel as hand-off words {tag:32 | half of a double:32}, written
-// with write-through stores and polled with sc1 loads — the data is the flag (cdna_hip_programming.md §6 Guideline 16, form R2,
-// as in the persistent PCG), so no fence and no second launch separate the last partial from the decision.  tag = the launch's
-// number in LmState::decide_epoch, which only the deciding workgroup advances, at the very end.
+// The decision on board k_backsub (DEC): every workgroup publishes its two partial sums as hand-off words {tag:32 | half of a
+// double:32} with write-through stores and then counts itself in (one relaxed atomic add); the workgroup that arrives LAST takes the
+// decision.  It reads the words with sc1 loads and checks their tags — the data is the flag (cdna_hip_programming.md §6 Guideline
+// 16, form R2, as in the persistent PCG): the counter only ELECTS the decider, no ordering between the stores and the atomic is
+// relied on, and no fence or second launch separates the last partial from the decision.  tag = the launch's number in
+// LmState::decide_epoch, which only the decider advances, at the very end (it also clears the counter for the next launch).
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p);
 __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v);
 __device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w, const unsigned ep, const double chi, const double sc) {
@@ -486,24 +488,37 @@ __device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w,
     st_granule(o, e | (unsigned)__double2loint(chi)); st_granule(o + 1, e | (unsigned)__double2hiint(chi));
     st_granule(o + 2, e | (unsigned)__double2loint(sc)); st_granule(o + 3, e | (unsigned)__double2hiint(sc));
 }
-// One workgroup (256 threads): wait for the partials of every other workgroup of this launch, add them in decide_role's order and
-// step the LM state machine.  It touches LmState only after every workgroup has published, i.e. after every workgroup has read
-// its gate and its lambda / sel.  A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
+// The deciding workgroup (256 threads): fetch the partials of every workgroup of this launch — eight workgroups' words in flight per
+// thread, a word whose tag is not there yet is polled — add them in decide_role's order and step the LM state machine.  LmState is
+// written only here, after every workgroup has arrived, i.e. after every workgroup has read its gate and its lambda / sel.
+// A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
 __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, double* red) {
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const double lambda = st->lambda;
+    const int n = g.n_lin_a + 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.trial_gran, 0, (int)(n * 32), 0x00020000);
     double chi = 0.0, sc = 0.0;
     int bad = 0;
-    for (int w = tid; w < g.n_lin_a + 1; w += 256) {
-        const unsigned long long* p = g.trial_gran + 4 * (size_t)w;
-        unsigned long long a = 0, b = 0, c = 0, d = 0;
-        for (int spin = 0;; ++spin) {
-            a = ld_granule(p); b = ld_granule(p + 1); c = ld_granule(p + 2); d = ld_granule(p + 3);
-            if ((unsigned)(a >> 32) == ep && (unsigned)(b >> 32) == ep && (unsigned)(c >> 32) == ep && (unsigned)(d >> 32) == ep) break;
-            if (spin > (1 << 21)) { bad = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
+    constexpr int U = 8;
+    for (int w0 = tid; w0 < n; w0 += 256 * U) {
+        v4u_t a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int w = w0 + 256 * u;
+            if (w < n) { a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w, 0, 16); b[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w + 16, 0, 16); }
         }
-        if (ok) { chi += __hiloint2double((int)(unsigned)b, (int)(unsigned)a); sc += __hiloint2double((int)(unsigned)d, (int)(unsigned)c); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int w = w0 + 256 * u;
+            if (w >= n) continue;
+            for (int spin = 0; !(a[u].y == ep && a[u].w == ep && b[u].y == ep && b[u].w == ep); ++spin) {
+                if (spin > (1 << 21)) { bad = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+                a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w, 0, 16); b[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w + 16, 0, 16);
+            }
+            if (ok) { chi += __hiloint2double((int)a[u].z, (int)a[u].x); sc += __hiloint2double((int)b[u].z, (int)b[u].x); }
+        }
     }
     if (ok) for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
     chi = block_sum_256(chi, red);
@@ -513,6 +528,18 @@ __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState
     if (bad) st->pcg_timeout = 1;
     lm_decide(st, ok && !bad, lambda, chi, sc, false);
     st->decide_epoch = ep;
+    st->decide_ctr = 0u;
+}
+// All 256 threads of a workgroup of the launch: publish, count in, and decide if this workgroup is the last one (red: >= 5 doubles).
+__device__ __forceinline__ void arrive_and_maybe_decide(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, const double chi, const double sc, double* red) {
+    int* last = reinterpret_cast<int*>(red + 4);
+    if (threadIdx.x == 0) {
+        publish_trial(g, blockIdx.x, ep, chi, sc);
+        const unsigned before = __hip_atomic_fetch_add(&st->decide_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last = (before == (unsigned)g.n_lin_a) ? 1 : 0;             // n_lin_a + 1 workgroups arrive
+    }
+    __syncthreads();
+    if (*last) decide_gather_role(g, st, ep, ok, red);
 }
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
@@ -2116,8 +2143,8 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // also linearises them there, into the set the speculative k_linearize is about to fill — k_odo_linearize (6.6 us, one
 // workgroup) leaves the unit.  The role is register-hungry (224 VGPRs), so this instantiation runs at two waves per SIMD: it is
 // used only where k_backsub is a single round of waves anyway (the speculative unit's size limit).
-// DEC (the gated unit: batched windows, large windows, Optimizer without the speculative unit): workgroup n_lin_a + 1 of the launch
-// takes the LM decision on the trial (decide_gather_role) — k_decide (6.3 us + a launch gap per unit) leaves the sequence.
+// DEC (the gated unit: batched windows, large windows, Optimizer without the speculative unit): the workgroup that finishes last
+// takes the LM decision on the trial (arrive_and_maybe_decide) — k_decide (6.3 us + a launch gap per unit) leaves the sequence.
 template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false>
 __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     static_assert(!(DEC && ODOSPEC), "the decision rides on the gated unit only");
@@ -2129,9 +2156,8 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     unsigned ep = 0;
     if (DEC) {
         ep = st->decide_epoch + 1u;
-        if ((int)blockIdx.x == g.n_lin_a + 1) { if (trial) decide_gather_role(g, st, ep, go, smem); return; }
-        // a failed solve: nothing to compute, but the deciding workgroup must not change the gate before every workgroup has read it
-        if (trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, ep, 0.0, 0.0);
+        // a failed solve: nothing to compute, but the decision may only be taken once every workgroup has read the gate
+        if (trial && !go) { if ((int)blockIdx.x <= g.n_lin_a) arrive_and_maybe_decide(g, st, ep, false, 0.0, 0.0, smem); return; }
     }
     // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
     if (!DEC && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
@@ -2164,7 +2190,8 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
             chi_acc += e * (g.inv_laser_cov * e);
         }
         const double chi_tot = block_sum_256(chi_acc, red);
-        if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, 0.0); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; } }
+        if (DEC) { arrive_and_maybe_decide(g, st, ep, true, chi_tot, 0.0, red); return; }
+        if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; }
         if (ODOSPEC) {
             __syncthreads();
             const LinSel<Src> lspec(g, ls ^ 1);                      // == spec_dst of the snapshot above
@@ -2187,7 +2214,8 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
-    if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
+    if (DEC) { arrive_and_maybe_decide(g, st, ep, true, chi_tot, sc_tot, red); return; }
+    if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; }
 }
 
 // ================================================================= K9: Levenberg-Marquardt control (lm_decide / decide_role: above k_linearize)
@@ -2930,7 +2958,7 @@ static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, h
 template <int G, class Src>
 static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odospec, int dec, hipStream_t s) {
     if (!staged(d)) {
-        if (dec) TIMED_LAUNCH((k_backsub<G, One, false, false, true>), dim3(d.backsub_blocks + 1, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
+        if (dec) TIMED_LAUNCH((k_backsub<G, One, false, false, true>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
         else TIMED_LAUNCH((k_backsub<G, One, false, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
         return;
     }
@@ -2941,7 +2969,7 @@ static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odo
     } else if (dec) {
         const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
         ensure_lds(k_backsub<G, Src, false, true, true>, lds);
-        TIMED_LAUNCH((k_backsub<G, Src, false, true, true>), dim3(d.backsub_blocks + 1, B), dim3(256), lds, s, src);
+        TIMED_LAUNCH((k_backsub<G, Src, false, true, true>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
     } else {
         const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
         ensure_lds(k_backsub<G, Src, false>, lds);
