@@ -78,7 +78,6 @@ struct LmState {
     int32_t n_edges_ok;     // stereo edges that can ever be active (not both ends fixed): the active set of phase 1
     uint32_t decide_epoch;  // tag of the last k_backsub launch that carried the LM decision; never reset (k_reset leaves it): stale
                             // hand-off words of an earlier launch or solve can then never match the tag a launch waits for
-    uint32_t decide_ctr;    // workgroups of the current such launch that have published their partial sums (the last one decides and clears it)
 };
 
 // The outputs of a linearisation that the Schur complement and the back-substitution consume.  Two sets: while the LM decision

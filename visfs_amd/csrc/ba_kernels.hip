@@ -475,11 +475,11 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
 }
 
 // The decision on board k_backsub (DEC): every workgroup publishes its two partial sums as hand-off words {tag:32 | half of a
-// double:32} with write-through stores and then counts itself in (one relaxed atomic add); the workgroup that arrives LAST takes the
-// decision.  It reads the words with sc1 loads and checks their tags — the data is the flag (cdna_hip_programming.md §6 Guideline
-// 16, form R2, as in the persistent PCG): the counter only ELECTS the decider, no ordering between the stores and the atomic is
-// relied on, and no fence or second launch separates the last partial from the decision.  tag = the launch's number in
-// LmState::decide_epoch, which only the decider advances, at the very end (it also clears the counter for the next launch).
+// double:32} with write-through stores; one more workgroup per window — the LAST ones of the launch in dispatch order, so they
+// start when the work is running out — reads the words with sc1 loads until every tag is there and takes the decision.  The data
+// is the flag (cdna_hip_programming.md §6 Guideline 16, form R2, as in the persistent PCG): no fence, no counter (1875 relaxed
+// atomic adds on one word cost the C4 launch 34 us: same-address atomics serialise at ~18 ns), no second launch.
+// tag = the launch's number in LmState::decide_epoch, which only the decider advances, at the very end.
 __device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* p);
 __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v);
 __device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w, const unsigned ep, const double chi, const double sc) {
@@ -488,10 +488,10 @@ __device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w,
     st_granule(o, e | (unsigned)__double2loint(chi)); st_granule(o + 1, e | (unsigned)__double2hiint(chi));
     st_granule(o + 2, e | (unsigned)__double2loint(sc)); st_granule(o + 3, e | (unsigned)__double2hiint(sc));
 }
-// The deciding workgroup (256 threads): fetch the partials of every workgroup of this launch — eight workgroups' words in flight per
-// thread, a word whose tag is not there yet is polled — add them in decide_role's order and step the LM state machine.  LmState is
-// written only here, after every workgroup has arrived, i.e. after every workgroup has read its gate and its lambda / sel.
-// A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
+// The deciding workgroup (256 threads): fetch the partials of every workgroup of the window — eight workgroups' words in flight per
+// thread; a word whose tag is not there yet is polled again after a pause — add them in decide_role's order and step the LM state
+// machine.  LmState is written only here, after every workgroup has published, i.e. after every workgroup has read its gate and
+// its lambda / sel.  A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
 __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, double* red) {
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
@@ -513,8 +513,8 @@ __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState
             const int w = w0 + 256 * u;
             if (w >= n) continue;
             for (int spin = 0; !(a[u].y == ep && a[u].w == ep && b[u].y == ep && b[u].w == ep); ++spin) {
-                if (spin > (1 << 21)) { bad = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
+                if (spin > (1 << 20)) { bad = 1; break; }
+                __builtin_amdgcn_s_sleep(24);            // ~0.65 us: the pollers must not crowd the memory system the workers are bound by
                 a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w, 0, 16); b[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w + 16, 0, 16);
             }
             if (ok) { chi += __hiloint2double((int)a[u].z, (int)a[u].x); sc += __hiloint2double((int)b[u].z, (int)b[u].x); }
@@ -528,18 +528,18 @@ __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState
     if (bad) st->pcg_timeout = 1;
     lm_decide(st, ok && !bad, lambda, chi, sc, false);
     st->decide_epoch = ep;
-    st->decide_ctr = 0u;
 }
-// All 256 threads of a workgroup of the launch: publish, count in, and decide if this workgroup is the last one (red: >= 5 doubles).
-__device__ __forceinline__ void arrive_and_maybe_decide(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, const double chi, const double sc, double* red) {
-    int* last = reinterpret_cast<int*>(red + 4);
-    if (threadIdx.x == 0) {
-        publish_trial(g, blockIdx.x, ep, chi, sc);
-        const unsigned before = __hip_atomic_fetch_add(&st->decide_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *last = (before == (unsigned)g.n_lin_a) ? 1 : 0;             // n_lin_a + 1 workgroups arrive
-    }
-    __syncthreads();
-    if (*last) decide_gather_role(g, st, ep, ok, red);
+// The deciders of a launch sit in its last grid row, behind the working workgroups: gridDim.x = working workgroups + gridDim.y,
+// workgroup (working + j, gridDim.y - 1) decides for window j.  Returns the window, or -1 for a working (or idle) workgroup.
+__device__ __forceinline__ int decider_window() {
+    const int working = (int)gridDim.x - (int)gridDim.y;
+    if ((int)blockIdx.x < working) return -1;
+    return (blockIdx.y == gridDim.y - 1) ? (int)blockIdx.x - working : -2;          // -2: an idle filler of the rectangular grid
+}
+__device__ __forceinline__ const DeviceGraph& graph_at(const One& s, int) { return s.g; }
+__device__ __forceinline__ const DeviceGraph& graph_at(const Many& s, const int j) {
+    typedef const __attribute__((address_space(4))) DeviceGraph* ConstGraphPtr;
+    return *(const DeviceGraph*)(ConstGraphPtr)(s.gs + j);
 }
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
@@ -2143,21 +2143,31 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // also linearises them there, into the set the speculative k_linearize is about to fill — k_odo_linearize (6.6 us, one
 // workgroup) leaves the unit.  The role is register-hungry (224 VGPRs), so this instantiation runs at two waves per SIMD: it is
 // used only where k_backsub is a single round of waves anyway (the speculative unit's size limit).
-// DEC (the gated unit: batched windows, large windows, Optimizer without the speculative unit): the workgroup that finishes last
-// takes the LM decision on the trial (arrive_and_maybe_decide) — k_decide (6.3 us + a launch gap per unit) leaves the sequence.
+// DEC (the gated unit: batched windows, large windows, Optimizer without the speculative unit): one more workgroup per window, the
+// last ones of the launch, takes the LM decision on the trial (decide_gather_role) — k_decide (6.3 us + a launch gap per unit) leaves.
 template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false>
 __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     static_assert(!(DEC && ODOSPEC), "the decision rides on the gated unit only");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (DEC) {
+        const int dw = decider_window();
+        if (dw >= 0) {
+            const DeviceGraph& gd = graph_at(src, dw);
+            LmState* sd = gd.st;
+            if (sd->mode & MODE_TRIAL) decide_gather_role(gd, sd, sd->decide_epoch + 1u, !sd->solver_failed && !sd->pcg_timeout, smem);
+            return;
+        }
+        if (dw == -2) return;
+    }
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     const bool trial = (st->mode & MODE_TRIAL) != 0;
     const bool go = trial && !st->solver_failed && !st->pcg_timeout;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     unsigned ep = 0;
     if (DEC) {
         ep = st->decide_epoch + 1u;
         // a failed solve: nothing to compute, but the decision may only be taken once every workgroup has read the gate
-        if (trial && !go) { if ((int)blockIdx.x <= g.n_lin_a) arrive_and_maybe_decide(g, st, ep, false, 0.0, 0.0, smem); return; }
+        if (trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, ep, 0.0, 0.0);
     }
     // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
     if (!DEC && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
@@ -2190,8 +2200,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
             chi_acc += e * (g.inv_laser_cov * e);
         }
         const double chi_tot = block_sum_256(chi_acc, red);
-        if (DEC) { arrive_and_maybe_decide(g, st, ep, true, chi_tot, 0.0, red); return; }
-        if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; }
+        if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, 0.0); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; } }
         if (ODOSPEC) {
             __syncthreads();
             const LinSel<Src> lspec(g, ls ^ 1);                      // == spec_dst of the snapshot above
@@ -2214,8 +2223,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
-    if (DEC) { arrive_and_maybe_decide(g, st, ep, true, chi_tot, sc_tot, red); return; }
-    if (tid == 0) { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; }
+    if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
 }
 
 // ================================================================= K9: Levenberg-Marquardt control (lm_decide / decide_role: above k_linearize)
@@ -2958,7 +2966,7 @@ static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, h
 template <int G, class Src>
 static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odospec, int dec, hipStream_t s) {
     if (!staged(d)) {
-        if (dec) TIMED_LAUNCH((k_backsub<G, One, false, false, true>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
+        if (dec) TIMED_LAUNCH((k_backsub<G, One, false, false, true>), dim3(d.backsub_blocks + B, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
         else TIMED_LAUNCH((k_backsub<G, One, false, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
         return;
     }
@@ -2969,7 +2977,7 @@ static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odo
     } else if (dec) {
         const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
         ensure_lds(k_backsub<G, Src, false, true, true>, lds);
-        TIMED_LAUNCH((k_backsub<G, Src, false, true, true>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
+        TIMED_LAUNCH((k_backsub<G, Src, false, true, true>), dim3(d.backsub_blocks + B, B), dim3(256), lds, s, src);
     } else {
         const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
         ensure_lds(k_backsub<G, Src, false>, lds);
