@@ -589,7 +589,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
     // members keep the gated form.
     { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (!w.batch_member && No <= 150000)) && Np <= MAX_STAGED_POSES; }
-    { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = !(e && e[0] == '0'); }
+    // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
+    { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = e ? (e[0] != '0') : !w.batch_member; }
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);

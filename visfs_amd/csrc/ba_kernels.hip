@@ -488,8 +488,8 @@ __device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w,
     st_granule(o, e | (unsigned)__double2loint(chi)); st_granule(o + 1, e | (unsigned)__double2hiint(chi));
     st_granule(o + 2, e | (unsigned)__double2loint(sc)); st_granule(o + 3, e | (unsigned)__double2hiint(sc));
 }
-// The deciding workgroup (256 threads): fetch the partials of every workgroup of the window — eight workgroups' words in flight per
-// thread; a word whose tag is not there yet is polled again after a pause — add them in decide_role's order and step the LM state
+// The deciding workgroup (256 threads): fetch the partials of every workgroup of the window — four workgroups' words in flight per
+// thread, fetched again after a pause while a tag is missing — add them in decide_role's order and step the LM state
 // machine.  LmState is written only here, after every workgroup has published, i.e. after every workgroup has read its gate and
 // its lambda / sel.  A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
 __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, double* red) {
@@ -500,24 +500,29 @@ __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.trial_gran, 0, (int)(n * 32), 0x00020000);
     double chi = 0.0, sc = 0.0;
     int bad = 0;
-    constexpr int U = 8;
+    // (kept small on purpose: the role shares the kernel's register budget with the landmark role — an eight-deep version with a
+    // poll loop per word needed 256 VGPRs + 56 AGPRs and cost EVERY workgroup of k_backsub its occupancy: 16 -> 46 us at C4)
+    constexpr int U = 4;
     for (int w0 = tid; w0 < n; w0 += 256 * U) {
         v4u_t a[U], b[U];
+        for (int spin = 0;; ++spin) {
+            bool ready = true;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int w = w0 + 256 * u;
-            if (w < n) { a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w, 0, 16); b[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w + 16, 0, 16); }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int w = w0 + 256 * u;
-            if (w >= n) continue;
-            for (int spin = 0; !(a[u].y == ep && a[u].w == ep && b[u].y == ep && b[u].w == ep); ++spin) {
-                if (spin > (1 << 20)) { bad = 1; break; }
-                __builtin_amdgcn_s_sleep(24);            // ~0.65 us: the pollers must not crowd the memory system the workers are bound by
+            for (int u = 0; u < U; ++u) {
+                const int w = min(w0 + 256 * u, n - 1);             // (clamped: a thread's surplus slots re-read the last workgroup's words)
                 a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w, 0, 16); b[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * w + 16, 0, 16);
             }
-            if (ok) { chi += __hiloint2double((int)a[u].z, (int)a[u].x); sc += __hiloint2double((int)b[u].z, (int)b[u].x); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) ready = ready && a[u].y == ep && a[u].w == ep && b[u].y == ep && b[u].w == ep;
+            if (ready) break;
+            if (spin > (1 << 20)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(8);                 // ~0.2 us: the pollers must not crowd the memory system the workers are bound by
+        }
+        if (ok) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (w0 + 256 * u < n) { chi += __hiloint2double((int)a[u].z, (int)a[u].x); sc += __hiloint2double((int)b[u].z, (int)b[u].x); }
+            }
         }
     }
     if (ok) for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
@@ -536,11 +541,13 @@ __device__ __forceinline__ int decider_window() {
     if ((int)blockIdx.x < working) return -1;
     return (blockIdx.y == gridDim.y - 1) ? (int)blockIdx.x - working : -2;          // -2: an idle filler of the rectangular grid
 }
-__device__ __forceinline__ const DeviceGraph& graph_at(const One& s, int) { return s.g; }
-__device__ __forceinline__ const DeviceGraph& graph_at(const Many& s, const int j) {
-    typedef const __attribute__((address_space(4))) DeviceGraph* ConstGraphPtr;
-    return *(const DeviceGraph*)(ConstGraphPtr)(s.gs + j);
+// The decider of window j.
+__device__ __forceinline__ void decider_run(const DeviceGraph& gd, double* red) {
+    LmState* sd = gd.st;
+    if (sd->mode & MODE_TRIAL) decide_gather_role(gd, sd, sd->decide_epoch + 1u, !sd->solver_failed && !sd->pcg_timeout, red);
 }
+__device__ __forceinline__ void decider_of(const One& s, int, double* red) { decider_run(s.g, red); }
+__device__ __forceinline__ void decider_of(const Many& s, const int j, double* red) { decider_run(s.gs[j], red); }
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
 // spec = 0: linearise the committed estimate (first unit of a phase, stage hooks, large windows) when the gate says so.
@@ -2145,30 +2152,24 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // used only where k_backsub is a single round of waves anyway (the speculative unit's size limit).
 // DEC (the gated unit: batched windows, large windows, Optimizer without the speculative unit): one more workgroup per window, the
 // last ones of the launch, takes the LM decision on the trial (decide_gather_role) — k_decide (6.3 us + a launch gap per unit) leaves.
+// The batched instantiation drifts from 90 to 114 VGPRs with the role on board (one wave per SIMD less for a bandwidth-bound
+// launch): it is held at five waves per SIMD (96 VGPRs, a dozen spill slots outside the loops).
 template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false>
-__global__ __launch_bounds__(256) void k_backsub(const Src src) {
+__global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void k_backsub(const Src src) {
     static_assert(!(DEC && ODOSPEC), "the decision rides on the gated unit only");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (DEC) {
         const int dw = decider_window();
-        if (dw >= 0) {
-            const DeviceGraph& gd = graph_at(src, dw);
-            LmState* sd = gd.st;
-            if (sd->mode & MODE_TRIAL) decide_gather_role(gd, sd, sd->decide_epoch + 1u, !sd->solver_failed && !sd->pcg_timeout, smem);
-            return;
-        }
+        if (dw >= 0) { decider_of(src, dw, smem); return; }
         if (dw == -2) return;
     }
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
     const bool trial = (st->mode & MODE_TRIAL) != 0;
     const bool go = trial && !st->solver_failed && !st->pcg_timeout;
-    unsigned ep = 0;
-    if (DEC) {
-        ep = st->decide_epoch + 1u;
-        // a failed solve: nothing to compute, but the decision may only be taken once every workgroup has read the gate
-        if (trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, ep, 0.0, 0.0);
-    }
+    // a failed solve: nothing to compute, but the decision may only be taken once every workgroup has read the gate
+    // (the tag is read where it is used: nothing of the decision's bookkeeping stays live across the landmark role)
+    if (DEC && trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, st->decide_epoch + 1u, 0.0, 0.0);
     // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
     if (!DEC && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
     if (!go) return;
@@ -2200,7 +2201,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
             chi_acc += e * (g.inv_laser_cov * e);
         }
         const double chi_tot = block_sum_256(chi_acc, red);
-        if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, 0.0); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; } }
+        if (tid == 0) { if (DEC) publish_trial(g, bid, st->decide_epoch + 1u, chi_tot, 0.0); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = 0.0; } }
         if (ODOSPEC) {
             __syncthreads();
             const LinSel<Src> lspec(g, ls ^ 1);                      // == spec_dst of the snapshot above
@@ -2223,7 +2224,7 @@ __global__ __launch_bounds__(256) void k_backsub(const Src src) {
     backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
-    if (tid == 0) { if (DEC) publish_trial(g, bid, ep, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
+    if (tid == 0) { if (DEC) publish_trial(g, bid, st->decide_epoch + 1u, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
 }
 
 // ================================================================= K9: Levenberg-Marquardt control (lm_decide / decide_role: above k_linearize)
@@ -3116,7 +3117,7 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
     else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
-    // the LM decision rides on k_backsub (fused_decide = false: the separate k_decide launch of round 1, for A/B runs)
+    // the LM decision rides on k_backsub (fused_decide = false: one k_decide launch for all windows, as in round 1)
     launch_backsub_src(src, d, B, 0, fused_decide ? 1 : 0, s);
     if (!fused_decide) hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
 }
