@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VISFS_BA_ABI_VERSION 3
+#define VISFS_BA_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 /* The reference signals failure by returning an EMPTY pose map
@@ -43,14 +43,16 @@ enum {
     VISFS_BA_ERR_HUGE_CHI2_1 = 4,  /* Optimizer.cpp:277-280 */
     VISFS_BA_ERR_HUGE_CHI2_2 = 5,  /* Optimizer.cpp:315-318 */
     VISFS_BA_ERR_BAD_ARGUMENT = 6,
-    VISFS_BA_ERR_UNSUPPORTED = 7,  /* framework != g2o-algorithm, laser factor, ... (out of scope) */
+    VISFS_BA_ERR_UNSUPPORTED = 7,  /* Ceres DOGLEG strategy, a size beyond a kernel's limits, ... */
     VISFS_BA_ERR_DEVICE = 8,       /* HIP runtime error / no MI355X present */
     VISFS_BA_ERR_NOT_LOADED = 9    /* no graph resident in the handle */
 };
 
 /* ---- parameters: the eight Optimizer keys (Parameters.h:184-191, read at Optimizer.cpp:37-54) */
 typedef struct visfs_ba_params {
-    int32_t framework;            /* Optimizer/Framework: 0 = g2o algorithm (the only one implemented) */
+    int32_t framework;            /* Optimizer/Framework: 0 = the g2o branch (Optimizer.cpp:72-364), 1 = the Ceres branch (:366-593; its
+                                   * LEVENBERG_MARQUARDT strategy: trust_region 1 = DOGLEG is refused; solver is ignored — every
+                                   * linear_solver_type the branch selects is an exact dense solve) */
     int32_t solver;               /* Optimizer/Solver: 0 csparse, 1 cholmod, 3 eigen → direct Cholesky of S; 2 → block-Jacobi PCG */
     int32_t trust_region;         /* Optimizer/TrustRegion: 0 Levenberg, 1 GaussNewton */
     int32_t iterations;           /* Optimizer/Iterations (run as iterations/2 + iterations/2) */
@@ -264,6 +266,15 @@ int visfs_ba_stage_mark_outliers(visfs_ba_handle* h);
  * [g2o-upstream] OptimizationAlgorithmLevenberg::solve, incl. its failure paths, against the CPU checker. */
 int visfs_ba_hook_lm_script(int32_t gauss_newton, int32_t n_iter, double chi0, double max_diag0, int32_t n_trials,
                             const double* temp_chi, const double* scale, const int32_t* ok, visfs_ba_stats* stats);
+/* Host-only hook: the control of the Ceres branch (Optimizer/Framework=1; [ceres-upstream] TrustRegionMinimizer + LevenbergMarquardtStrategy,
+ * the device-side state machine's own functions compiled for the host) on scripted outcomes: iteration t's linear solve reports
+ * (ok[t], model_cost_change[t], cand_cost[t], step_norm[t]); a step that is taken then reports (grad_max[t], x_norm[t]) of the new
+ * linearisation; the last entry repeats.  Fills stats->trace_lambda (trust-region radius after each iteration), trace_chi2 (2 x cost),
+ * iterations_run[0], chi2_final; returns the termination reason (1 max iterations, 2 gradient, 3 parameter, 4 function tolerance,
+ * 5 minimum radius, 6 consecutive invalid steps). */
+int visfs_ba_hook_ceres_script(int32_t max_iter, double cost0, double x_norm0, double grad_max0, int32_t n, const int32_t* ok,
+                               const double* model_cost_change, const double* cand_cost, const double* step_norm,
+                               const double* grad_max, const double* x_norm, visfs_ba_stats* stats);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------ */
 /* Sizes of the resident graph and of the index structures built at upload. */

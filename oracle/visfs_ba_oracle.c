@@ -401,6 +401,15 @@ void oracle_huber(double e2, double delta, double rho[2]) {
     else { const double sqrte = sqrt(e2); rho[0] = 2 * sqrte * delta - dsqr; rho[1] = delta / sqrte; }
 }
 
+/* [ceres-upstream] HuberLoss(a)::Evaluate on s = ||residual||^2 (loss_function.cc), and the Corrector for rho'' <= 0 (corrector.cc):
+ * residual and Jacobian are scaled by sqrt(rho'), the cost is rho / 2.  Same function of s as g2o's kernel for a > 0; unlike the
+ * g2o branch the Ceres branch attaches the loss whatever robustKernelDelta is (Optimizer.cpp:370,469), so a <= 0 is restated too. */
+static void ceres_huber(double s, double a, double rho[2]) {
+    const double b = a * a;
+    if (s > b) { const double r = sqrt(s); rho[0] = 2.0 * a * r - b; rho[1] = fmax(DBL_MIN, a / r); }
+    else { rho[0] = s; rho[1] = 1.0; }
+}
+
 /* ===================================================================== */
 /* graph build / write-back                                               */
 /* ===================================================================== */
@@ -535,6 +544,12 @@ struct oracle_sys {
     /* per trial */
     double *Dinv, *S, *bs, *dxp, *dxl, *chol;
     double lambda_used;
+    /* Ceres flavour (Optimizer/Framework=1): weights of the stereo / laser terms (1/var for g2o's e^T Omega e, 1/var^2 for
+     * Ceres' ||Omega e||^2), and the per-variable multipliers of the damping: H_ii + lambda m_i (m = 1 for g2o) */
+    int ceres;
+    double w_px, w_laser;
+    double *ml, *mp;            /* [3 Nl], [n6] */
+    double *s2l, *s2p;          /* Jacobi scaling squared, fixed at iteration zero [ceres-upstream] */
     double pcg_residual;        /* LinearSolverPCG::_residual */
     double *pcg_r, *pcg_d, *pcg_q, *pcg_s, *pcg_J;
     /* outputs */
@@ -547,8 +562,15 @@ static void* xcalloc(size_t n, size_t sz) { void* p = calloc(n ? n : 1, sz); if 
 oracle_sys* oracle_sys_create(const visfs_ba_params* prm, const visfs_ba_graph* g, int nthreads) {
     oracle_sys* s = (oracle_sys*)xcalloc(1, sizeof(*s));
     s->prm = *prm;
-    s->Np = g->n_poses; s->Nl = g->n_points; s->No = g->n_obs; s->Ne = g->n_odo;
+    s->ceres = (prm->framework == 1);
+    /* Optimizer.cpp:405-422: the Ceres branch never adds a wheel-odometry factor (links between two window poses fall in the
+     * "TODO" arm, and the other arm needs both ids in the window) */
+    s->Np = g->n_poses; s->Nl = g->n_points; s->No = g->n_obs; s->Ne = s->ceres ? 0 : g->n_odo;
     s->nthreads = nthreads < 1 ? 1 : nthreads;
+    /* g2o: chi2 = e^T Omega e with Omega = I/var (Optimizer.cpp:153); Ceres: residual = info * e with the SAME matrix, so the
+     * squared norm carries 1/var^2 (StereoObservationFactor.cpp:25-26; OccupiedSpace2dFactor.cpp:45) */
+    s->w_px = 1.0 / prm->pixel_variance; s->w_laser = 1.0 / prm->laser_covariance;
+    if (s->ceres) { s->w_px *= s->w_px; s->w_laser *= s->w_laser; }
     s->intr[0] = g->fx; s->intr[1] = g->fy; s->intr[2] = g->cx; s->intr[3] = g->cy; s->intr[4] = g->bf;
     const int Np = s->Np, Nl = s->Nl, No = s->No, Ne = s->Ne;
     s->pose0 = xcalloc((size_t)Np * 7, 8); memcpy(s->pose0, g->pose_tq, (size_t)Np * 56);
@@ -594,6 +616,10 @@ oracle_sys* oracle_sys_create(const visfs_ba_params* prm, const visfs_ba_graph* 
     s->Hpp = xcalloc((size_t)s->n6 * s->n6, 8); s->bp = xcalloc(s->n6, 8);
     s->odo_err = xcalloc((size_t)Ne * 6, 8);
     s->Dinv = xcalloc((size_t)Nl * 6, 8);
+    s->ml = xcalloc((size_t)Nl * 3, 8); s->s2l = xcalloc((size_t)Nl * 3, 8);
+    s->mp = xcalloc(s->n6, 8); s->s2p = xcalloc(s->n6, 8);
+    for (int i = 0; i < 3 * Nl; ++i) s->ml[i] = 1.0;
+    for (int i = 0; i < s->n6; ++i) s->mp[i] = 1.0;
     s->S = xcalloc((size_t)s->n6 * s->n6, 8); s->bs = xcalloc(s->n6, 8); s->chol = xcalloc((size_t)s->n6 * s->n6, 8);
     s->dxp = xcalloc(s->n6, 8); s->dxl = xcalloc((size_t)Nl * 3, 8);
     s->pcg_r = xcalloc(s->n6, 8); s->pcg_d = xcalloc(s->n6, 8); s->pcg_q = xcalloc(s->n6, 8); s->pcg_s = xcalloc(s->n6, 8);
@@ -620,7 +646,7 @@ void oracle_sys_destroy(oracle_sys* s) {
     free(s->err); free(s->chi2); free(s->wgt); free(s->W); free(s->Hll); free(s->bl); free(s->Hpp); free(s->bp);
     free(s->odo_err); free(s->Dinv); free(s->S); free(s->bs); free(s->chol); free(s->dxp); free(s->dxl);
     free(s->pcg_r); free(s->pcg_d); free(s->pcg_q); free(s->pcg_s); free(s->pcg_J); free(s->final_chi2); free(s->outlier);
-    free(s->laser_xyz); free(s->grid_cost);
+    free(s->laser_xyz); free(s->grid_cost); free(s->ml); free(s->mp); free(s->s2l); free(s->s2p);
     free(s);
 }
 
@@ -630,8 +656,9 @@ static inline int edge_active(const oracle_sys* s, int k) { return s->obs_level[
 
 /* computeActiveErrors + activeRobustChi2 at (pose, pt). Fills err/chi2 when store != 0. */
 static double active_robust_chi2(oracle_sys* s, const double* pose, const double* pt, int store) {
-    const double inv_var = 1.0 / s->prm.pixel_variance;   /* Omega = I3 / pixelVariance, Optimizer.cpp:153 */
+    const double inv_var = s->w_px;                       /* Omega = I3 / pixelVariance, Optimizer.cpp:153 (squared for Ceres) */
     const double delta = s->prm.robust_kernel_delta;
+    const int ceres = s->ceres;
     double total = 0.0;
 #ifdef _OPENMP
 #pragma omp parallel for reduction(+:total) num_threads(s->nthreads) if (s->nthreads > 1)
@@ -643,7 +670,8 @@ static double active_robust_chi2(oracle_sys* s, const double* pose, const double
         /* chi2() = e . (Omega e) */
         const double c = e[0] * (inv_var * e[0]) + e[1] * (inv_var * e[1]) + e[2] * (inv_var * e[2]);
         if (store) { s->err[3*k] = e[0]; s->err[3*k+1] = e[1]; s->err[3*k+2] = e[2]; s->chi2[k] = c; }
-        if (delta > 0.0) { double rho[2]; oracle_huber(c, delta, rho); total += rho[0]; }
+        if (ceres) { double rho[2]; ceres_huber(c, delta, rho); total += rho[0]; }     /* the loss is attached unconditionally (:370,469) */
+        else if (delta > 0.0) { double rho[2]; oracle_huber(c, delta, rho); total += rho[0]; }
         else total += c;
     }
     /* odometry edges: no robust kernel (Optimizer.cpp:135-142) */
@@ -659,7 +687,7 @@ static double active_robust_chi2(oracle_sys* s, const double* pose, const double
         total += c;
     }
     /* laser edges: information 1 / laserCovariance, no robust kernel (Optimizer.cpp:232,244-249) */
-    const double inv_laser = 1.0 / s->prm.laser_covariance;
+    const double inv_laser = s->w_laser;
     for (int k = 0; k < s->Nz; ++k) {
         double e;
         oracle_laser_edge(pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, NULL);
@@ -682,7 +710,7 @@ static void hpp_add(oracle_sys* s, int a, int b, const double* A, const double* 
 void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag) {
     const double chi = active_robust_chi2(s, s->pose, s->pt, 1);
     if (robust_chi2) *robust_chi2 = chi;
-    const double inv_var = 1.0 / s->prm.pixel_variance;
+    const double inv_var = s->w_px;
     const double delta = s->prm.robust_kernel_delta;
     memset(s->Hll, 0, (size_t)s->Nl * 48); memset(s->bl, 0, (size_t)s->Nl * 24);
     memset(s->Hpp, 0, (size_t)s->n6 * s->n6 * 8); memset(s->bp, 0, (size_t)s->n6 * 8);
@@ -701,7 +729,8 @@ void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag) 
             double e[3], Ji[9], Jj[18];
             oracle_stereo_edge(s->pose + 7 * ip, s->pt + 3 * l, s->obs_uvr + 3 * k, s->intr, e, Ji, Jj);
             double rho1 = 1.0;
-            if (delta > 0.0) { double rho[2]; oracle_huber(s->chi2[k], delta, rho); rho1 = rho[1]; }
+            if (s->ceres) { double rho[2]; ceres_huber(s->chi2[k], delta, rho); rho1 = rho[1]; }
+            else if (delta > 0.0) { double rho[2]; oracle_huber(s->chi2[k], delta, rho); rho1 = rho[1]; }
             s->wgt[k] = rho1;
             const double wo = rho1 * inv_var;                 /* weightedOmega = rho' * Omega (diagonal) */
             const int pfree = !s->pose_fixed[ip], lfree = !s->pt_fixed[l];
@@ -778,7 +807,7 @@ void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag) 
         }
     }
     /* laser edges: the range point is fixed, only the pose block receives J^T Omega J and -J^T Omega e */
-    const double inv_laser = 1.0 / s->prm.laser_covariance;
+    const double inv_laser = s->w_laser;
     for (int k = 0; k < s->Nz; ++k) {
         double e, J[6];
         oracle_laser_edge(s->pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, J);
@@ -913,7 +942,7 @@ static int schur_solve(oracle_sys* s, double lambda, int* pcg_iters) {
     s->lambda_used = lambda;
     /* Hschur = Hpp (+lambda on the diagonal); bschur = bp - coefficients */
     memcpy(s->S, s->Hpp, (size_t)n * n * 8);
-    for (int i = 0; i < n; ++i) s->S[(size_t)i * n + i] += lambda;
+    for (int i = 0; i < n; ++i) s->S[(size_t)i * n + i] += lambda * s->mp[i];      /* mp = 1 (g2o: lambda I) */
     memcpy(s->bs, s->bp, (size_t)n * 8);
     /* poses without any active edge are not part of g2o's active set: pin them (dx = 0) */
     for (int b = 0; b < s->npf; ++b) {
@@ -929,7 +958,7 @@ static int schur_solve(oracle_sys* s, double lambda, int* pcg_iters) {
         double* Di = s->Dinv + 6 * l;
         if (s->pt_fixed[l] || !landmark_has_active_edge(s, l)) { memset(Di, 0, 48); continue; }
         double h[6]; memcpy(h, s->Hll + 6 * l, 48);
-        h[0] += lambda; h[3] += lambda; h[5] += lambda;
+        h[0] += lambda * s->ml[3 * l]; h[3] += lambda * s->ml[3 * l + 1]; h[5] += lambda * s->ml[3 * l + 2];
         sym3_inv(h, Di);
     }
     if (nt > 1) {
@@ -1033,8 +1062,8 @@ static void apply_update(oracle_sys* s) {
 static double compute_scale(const oracle_sys* s, double lambda) {
     /* [g2o-upstream] OptimizationAlgorithmLevenberg::computeScale: sum_j x_j (lambda x_j + b_j) */
     double scale = 0.0;
-    for (int i = 0; i < s->n6; ++i) scale += s->dxp[i] * (lambda * s->dxp[i] + s->bp[i]);
-    for (int l = 0; l < s->Nl; ++l) { if (s->pt_fixed[l]) continue; for (int c = 0; c < 3; ++c) scale += s->dxl[3*l+c] * (lambda * s->dxl[3*l+c] + s->bl[3*l+c]); }
+    for (int i = 0; i < s->n6; ++i) scale += s->dxp[i] * (lambda * s->mp[i] * s->dxp[i] + s->bp[i]);
+    for (int l = 0; l < s->Nl; ++l) { if (s->pt_fixed[l]) continue; for (int c = 0; c < 3; ++c) scale += s->dxl[3*l+c] * (lambda * s->ml[3*l+c] * s->dxl[3*l+c] + s->bl[3*l+c]); }
     return scale;
 }
 
@@ -1205,12 +1234,204 @@ int oracle_sys_mark_outliers(oracle_sys* s) {
     return s->prm.robust_kernel_delta > 0.0 ? mark_outliers(s) : 0;
 }
 
+/* ===================================================================== */
+/* Optimizer/Framework=1: the Ceres branch (Optimizer.cpp:366-593)         */
+/* ===================================================================== */
+/* [ceres-upstream] TrustRegionMinimizer with LevenbergMarquardtStrategy, restated from the published algorithm of Ceres 2.0 / 2.1
+ * (internal/ceres/trust_region_minimizer.cc, levenberg_marquardt_strategy.cc; the reference needs <= 2.1 for
+ * ceres::LocalParameterization and pins no version).  Solver::Options defaults: initial_trust_region_radius 1e4, max 1e16, min 1e-32,
+ * min_relative_decrease 1e-3, min / max_lm_diagonal 1e-6 / 1e32, function / gradient / parameter tolerance 1e-6 / 1e-10 / 1e-8,
+ * max_num_consecutive_invalid_steps 5, jacobi_scaling on, monotonic steps.  The control flow exists once (ceres_tr_step /
+ * ceres_tr_finalize) and is driven by the real system and by scripted outcomes (oracle_ceres_script). */
+typedef struct {
+    double radius, decrease_factor, cost, x_norm;
+    int iter, invalid, done, reason;    /* reason: 1 max iterations, 2 gradient, 3 parameter, 4 function tolerance, 5 min radius, 6 invalid steps */
+} ceres_tr;
+static void ceres_tr_init(ceres_tr* t, double cost, double x_norm) {
+    t->radius = 1e4; t->decrease_factor = 2.0; t->cost = cost; t->x_norm = x_norm; t->iter = 0; t->invalid = 0; t->done = 0; t->reason = 0;
+}
+/* One pass of the minimizer loop after the linear solve: solve_ok = the strategy produced a finite step; model_cost_change =
+ * -(J step)^T (f + J step / 2); cand_cost = cost at x (+) step (only read when the step is valid); step_norm = ||x - candidate||.
+ * Returns 1 when the step is taken (the caller moves x, re-evaluates the Jacobian and reports ||g||_inf, ||x|| to ceres_tr_finalize). */
+static int ceres_tr_step(ceres_tr* t, int solve_ok, double model_cost_change, double cand_cost, double step_norm) {
+    if (!solve_ok || !(model_cost_change > 0.0)) {                       /* step_is_valid = model_cost_change > 0 */
+        if (++t->invalid >= 5) { t->done = 1; t->reason = 6; }            /* HandleInvalidStep */
+        else t->radius *= 0.5;                                            /* LevenbergMarquardtStrategy::StepIsInvalid */
+        return 0;
+    }
+    t->invalid = 0;
+    if (!isfinite(cand_cost)) cand_cost = DBL_MAX;                       /* a failed evaluation of the candidate */
+    if (step_norm <= 1e-8 * (t->x_norm + 1e-8)) { t->done = 1; t->reason = 3; return 0; }      /* ParameterToleranceReached */
+    const double cost_change = t->cost - cand_cost;
+    if (fabs(cost_change) <= 1e-6 * t->cost) { t->done = 1; t->reason = 4; return 0; }         /* FunctionToleranceReached: the step is NOT taken */
+    const double rho = cost_change / model_cost_change;                  /* StepQuality, monotonic */
+    if (rho > 1e-3) {
+        t->cost = cand_cost;
+        t->radius = t->radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));               /* StepAccepted */
+        t->radius = fmin(1e16, t->radius);
+        t->decrease_factor = 2.0;
+        return 1;
+    }
+    t->radius = t->radius / t->decrease_factor;                          /* StepRejected */
+    t->decrease_factor *= 2.0;
+    return 0;
+}
+/* FinalizeIterationAndCheckIfMinimizerCanContinue (no time limit: see DESIGN.md): accepted = this iteration took its step. */
+static void ceres_tr_finalize(ceres_tr* t, int max_iter, int accepted, double grad_max, double x_norm) {
+    if (accepted) t->x_norm = x_norm;
+    if (t->done) return;
+    if (t->iter >= max_iter) { t->done = 1; t->reason = 1; return; }
+    if (accepted && grad_max <= 1e-10) { t->done = 1; t->reason = 2; return; }
+    if (t->radius < 1e-32) { t->done = 1; t->reason = 5; return; }
+}
+
+/* ||x|| and ||g||_inf of the reduced program: non-constant parameter blocks that appear in a residual block — free poses (7 numbers)
+ * and free landmarks (3) with at least one observation; g in the tangent space the factors differentiate in. */
+static int pose_has_residual(const oracle_sys* s, int i) {
+    const int a = s->pose_idx[i];
+    if (a < 0) return 0;
+    return s->po_ptr[a + 1] > s->po_ptr[a] || (s->Nz > 0 && s->laser_pose == i);
+}
+static double ceres_x_norm2(const oracle_sys* s, const double* pose, const double* pt) {
+    double n2 = 0.0;
+    for (int i = 0; i < s->Np; ++i) if (pose_has_residual(s, i)) for (int c = 0; c < 7; ++c) n2 += pose[7 * i + c] * pose[7 * i + c];
+    for (int l = 0; l < s->Nl; ++l) if (!s->pt_fixed[l] && s->lm_ptr[l + 1] > s->lm_ptr[l]) for (int c = 0; c < 3; ++c) n2 += pt[3 * l + c] * pt[3 * l + c];
+    return n2;
+}
+static double ceres_step_norm2(const oracle_sys* s) {
+    double n2 = 0.0;
+    for (int i = 0; i < s->Np; ++i) if (pose_has_residual(s, i)) for (int c = 0; c < 7; ++c) { const double d = s->pose_trial[7 * i + c] - s->pose[7 * i + c]; n2 += d * d; }
+    for (int l = 0; l < s->Nl; ++l) if (!s->pt_fixed[l] && s->lm_ptr[l + 1] > s->lm_ptr[l]) for (int c = 0; c < 3; ++c) { const double d = s->pt_trial[3 * l + c] - s->pt[3 * l + c]; n2 += d * d; }
+    return n2;
+}
+static double ceres_grad_max(const oracle_sys* s) {
+    double m = 0.0;
+    for (int i = 0; i < s->n6; ++i) m = fmax(m, fabs(s->bp[i]));
+    for (int l = 0; l < s->Nl; ++l) if (!s->pt_fixed[l]) for (int c = 0; c < 3; ++c) m = fmax(m, fabs(s->bl[3 * l + c]));
+    return m;
+}
+/* LevenbergMarquardtStrategy::ComputeStep's diagonal in the UNSCALED variables: with the Jacobi scaling s_i = 1 / (1 + sqrt(H0_ii))
+ * (H0 = J^T J at iteration zero) Ceres solves (S H S + D^2) y = S b with D_i^2 = clamp(H_ii s_i^2, 1e-6, 1e32) / radius and takes the
+ * step S y; that is (H + diag(m_i) / radius) dx = b with m_i = clamp(H_ii s_i^2) / s_i^2. */
+static void ceres_multipliers(oracle_sys* s) {
+    for (int i = 0; i < s->n6; ++i) {
+        const double h = s->Hpp[(size_t)i * s->n6 + i] * s->s2p[i];
+        s->mp[i] = fmin(fmax(h, 1e-6), 1e32) / s->s2p[i];
+    }
+    for (int l = 0; l < s->Nl; ++l) {
+        static const int dq[3] = { 0, 3, 5 };
+        for (int c = 0; c < 3; ++c) {
+            const double h = s->Hll[6 * l + dq[c]] * s->s2l[3 * l + c];
+            s->ml[3 * l + c] = fmin(fmax(h, 1e-6), 1e32) / s->s2l[3 * l + c];
+        }
+    }
+}
+static int step_is_finite(const oracle_sys* s) {
+    for (int i = 0; i < s->n6; ++i) if (!isfinite(s->dxp[i])) return 0;
+    for (int i = 0; i < 3 * s->Nl; ++i) if (!isfinite(s->dxl[i])) return 0;
+    return 1;
+}
+
+/* ceres::Solve(options, &problem, &summary) of Optimizer.cpp:504-527 + the outlier loop :529-540.  Every linear_solver_type the
+ * branch can select (DENSE_SCHUR / DENSE_NORMAL_CHOLESKY / DENSE_QR) solves the same damped normal equations exactly: restated as
+ * Schur elimination + dense Cholesky.  options.max_solver_time_in_seconds = 0.06 is NOT restated (the result would depend on the
+ * machine); DOGLEG (Optimizer/TrustRegion=1) is not restated: VISFS_BA_ERR_UNSUPPORTED. */
+static int ceres_optimize(oracle_sys* s, visfs_ba_stats* st) {
+    if (s->prm.trust_region == 1) return VISFS_BA_ERR_UNSUPPORTED;
+    const int max_it = s->prm.iterations;
+    const int saved_solver = s->prm.solver;
+    s->prm.solver = 0;                                         /* schur_solve: dense Cholesky on the reduced system */
+    double chi, md;
+    oracle_sys_linearize(s, &chi, &md);                        /* IterationZero: cost = sum rho / 2, robustified Jacobian */
+    st->chi2_initial = chi;
+    { int n_ok = 0; for (int k = 0; k < s->No; ++k) n_ok += s->obs_edge_ok[k]; st->n_active_edges[0] = st->n_active_edges[1] = n_ok; }
+    for (int i = 0; i < s->n6; ++i) { const double q = 1.0 / (1.0 + sqrt(s->Hpp[(size_t)i * s->n6 + i])); s->s2p[i] = q * q; }   /* EstimateScale */
+    for (int l = 0; l < s->Nl; ++l) { static const int dq[3] = { 0, 3, 5 }; for (int c = 0; c < 3; ++c) { const double q = 1.0 / (1.0 + sqrt(s->Hll[6 * l + dq[c]])); s->s2l[3 * l + c] = q * q; } }
+    ceres_tr t;
+    ceres_tr_init(&t, 0.5 * chi, sqrt(ceres_x_norm2(s, s->pose, s->pt)));
+    if (max_it <= 0) { t.done = 1; t.reason = 1; }             /* the first FinalizeIteration... sees iteration 0 >= max_num_iterations */
+    else if (ceres_grad_max(s) <= 1e-10) { t.done = 1; t.reason = 2; }
+    while (!t.done) {
+        t.iter++;
+        ceres_multipliers(s);
+        int pit = 0;
+        int ok = schur_solve(s, 1.0 / t.radius, &pit);
+        st->trials_run[0]++;
+        if (ok && !step_is_finite(s)) ok = 0;
+        double mcc = 0.0, cand = 0.0, step_norm = 0.0;
+        if (ok) mcc = 0.5 * compute_scale(s, 1.0 / t.radius);  /* = step^T b - step^T H step / 2 with (H + D) step = b */
+        if (ok && mcc > 0.0) {
+            apply_update(s);                                   /* Plus: t + dt, (deltaQ(dtheta) * q).normalized() (LocalParameterization.cpp:10-24) */
+            cand = 0.5 * active_robust_chi2(s, s->pose_trial, s->pt_trial, 0);
+            step_norm = sqrt(ceres_step_norm2(s));
+        }
+        const int accepted = ceres_tr_step(&t, ok, mcc, cand, step_norm);
+        double gmax = 0.0, xn = t.x_norm;
+        if (accepted) {
+            sys_commit(s);
+            xn = sqrt(ceres_x_norm2(s, s->pose, s->pt));
+            oracle_sys_linearize(s, &chi, &md);
+            gmax = ceres_grad_max(s);
+        }
+        if (st->n_trace < VISFS_BA_MAX_TRACE) { st->trace_lambda[st->n_trace] = t.radius; st->trace_chi2[st->n_trace] = 2.0 * t.cost; st->n_trace++; }
+        ceres_tr_finalize(&t, max_it, accepted, gmax, xn);
+    }
+    st->iterations_run[0] = t.iter;
+    s->prm.solver = saved_solver;
+    for (int i = 0; i < 3 * s->Nl; ++i) s->ml[i] = 1.0;
+    for (int i = 0; i < s->n6; ++i) s->mp[i] = 1.0;
+    /* :529-540: every stereo residual block (both-constant ones included), error . (pixelInfo error) > delta, unsquared */
+    const double chi_final = active_robust_chi2(s, s->pose, s->pt, 0);
+    st->chi2_phase1 = st->chi2_final = chi_final;
+    const double iv = 1.0 / s->prm.pixel_variance;
+    int n_out = 0;
+    for (int k = 0; k < s->No; ++k) {
+        double e[3];
+        oracle_stereo_edge(s->pose + 7 * s->obs_pose[k], s->pt + 3 * s->obs_pt[k], s->obs_uvr + 3 * k, s->intr, e, NULL, NULL);
+        const double c = e[0] * (iv * e[0]) + e[1] * (iv * e[1]) + e[2] * (iv * e[2]);
+        s->final_chi2[k] = c;
+        if (s->prm.robust_kernel_delta > 0.0 && c > s->prm.robust_kernel_delta) { s->outlier[k] = 1; ++n_out; }
+    }
+    st->n_outliers = n_out;
+    return VISFS_BA_OK;
+}
+
+/* The trust-region schedule on SCRIPTED outcomes: iteration t's solve reports (ok[t], model_cost_change[t], cand_cost[t],
+ * step_norm[t]); an accepted step then reports (grad_max[t], x_norm[t]).  Fills trace_lambda (radius after each iteration),
+ * trace_chi2 (2 x cost), iterations_run[0]; returns the termination reason (ceres_tr::reason). */
+int oracle_ceres_script(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc,
+                        const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, visfs_ba_stats* st) {
+    memset(st, 0, sizeof(*st));
+    ceres_tr t;
+    ceres_tr_init(&t, cost0, x_norm0);
+    if (max_iter <= 0) { t.done = 1; t.reason = 1; }
+    else if (grad_max0 <= 1e-10) { t.done = 1; t.reason = 2; }
+    while (!t.done) {
+        const int q = t.iter < n ? t.iter : n - 1;
+        t.iter++;
+        st->trials_run[0]++;
+        const int accepted = ceres_tr_step(&t, ok[q], mcc[q], cand_cost[q], step_norm[q]);
+        if (st->n_trace < VISFS_BA_MAX_TRACE) { st->trace_lambda[st->n_trace] = t.radius; st->trace_chi2[st->n_trace] = 2.0 * t.cost; st->n_trace++; }
+        ceres_tr_finalize(&t, max_iter, accepted, grad_max[q], x_norm[q]);
+    }
+    st->iterations_run[0] = t.iter;
+    st->chi2_final = 2.0 * t.cost;
+    return t.reason;
+}
+
 int oracle_sys_optimize(oracle_sys* s, visfs_ba_stats* st, double* seconds) {
     visfs_ba_stats local;
     if (!st) st = &local;
     memset(st, 0, sizeof(*st));
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (s->ceres) {
+        const int rc = ceres_optimize(s, st);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        st->status = rc;
+        return rc;
+    }
     const int half = s->prm.iterations / 2;
     st->iterations_run[0] = optimize_phase(s, half, st, 0);            /* Optimizer.cpp:265 */
     { int n_ok = 0; for (int k = 0; k < s->No; ++k) n_ok += s->obs_edge_ok[k]; st->n_active_edges[0] = st->n_active_edges[1] = n_ok; }
@@ -1250,8 +1471,8 @@ int oracle_solve_window(const visfs_ba_params* prm, const visfs_ba_window* w, vi
     r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
     r->iterations_run[0] = r->iterations_run[1] = 0;
     r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
-    if (prm->framework != 0) return r->status = VISFS_BA_ERR_UNSUPPORTED;
-    /* guards: Optimizer.cpp:74, 360-364 */
+    if (prm->framework != 0 && prm->framework != 1) return r->status = VISFS_BA_ERR_UNSUPPORTED;
+    /* guards: Optimizer.cpp:74, 360-364 (g2o) and :368, 586-590 (Ceres): the same conditions */
     if (!(w->n_poses >= 2 && prm->iterations > 0 && w->pose_ids[0] > 0)) {
         if (w->n_poses == 1 || prm->iterations <= 0) {
             for (int i = 0; i < w->n_poses; ++i) { r->pose_ids_out[i] = w->pose_ids[i]; memcpy(r->pose_Twr_out + 12 * i, w->pose_Twr + 12 * i, 96); }

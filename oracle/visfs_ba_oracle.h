@@ -88,6 +88,10 @@ int oracle_sys_mark_outliers(oracle_sys* s);
 int oracle_lm_script(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi,
                      const double* scale, const int32_t* ok, visfs_ba_stats* stats);
 
+/* Optimizer/Framework=1: [ceres-upstream] TrustRegionMinimizer + LevenbergMarquardtStrategy on scripted outcomes (see the .c file). */
+int oracle_ceres_script(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc,
+                        const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, visfs_ba_stats* stats);
+
 /* localOptimize-equivalent on host buffers (pack → optimise → write-back). */
 int oracle_solve_window(const visfs_ba_params* params, const visfs_ba_window* w, visfs_ba_result* r, int num_threads);
 

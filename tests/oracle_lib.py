@@ -53,6 +53,9 @@ def load(omp=False):
     lib.oracle_sys_mark_outliers.restype = C.c_int
     lib.oracle_lm_script.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _pd, _pd, C.POINTER(C.c_int32), C.POINTER(abi.Stats)]
     lib.oracle_lm_script.restype = C.c_int
+    _pi = C.POINTER(C.c_int32)
+    lib.oracle_ceres_script.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _pi, _pd, _pd, _pd, _pd, _pd, C.POINTER(abi.Stats)]
+    lib.oracle_ceres_script.restype = C.c_int
     lib.oracle_solve_window.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Window), C.POINTER(abi.Result), C.c_int]
     lib.oracle_solve_window.restype = C.c_int
     return lib

@@ -1,0 +1,146 @@
+"""Optimizer/Framework=1 — the Ceres branch of localOptimize (Optimizer.cpp:366-593) as restated by the CPU oracle.  PARITY UNPINNED:
+the reference holds no test for this path and Ceres is an un-vendored, un-pinned dependency that is not in this image; what can
+be checked without it is checked here — the objective the branch builds (||info e||^2 under HuberLoss, the factor Jacobians of
+StereoObservationFactor.cpp against finite differences of the cost), what the solve does to it (monotone descent to a stationary
+point of THAT objective), and the branch's own rules around the solve (no odometry factors, one pass, the outlier test on
+e . (info e) over every residual block, the write-back)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from helpers import graph_of, hard_window, rel_err
+from visfs_amd import abi, synth
+
+
+def _solve(olib, w, **kw):
+    prm = abi.default_params(framework=1, **kw)
+    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+    o = oracle_lib.OracleSystem(olib, prm, gb)
+    rc, st, _ = o.optimize()
+    return o, gb, rc, st
+
+
+def _cost(olib, gb, pose, pt, pv=1.5, delta=8.0):
+    """0.5 sum rho(||info e||^2), info = I / pixelVariance, in numpy from the oracle's stereo residual (StereoObservationFactor.cpp:12-26)."""
+    intr = np.array([gb.struct.fx, gb.struct.fy, gb.struct.cx, gb.struct.cy, gb.struct.bf])
+    pd = C.POINTER(C.c_double)
+    total = 0.0
+    for k in range(gb.n_obs):
+        ip, l = int(gb.obs_pose[k]), int(gb.obs_point[k])
+        if gb.pose_fixed[ip] and gb.point_fixed[l]:
+            continue
+        e = np.zeros(3)
+        tq = np.ascontiguousarray(pose[ip]); pw = np.ascontiguousarray(pt[l]); uvr = np.ascontiguousarray(gb.obs_uvr[k])
+        olib.oracle_stereo_edge(tq.ctypes.data_as(pd), pw.ctypes.data_as(pd), uvr.ctypes.data_as(pd), intr.ctypes.data_as(pd), e.ctypes.data_as(pd), None, None)
+        s = float(e @ e) / (pv * pv)
+        total += 0.5 * (s if s <= delta * delta else 2.0 * delta * np.sqrt(s) - delta * delta)
+    return total
+
+
+def test_zero_noise_window_converges_at_iteration_zero(olib):
+    w = synth.make_window("custom", n_kf=8, n_lm=120, n_obs=720, noise_px=0.0, outlier_frac=0.0, pose_noise_t=0.0, pose_noise_r=0.0, point_noise=0.0, seed=3)
+    o, gb, rc, st = _solve(olib, w, iterations=10)
+    # float pixel coordinates and depths leave residuals of ~1e-5 px: the cost is tiny, the solve ends within a few iterations
+    assert rc == abi.OK and st.chi2_final <= st.chi2_initial and st.chi2_final < 1e-6 and st.n_outliers == 0
+    o.close()
+
+
+@pytest.mark.parametrize("cfg", ["C1", "PROD"])
+def test_the_solve_descends_to_a_stationary_point_of_the_branch_s_objective(olib, cfg):
+    w = synth.make_window(cfg)
+    o, gb, rc, st = _solve(olib, w, iterations=50)
+    assert rc == abi.OK
+    cost2 = np.array([st.trace_chi2[i] for i in range(st.n_trace)])
+    assert (np.diff(cost2) <= 0).all() and st.chi2_final < 0.2 * st.chi2_initial          # monotonic steps only
+    po, pto, outo, chio = o.download()
+    # the oracle's cost is the numpy restatement's
+    assert abs(0.5 * st.chi2_final - _cost(olib, gb, po, pto)) <= 1e-9 * st.chi2_final
+    # stationarity: central differences of the numpy cost along random tangent directions of the free variables are ~0
+    # compared with their size at the start
+    prm = abi.default_params(framework=1, iterations=50)
+    rng = np.random.default_rng(1)
+    pd = C.POINTER(C.c_double)
+
+    def directional(pose, pt, seed):
+        r = np.random.default_rng(seed)
+        dp = r.normal(size=(gb.n_poses, 6)) * (1 - np.asarray(gb.pose_fixed)[:, None])
+        dl = r.normal(size=(gb.n_points, 3)) * (1 - np.asarray(gb.point_fixed)[:, None])
+        h = 1e-6
+        vals = []
+        for sgn in (+1, -1):
+            P = pose.copy()
+            for i in range(gb.n_poses):
+                tq = np.ascontiguousarray(P[i]); d = np.ascontiguousarray(sgn * h * dp[i])
+                olib.oracle_pose_update(tq.ctypes.data_as(pd), d.ctypes.data_as(pd)); P[i] = tq
+            vals.append(_cost(olib, gb, P, pt + sgn * h * dl))
+        return (vals[0] - vals[1]) / (2 * h)
+    pose0 = np.asarray(gb.pose_tq).reshape(-1, 7).copy(); pt0 = np.asarray(gb.point_xyz).reshape(-1, 3).copy()
+    for seed in range(3):
+        g_start, g_end = directional(pose0, pt0, seed), directional(po, pto, seed)
+        assert abs(g_end) < 1e-4 * abs(g_start), (seed, g_start, g_end)
+    o.close()
+
+
+def test_odometry_links_are_not_part_of_the_ceres_problem(olib):
+    """Optimizer.cpp:405-422: a link between two window poses takes the "TODO" arm; the other arm needs both poses in the window too."""
+    w3 = synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400)
+    assert len(w3["link_from"]) > 0
+    w2 = dict(w3)
+    w2["link_from"] = np.zeros(0, np.uint64); w2["link_to"] = np.zeros(0, np.uint64); w2["link_T"] = np.zeros((0, 12))
+    a = _solve(olib, w2, iterations=10); b = _solve(olib, w3, iterations=10)
+    assert all(np.array_equal(x, y) for x, y in zip(a[0].download(), b[0].download()))
+    a[0].close(); b[0].close()
+
+
+def test_one_pass_and_the_outlier_rule(olib):
+    w = synth.make_window("C1")
+    o, gb, rc, st = _solve(olib, w, iterations=10)
+    assert list(st.iterations_run)[1] == 0 and list(st.trials_run)[1] == 0            # no second optimisation (Optimizer.cpp:527-540)
+    po, pto, out, chi = o.download()
+    # chi = e . (info e) at the final state for EVERY stereo block; outlier <=> chi > delta (unsquared), default delta 8
+    assert np.array_equal(out.astype(bool), chi > 8.0) and st.n_outliers == int(out.sum()) > 0
+    gross = np.asarray(w["gross"]).astype(bool)
+    assert out[gross].mean() > 0.9                                                  # the 10-30 px gross errors are caught
+    o.close()
+    # a both-constant block (fixed landmark seen from the root pose) is tested as well: corrupt one
+    prm = abi.default_params(framework=1, iterations=10)
+    wb, gb, used, oref, mono = graph_of(olib.oracle_pack_window, prm, w)
+    both = [k for k in range(gb.n_obs) if gb.pose_fixed[gb.obs_pose[k]] and gb.point_fixed[gb.obs_point[k]]]
+    assert both
+    gb.obs_uvr[both[0], 0] += 40.0
+    o = oracle_lib.OracleSystem(olib, prm, gb); o.optimize()
+    assert o.download()[2][both[0]] == 1
+    o.close()
+    # delta <= 0: no outlier loop (:529), the loss is still attached
+    o, gb, rc, st = _solve(olib, w, iterations=5, robust_kernel_delta=0.0)
+    assert rc == abi.OK and st.n_outliers == 0
+    o.close()
+
+
+def test_dogleg_is_refused_and_the_solver_id_does_not_matter(olib):
+    w = synth.make_window("C1")
+    o, gb, rc, st = _solve(olib, w, iterations=10, trust_region=1)
+    assert rc == abi.ERR_UNSUPPORTED
+    o.close()
+    ref = None
+    for solver in (0, 1, 2, 3):                                   # DENSE_SCHUR / DENSE_NORMAL_CHOLESKY / DENSE_QR / default: exact dense solves
+        o, gb, rc, st = _solve(olib, w, iterations=10, solver=solver)
+        d = o.download(); o.close()
+        assert rc == abi.OK
+        if ref is None: ref = d
+        assert all(np.array_equal(x, y) for x, y in zip(d, ref))
+
+
+def test_window_level_write_back(olib):
+    w = synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400)
+    w["point_ids"] = np.r_[np.asarray(w["point_ids"]), np.uint64(77777)]       # a point without references → NaN on return (:575-579)
+    w["point_xyz"] = np.vstack([w["point_xyz"], [[1.0, 2.0, 3.0]]]); w["point_fixed"] = np.r_[w["point_fixed"], np.uint8(0)]
+    prm = abi.default_params(framework=1, iterations=10)
+    wb = abi.WindowBuffers(w); rb = abi.ResultBuffers(wb.struct.n_poses, wb.struct.n_refs)
+    rc = olib.oracle_solve_window(C.byref(prm), C.byref(wb.struct), C.byref(rb.struct), 1)
+    assert rc == abi.OK and rb.struct.n_poses_out == 12 and rb.struct.n_outliers > 0
+    assert np.isnan(wb.point_xyz[-1]).all() and np.isfinite(wb.point_xyz[:-1]).all()
+    et, er = synth.pose_errors(rb.pose_Twr_out[:12], np.asarray(w["truth_Twr"]).reshape(-1, 12)[:12])
+    assert et < 0.05 and er < 0.02                                             # the solve pulls the window towards the truth

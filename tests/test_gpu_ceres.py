@@ -1,0 +1,89 @@
+"""Optimizer/Framework=1 on the GPU: the Ceres branch of localOptimize (Optimizer.cpp:366-593) through the HIP path against the CPU
+oracle's restatement of it (tests/test_ceres_flavour.py says what pins that restatement).  Same kernels as the g2o branch — the
+objective differs by the weights (1 / var^2), the damping is LevenbergMarquardtStrategy's per-variable diagonal, the control is
+Ceres' trust-region loop (k_ceres_lin_finalize, ceres_decide) — so the bar is the same: identical iteration / step decisions and
+radius trace, identical outlier sets, poses and landmarks to rounding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from helpers import graph_of, hard_window, ragged_window, rel_err
+from test_gpu_parity import check_optimize, make_pair, solve_both
+from visfs_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["C1", "PROD", "C3s", "LASER", "HARD", "RAGGED", "C2"])
+def test_ceres_branch_matches_the_oracle(olib, case):
+    kw = dict(framework=1, iterations=20 if case != "C2" else 10)
+    if case == "LASER":
+        w = synth.make_laser_window(with_visual=True, n_points=400)
+    elif case == "HARD":
+        w = hard_window()
+    elif case == "RAGGED":
+        w = ragged_window(seed=7)
+    elif case == "C3s":
+        w = synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400)       # its odometry links are not part of the Ceres problem
+    else:
+        w = synth.make_window(case)
+    o, s, gb = make_pair(olib, w, **kw)
+    st = check_optimize(o, s, pose_tol=1e-6)
+    assert st.iterations_run[1] == 0 and st.iterations_run[0] >= 1
+    if case == "HARD":
+        radius = np.array([st.trace_lambda[i] for i in range(st.n_trace)])
+        assert (np.diff(radius) < 0).any()                               # the window really rejects steps
+    a = s.download()
+    s.reset(); s.optimize()
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, s.download()))   # run-to-run bitwise identical
+    s.close(); o.close()
+
+
+def test_ceres_branch_laser_only_window(olib):
+    w = synth.make_laser_window(with_visual=False, n_points=1000)
+    o, s, gb = make_pair(olib, w, framework=1, iterations=10)
+    check_optimize(o, s, pose_tol=1e-6)
+    s.close(); o.close()
+
+
+def test_ceres_branch_window_level_and_batch_entry(olib):
+    from visfs_amd import backend
+    w = synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400)
+    w["point_ids"] = np.r_[np.asarray(w["point_ids"]), np.uint64(77777)]       # a point without references → NaN on return
+    w["point_xyz"] = np.vstack([w["point_xyz"], [[1.0, 2.0, 3.0]]]); w["point_fixed"] = np.r_[w["point_fixed"], np.uint8(0)]
+    rc_o, wb_o, rb_o, rc_g, wb_g, rb_g = solve_both(olib, w, framework=1, iterations=10)
+    assert rc_o == rc_g == abi.OK and rb_g.struct.n_poses_out == rb_o.struct.n_poses_out == 12
+    et, er = synth.pose_errors(rb_g.pose_Twr_out[:12], rb_o.pose_Twr_out[:12])
+    assert et < 1e-6 and er < 1e-6
+    assert rb_g.outliers() == rb_o.outliers() and len(rb_g.outliers()) > 0
+    assert np.isnan(wb_g.point_xyz[-1]).all() and rel_err(wb_g.point_xyz[:-1], wb_o.point_xyz[:-1]) < 1e-6
+    assert list(rb_g.struct.iterations_run) == list(rb_o.struct.iterations_run)
+    # visfs_ba_solve_batch: Ceres-flavour windows are solved one after another, same results
+    prm = abi.default_params(framework=1, iterations=10)
+    s = backend.Solver(prm)
+    ws = [synth.make_window("custom", n_kf=10, n_lm=200, n_obs=1600, seed=60 + i) for i in range(3)]
+    got = s.solve_batch([abi.WindowBuffers(x) for x in ws])
+    for x, r in zip(ws, got):
+        rc1, r1 = s.solve_window(abi.WindowBuffers(x))
+        assert rc1 == abi.OK and r.struct.status == abi.OK
+        assert np.array_equal(r.pose_Twr_out, r1.pose_Twr_out) and r.outliers() == r1.outliers()
+    s.close()
+
+
+def test_ceres_dogleg_is_refused_and_stage_hooks_are_g2o_only(olib):
+    from visfs_amd import backend
+    w = synth.make_window("C1")
+    prm = abi.default_params(framework=1, trust_region=1)
+    s = backend.Solver(prm)
+    rc, rb = s.solve_window(abi.WindowBuffers(w))
+    assert rc == abi.ERR_UNSUPPORTED and rb.struct.n_poses_out == 0
+    s.close()
+    prm = abi.default_params(framework=1)
+    s = backend.Solver(prm)
+    gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s.upload(gb)
+    chi, md = C.c_double(), C.c_double()
+    assert s.lib.visfs_ba_stage_linearize(s.h, C.byref(chi), C.byref(md)) == abi.ERR_UNSUPPORTED
+    s.close()

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_TRACE = 64
 
 # status codes (include/visfs_ba.h)

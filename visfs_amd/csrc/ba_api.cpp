@@ -174,7 +174,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (timing) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "  upload %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
     const visfs_ba_params& prm = h->prm;
-    const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = gr->n_odo;
+    const bool ceres = prm.framework == 1;
+    // (Optimizer.cpp:405-422: the Ceres branch never adds a wheel-odometry factor — links between two window poses fall in its "TODO" arm)
+    const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = ceres ? 0 : gr->n_odo;
     if (Np < 1 || Nl < 0 || No < 0 || Ne < 0) return bad(h, "negative sizes");
     for (int k = 0; k < No; ++k) {
         const int p = gr->obs_point[k], c = gr->obs_pose[k];
@@ -487,6 +489,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.trial_gran = A.take<unsigned long long>((size_t)n_parts * 4);
+        g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.s2p = A.take<double>(std::max<size_t>(n6, 1));
         g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
         g.chol_f = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
         g.chol_y = A.take<double>(chol_np);
@@ -571,10 +575,14 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
+    dg.inv_pixel_var_out = dg.inv_pixel_var;
+    dg.ceres = ceres ? 1 : 0;
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
     dg.huber_delta = prm.robust_kernel_delta;             // Optimizer.cpp:212-216
     dg.Nz = Nz; dg.laser_pose = Nz ? gr->laser_pose : 0;
     dg.inv_laser_cov = 1.0 / prm.laser_covariance;        // Optimizer.cpp:232
+    // Ceres branch: residual = info * e, so the squared norm carries info^2 (StereoObservationFactor.cpp:25-26, OccupiedSpace2dFactor.cpp:45)
+    if (ceres) { dg.inv_pixel_var *= dg.inv_pixel_var; dg.inv_laser_cov *= dg.inv_laser_cov; }
     std::memcpy(dg.Tcr, gr->Tcr, 96);
     if (Nz) { dg.grid.nx = gr->grid->num_x_cells; dg.grid.ny = gr->grid->num_y_cells; dg.grid.resolution = gr->grid->resolution;
               dg.grid.max_x = gr->grid->max_x; dg.grid.max_y = gr->grid->max_y; }
@@ -589,8 +597,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
     // members keep the gated form.
     { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (!w.batch_member && No <= 150000)) && Np <= MAX_STAGED_POSES; }
+    // Optimizer/Framework=1 runs the plain gated unit with the direct solver: one unit = one iteration of Ceres' minimizer loop
+    if (ceres) { w.small_solve = false; w.fused = false; w.spec = false; }
     // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
-    { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = e ? (e[0] != '0') : !w.batch_member; }
+    { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
     w.n_pairs = npairs; w.device_bytes = total_bytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
@@ -598,7 +608,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     HIP_TRY(h, hipMemsetAsync(w.d_base + static_bytes, 0, total_bytes - static_bytes, w.stream));
     if (configure_kernels(w.g) != 0) { h->err = "hipFuncSetAttribute failed"; return VISFS_BA_ERR_DEVICE; }
     launch_build_pairs(w.g, w.stream);                     // the co-observation pair lists never exist on the host
-    launch_reset(w.g, prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
+    launch_reset(w.g, ceres ? prm.iterations : prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
     HIP_TRY(h, hipGetLastError());
     lap("enqueue");
     // no synchronisation here: the launches that follow queue up behind the copy; the pinned staging arena is only reused by the
@@ -622,7 +632,8 @@ int ws_read_state(visfs_ba_handle* h, Workspace& w) {
 // linearises its trial state beside the LM decision (k_linearize spec = 1), so k_decide and its launch leave the critical path.
 void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     if (!w.spec || first) { ProfScope p(w, VISFS_BA_K_LINEARIZE, w.g.Ne == 0 && w.g.Nz == 0); launch_linearize(w.g, w.stream); }
-    if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_lin_finalize(w.g, 0, w.stream); }
+    if (w.g.ceres) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_ceres_lin_finalize(w.g, w.stream); }
+    else if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_lin_finalize(w.g, 0, w.stream); }
     { ProfScope p(w, VISFS_BA_K_SCHUR, true); launch_schur_partial(w.g, w.stream); }
     if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, h->prm.solver, w.stream); }
     else {
@@ -680,7 +691,8 @@ int batch_members_per_launch(visfs_ba_handle* h, const std::vector<Workspace*>& 
 int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
-    const int half = h->prm.iterations / 2;
+    // g2o branch: optimize(iterations / 2) twice (Optimizer.cpp:265,311); Ceres branch: one Solve with max_num_iterations = iterations (:521)
+    const int half = w.g.ceres ? h->prm.iterations : h->prm.iterations / 2;
     std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
     if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lock.lock();   // persistent PCG: one grid at a time per device
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
@@ -700,7 +712,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     // kernels act only when the phase they close is done (LmState::done / ended), so the common solve — no rejected trial beyond
     // the units of its phase — costs ONE state read instead of one per phase (each is a stream drain plus the bubble until the
     // next launches arrive: ~25 us, 5 % of a production-size solve).  Whatever is left is driven from the state that comes back.
-    const int half2 = (h->prm.robust_kernel_delta > 0.0) ? half : 0;                                // :310-311 (gated off on abort)
+    const int half2 = (h->prm.robust_kernel_delta > 0.0 && !w.g.ceres) ? half : 0;                  // :310-311 (gated off on abort); no second pass in the Ceres branch
     auto enqueue_units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { enqueue_unit(h, w, first); first = false; } };
     auto phase_end = [&](int which) {
         ProfScope p(w, VISFS_BA_K_PHASE_END);
@@ -819,6 +831,15 @@ struct PackedWindow {
     int32_t mono = 0;
 };
 
+// Optimizer/Framework (Parameters.h:184): 0 = the g2o branch, 1 = the Ceres branch with its LEVENBERG_MARQUARDT strategy; the DOGLEG
+// strategy (Optimizer/TrustRegion=1 under Framework=1, Optimizer.cpp:515-519) is not implemented.
+static const char* framework_refusal(const visfs_ba_params& prm) {
+    if (prm.framework == 0) return nullptr;
+    if (prm.framework != 1) return "Optimizer/Framework must be 0 (g2o branch) or 1 (Ceres branch)";
+    if (prm.trust_region == 1) return "Optimizer/Framework=1 with Optimizer/TrustRegion=1 (Ceres DOGLEG) is not implemented";
+    return nullptr;
+}
+
 // localOptimize in three steps so that a batch can run the middle one for many windows at once.
 // prepare_window: guards of Optimizer.cpp:74 / :360-364, graph build (:100-223), upload.  Returns 1 when the window is resident and
 // has to be optimised, 0 when `r` is already final (pass-through or refused input).
@@ -827,7 +848,7 @@ int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win,
     r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
     r->iterations_run[0] = r->iterations_run[1] = 0;
     r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
-    if (prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; r->status = VISFS_BA_ERR_UNSUPPORTED; return 0; }
+    if (const char* why = framework_refusal(prm)) { h->err = why; r->status = VISFS_BA_ERR_UNSUPPORTED; return 0; }
     if (win->n_laser_points < 0 || (win->n_laser_points > 0 && win->grid && !win->laser_xyz)) { r->status = bad(h, "laser points without coordinates"); return 0; }
     if (win->n_poses < 0 || win->n_points < 0 || win->n_refs < 0 || win->n_links < 0) { r->status = bad(h, "negative sizes"); return 0; }
     // guards of Optimizer.cpp:74 and :360-364
@@ -1007,6 +1028,9 @@ int visfs_ba_create(const visfs_ba_params* params, int device_index, visfs_ba_ha
             return fail(VISFS_BA_ERR_DEVICE, std::string("device ") + std::to_string(device_index) + " is " + prop.gcnArchName + ": the kernels are built for gfx950 (MI355X) only");
         visfs_ba_handle* h = new visfs_ba_handle();
         h->prm = *params;
+        // the Ceres branch's linear_solver_type values (DENSE_SCHUR / DENSE_NORMAL_CHOLESKY / DENSE_QR, Optimizer.cpp:506-512) all solve the
+        // damped normal equations exactly: one implementation, Schur elimination + the blocked dense Cholesky
+        if (h->prm.framework == 1) h->prm.solver = 0;
         h->device = device_index;
         if (ws_init(h, h->ws) != VISFS_BA_OK) {
             const std::string why = "resource allocation on device " + std::to_string(device_index) + " failed: " + h->err;
@@ -1128,7 +1152,7 @@ void visfs_ba_unpack_pose(const double* tq, const double* Trc, double* Twr_out) 
 
 int visfs_ba_graph_upload(visfs_ba_handle* h, const visfs_ba_graph* g) {
     if (!h || !g) return VISFS_BA_ERR_BAD_ARGUMENT;
-    if (h->prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return VISFS_BA_ERR_UNSUPPORTED; }
+    if (const char* why = framework_refusal(h->prm)) { h->err = why; return VISFS_BA_ERR_UNSUPPORTED; }
     return guarded(h, [&]() { return ws_upload(h, h->ws, g); });
 }
 
@@ -1136,7 +1160,7 @@ int visfs_ba_graph_reset(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
     if (!h->ws.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     HIP_TRY(h, hipSetDevice(h->device));
-    launch_reset(h->ws.g, h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
+    launch_reset(h->ws.g, h->ws.g.ceres ? h->prm.iterations : h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
     HIP_TRY(h, hipGetLastError());
     return VISFS_BA_OK;
 }
@@ -1198,7 +1222,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
         for (int i = 0; i < n; ++i) {
             if (!need[i]) continue;
             const Workspace& ws = *h->batch[i];
-            const bool batchable = batching && (h->prm.solver == 2 || ws.small_solve || ws.fused) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
+            const bool batchable = batching && h->prm.framework == 0 && (h->prm.solver == 2 || ws.small_solve || ws.fused) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
@@ -1231,7 +1255,8 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
 int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* const* graphs) {
     if (!h || n < 0 || (n > 0 && !graphs)) return VISFS_BA_ERR_BAD_ARGUMENT;
     for (int i = 0; i < n; ++i) if (!graphs[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
-    if (h->prm.framework != 0) { h->err = "only Optimizer/Framework=0 (g2o algorithm) is implemented"; return VISFS_BA_ERR_UNSUPPORTED; }
+    if (const char* why = framework_refusal(h->prm)) { h->err = why; return VISFS_BA_ERR_UNSUPPORTED; }
+    if (h->prm.framework == 1) { h->err = "batched launches are implemented for Optimizer/Framework=0 only: solve Ceres-flavour windows one by one (visfs_ba_solve_batch does)"; return VISFS_BA_ERR_UNSUPPORTED; }
     return guarded(h, [&]() -> int {
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         h->n_batch = 0;
@@ -1355,6 +1380,7 @@ int visfs_ba_profile_read(visfs_ba_handle* h, visfs_ba_profile* out) {
 int visfs_ba_graph_free_poses(visfs_ba_handle* h) { return (h && h->ws.loaded) ? h->ws.g.Npf : -1; }
 
 int visfs_ba_stage_linearize(visfs_ba_handle* h, double* robust_chi2, double* max_diag) {
+    if (h && h->prm.framework != 0) { h->err = "the stage hooks step the g2o branch only (Optimizer/Framework=0)"; return VISFS_BA_ERR_UNSUPPORTED; }
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
     Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
@@ -1372,6 +1398,7 @@ int visfs_ba_stage_linearize(visfs_ba_handle* h, double* robust_chi2, double* ma
 }
 
 int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, double* scale, int32_t* pcg_iterations, int32_t* solver_ok) {
+    if (h && h->prm.framework != 0) { h->err = "the stage hooks step the g2o branch only (Optimizer/Framework=0)"; return VISFS_BA_ERR_UNSUPPORTED; }
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
     Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
@@ -1525,6 +1552,15 @@ int visfs_ba_hook_lm_script(int32_t gauss_newton, int32_t n_iter, double chi0, d
     const int used = lm_script_host(gauss_newton, n_iter, chi0, max_diag0, n_trials, temp_chi, scale, ok, &st);
     fill_stats(st, stats);
     return used;
+}
+
+int visfs_ba_hook_ceres_script(int32_t max_iter, double cost0, double x_norm0, double grad_max0, int32_t n, const int32_t* ok, const double* model_cost_change,
+                               const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, visfs_ba_stats* stats) {
+    if (!ok || !model_cost_change || !cand_cost || !step_norm || !grad_max || !x_norm || !stats || n < 1) return VISFS_BA_ERR_BAD_ARGUMENT;
+    LmState st;
+    const int reason = ceres_script_host(max_iter, cost0, x_norm0, grad_max0, n, ok, model_cost_change, cand_cost, step_norm, grad_max, x_norm, &st);
+    fill_stats(st, stats);
+    return reason;
 }
 
 int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {

@@ -76,6 +76,11 @@ struct LmState {
     int32_t ended;          // phase ends applied so far (0, 1, 2): k_eval / k_phase_end act only when the phase they close is done
     int32_t pcg_phase1;     // pcg_total when phase 1 ended
     int32_t n_edges_ok;     // stereo edges that can ever be active (not both ends fixed): the active set of phase 1
+    // Optimizer/Framework=1 ([ceres-upstream] TrustRegionMinimizer + LevenbergMarquardtStrategy): lambda = 1 / tr_radius, ni = the
+    // strategy's decrease factor, current_chi = 2 x cost
+    double tr_radius, tr_x_norm;
+    int32_t tr_invalid;     // consecutive invalid steps
+    int32_t tr_reason;      // why the minimizer stopped: 1 max iterations, 2 gradient, 3 parameter, 4 function tolerance, 5 min radius, 6 invalid steps
     uint32_t decide_epoch;  // tag of the last k_backsub launch that carried the LM decision; never reset (k_reset leaves it): stale
                             // hand-off words of an earlier launch or solve can then never match the tag a launch waits for
 };
@@ -114,6 +119,10 @@ struct DeviceGraph {
     int32_t group;          // lanes per landmark (4/8/16/32/64)
     double fx, fy, cx, cy, bf;
     double inv_pixel_var, inv_odo_cov, huber_delta;
+    // Optimizer/Framework=1 (Ceres branch, Optimizer.cpp:366-593): the residual is info * e with info = I / var, so the objective carries
+    // 1 / var^2 (inv_pixel_var, inv_laser_cov hold the squares then) while the outlier test of :529-540 keeps e . (info e)
+    int32_t ceres;
+    double inv_pixel_var_out;
     // laser occupied-space edges (Optimizer.cpp:224-258): Nz unary edges on pose `laser_pose`; aggregated into slot Ne of odo_blk
     int32_t Nz, laser_pose;
     double inv_laser_cov;
@@ -187,6 +196,10 @@ struct DeviceGraph {
     unsigned long long* granules; // [2][2*6Npf] {epoch:32 | half of a double:32} hand-off words of the persistent PCG
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
+    // Optimizer/Framework=1: Jacobi scaling squared, fixed at iteration zero (k_ceres_lin_finalize): the damping of variable i is
+    // lambda * clamp(H_ii s2_i, 1e-6, 1e32) / s2_i instead of lambda (damp_of)
+    double* s2l;                // [Nl][3]
+    double* s2p;                // [Npf][6]
     unsigned long long* trial_gran; // [n_lin_a + 1][4] the same two sums as {epoch:32 | half:32} hand-off words (k_backsub with the LM decision on board)
     double* chol_f;             // [chol_np][chol_np] the Cholesky factor L (direct solver), separate from the matrix being updated
     double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)

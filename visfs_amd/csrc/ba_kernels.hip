@@ -249,6 +249,19 @@ template <> struct LinSel<Many> {
 };
 
 __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x * (iv * e.x) + e.y * (iv * e.y) + e.z * (iv * e.z); }
+// The robust kernel of a stereo term: g2o's Huber when delta > 0 (Optimizer.cpp:212-216), Ceres' HuberLoss always (:370,469).
+__device__ __forceinline__ void robustify(const DeviceGraph& g, const double c2, const double delta, double& rho0, double& rho1) {
+    if (g.ceres) huber_ceres(c2, delta, rho0, rho1);
+    else robustify(g, c2, delta, rho0, rho1);
+}
+// Damping added to diagonal entry H_ii of variable idx (s2: the Jacobi scaling squared of its block): lambda for g2o's
+// (H + lambda I); for the Ceres flavour lambda * clamp(H_ii s2, 1e-6, 1e32) / s2 — LevenbergMarquardtStrategy's diagonal
+// sqrt(clamp(diag(J'^T J')) / radius) of the column-scaled Jacobian J' = J S, written in the unscaled variables.
+__device__ __forceinline__ double damp_of(const DeviceGraph& g, const double lambda, const double hii, const double* __restrict__ s2, const size_t idx) {
+    if (!g.ceres) return lambda;
+    const double q = s2[idx];
+    return lambda * (fmin(fmax(hii * q, 1e-6), 1e32) / q);
+}
 
 // Upper-triangle index of (r,c), r <= c, in the 21-entry packing used by role B.
 __device__ __forceinline__ int upper_idx(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
@@ -293,7 +306,7 @@ __device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k
     const Vec3 e = stereo_error(T, pw, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
     const double c2 = chi2_of(e, iv);
     double rho0 = c2, rho1 = 1.0;
-    if (delta > 0.0) huber(c2, delta, rho0, rho1);
+    robustify(g, c2, delta, rho0, rho1);
     const double wo = rho1 * iv;
     double Jx[18];
     stereo_jacobian_pose(pc, K, Jx);
@@ -333,7 +346,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
         const double c2 = chi2_of(e, iv);
         const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
         double rho0 = c2, rho1 = 1.0;
-        if (delta > 0.0) huber(c2, delta, rho0, rho1);
+        robustify(g, c2, delta, rho0, rho1);
         L.obs_w[k] = active ? rho1 : 0.0;
         g.obs_chi2[k] = active ? c2 : 0.0;
         if (g.debug) { g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
@@ -455,6 +468,91 @@ __host__ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, c
     }
 }
 
+// ---- Optimizer/Framework=1: [ceres-upstream] TrustRegionMinimizer (Ceres 2.0 / 2.1 control flow) with LevenbergMarquardtStrategy, default
+// Solver::Options except max_num_iterations (Optimizer.cpp:504-527).  One unit of the device state machine = one iteration of the
+// minimizer loop; current_chi = 2 x cost.  solve_ok: the strategy produced a finite step; sc = step^T (D step + b) = 2 x
+// model_cost_change; chi = sum of rho at the candidate; step_norm = ||x - candidate||.  The same function runs on the host under the
+// scripted known-answer tests (visfs_ba_hook_ceres_script).
+__host__ __device__ __forceinline__ void ceres_decide(LmState* st, const bool solve_ok, const double chi, const double sc, const double step_norm) {
+    const int ph = st->phase;
+    st->trials_run[ph] += 1;
+    st->solver_failed = 0;
+    if (solve_ok) st->n_active[3] += 1;
+    st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
+    const double cost = 0.5 * st->current_chi, mcc = 0.5 * sc;
+    bool stop = false, accepted = false;
+    if (!solve_ok || !(mcc > 0.0)) {                                       // step_is_valid = model_cost_change > 0
+        st->tr_invalid += 1;
+        if (st->tr_invalid >= 5) { stop = true; st->tr_reason = 6; }         // max_num_consecutive_invalid_steps
+        else st->tr_radius *= 0.5;                                          // LevenbergMarquardtStrategy::StepIsInvalid
+    } else {
+        st->tr_invalid = 0;
+        double cand = 0.5 * chi;
+        if (!(fabs(cand) <= DBL_MAX)) cand = DBL_MAX;                      // the candidate could not be evaluated
+        const double cost_change = cost - cand;
+        if (step_norm <= 1e-8 * (st->tr_x_norm + 1e-8)) { stop = true; st->tr_reason = 3; }            // ParameterToleranceReached
+        else if (fabs(cost_change) <= 1e-6 * cost) { stop = true; st->tr_reason = 4; }                 // FunctionToleranceReached: the step is not taken
+        else {
+            const double rho = cost_change / mcc;
+            st->rho = rho; st->temp_chi = 2.0 * cand; st->scale = sc;
+            if (rho > 1e-3) {                                                // min_relative_decrease
+                accepted = true;
+                st->current_chi = 2.0 * cand;
+                st->sel ^= 1;                                               // the candidate becomes x
+                st->tr_radius = st->tr_radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
+                st->tr_radius = fmin(1e16, st->tr_radius);
+                st->ni = 2.0;
+            } else {
+                st->tr_radius = st->tr_radius / st->ni;
+                st->ni *= 2.0;
+            }
+        }
+    }
+    st->lambda = 1.0 / st->tr_radius;
+    if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = st->tr_radius; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test of an accepted step follows its linearisation: k_ceres_lin_finalize)
+    if (!stop && st->phase_iter >= st->max_iter) { stop = true; st->tr_reason = 1; }
+    if (!stop && st->tr_radius < 1e-32) { stop = true; st->tr_reason = 5; }
+    if (stop) { st->done = 1; st->mode = 0; }
+    else st->mode = accepted ? (MODE_LIN | MODE_TRIAL) : MODE_TRIAL;
+}
+// A fresh linearisation (iteration zero, or the x an accepted step has produced): cost, ||x||, ||g||_inf; the trust region starts here.
+__host__ __device__ __forceinline__ void ceres_lin_update(LmState* st, const double chi_total, const double grad_max, const double x_norm) {
+    st->current_chi = chi_total;
+    st->tr_x_norm = x_norm;
+    st->max_diag = grad_max;
+    if (st->phase_iter == 0) {
+        st->chi2_initial = chi_total;
+        st->tr_radius = 1e4; st->ni = 2.0; st->tr_invalid = 0; st->tr_reason = 0;     // initial_trust_region_radius
+        st->lambda = 1.0 / st->tr_radius;
+    }
+    if (grad_max <= 1e-10) { st->done = 1; st->mode = 0; st->tr_reason = 2; }          // GradientToleranceReached
+}
+// Does pose ip / landmark l belong to the reduced program (a non-constant parameter block that appears in a residual block)?
+__device__ __forceinline__ bool ceres_pose_in_x(const DeviceGraph& g, const int ip) {
+    const int a = g.pose_free[ip];
+    if (a < 0) return false;
+    return g.chunk_ptr[g.pose_chunk_ptr[a + 1]] > g.chunk_ptr[g.pose_chunk_ptr[a]] || (g.Nz > 0 && g.laser_pose == ip);
+}
+// The k_decide role of the Ceres flavour (256 threads): ||x - candidate|| over the reduced program, then the state machine.
+__device__ __forceinline__ void ceres_decide_role(const DeviceGraph& g, LmState* st, const bool ok, const double chi, const double sc, double* red) {
+    const int tid = threadIdx.x;
+    double n2 = 0.0;
+    if (ok) {
+        for (int t = tid; t < 3 * g.Nl; t += 256) { const double d = g.dxl[t]; n2 += d * d; }       // 0 for constant / unobserved landmarks
+        const double* pa = g.pose[st->sel];
+        const double* pb = g.pose[st->sel ^ 1];
+        for (int t = tid; t < POSE_STRIDE * g.Np; t += 256) {
+            const int ip = t / POSE_STRIDE, c = t % POSE_STRIDE;
+            if (c < 7 && ceres_pose_in_x(g, ip)) { const double d = pb[t] - pa[t]; n2 += d * d; }
+        }
+    }
+    n2 = block_sum_256(n2, red);
+    if (tid != 0) return;
+    const bool finite_step = fabs(n2) <= DBL_MAX;                           // IsArrayValid(step)
+    ceres_decide(st, ok && finite_step, chi, sc, sqrt(n2));
+}
+
 __device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc, false); }
 
 // The k_decide role: 256 threads sum the trial's chi2 / computeScale partials, thread 0 steps the LM state machine.
@@ -466,10 +564,11 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
     double chi = 0.0, sc = 0.0;
     if (ok) {
         for (int w = tid; w < g.n_lin_a + 1; w += 256) { chi += g.trial_part[2 * w]; sc += g.trial_part[2 * w + 1]; }
-        for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (lambda * x + g.bp[t]); }
+        for (int t = tid; t < 6 * g.Npf; t += 256) { const double x = g.x[t]; sc += x * (damp_of(g, lambda, g.Hpp[36 * (size_t)(t / 6) + 7 * (t % 6)], g.s2p, t) * x + g.bp[t]); }
     }
     chi = block_sum_256(chi, red);
     sc = block_sum_256(sc, red);
+    if (g.ceres) { ceres_decide_role(g, st, ok, chi, sc, red); return; }
     if (tid != 0) return;
     lm_decide(st, ok, lambda, chi, sc, spec);
 }
@@ -756,6 +855,27 @@ int lm_script_host(const int gauss_newton, const int n_iter, const double chi0, 
     return pos;
 }
 
+// Test hook (visfs_ba_hook_ceres_script): the Ceres-flavour state machine stepped on the host by the functions the kernels run
+// (ceres_lin_update, ceres_decide), on scripted outcomes: iteration t's solve reports (ok, model_cost_change, candidate cost,
+// ||step||); an accepted step then reports (||g||_inf, ||x||) of its linearisation.
+int ceres_script_host(const int max_iter, const double cost0, const double x_norm0, const double grad_max0, const int n, const int32_t* ok,
+                      const double* mcc, const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, LmState* st) {
+    *st = LmState{};
+    st->ni = 2.0; st->max_iter = max_iter; st->current_chi = 2.0 * cost0;
+    st->done = max_iter <= 0 ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL);
+    if (st->done) st->tr_reason = 1;
+    if (st->mode & MODE_LIN) ceres_lin_update(st, 2.0 * cost0, grad_max0, x_norm0);
+    int pos = 0;
+    for (int guard = 0; st->mode != 0 && guard < 100000; ++guard) {
+        const int q = pos < n ? pos : n - 1;
+        ++pos;
+        ceres_decide(st, ok[q] != 0, 2.0 * cand_cost[q], 2.0 * mcc[q], step_norm[q]);
+        if (st->mode & MODE_LIN) ceres_lin_update(st, st->current_chi, grad_max[q], x_norm[q]);
+    }
+    st->chi2_final = st->current_chi;
+    return st->tr_reason;
+}
+
 // Single workgroup, launched in the FIRST unit of a phase (and by the stage hook): sums Hpp/b_p, reduces the
 // robust chi2 and max|diag H| of the linearisation and does computeLambdaInit ([g2o-upstream] tau = 1e-5).
 // Later units take current_chi from the accepted trial and lambda from k_decide.
@@ -787,6 +907,49 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
         double chi_total = red[0], md_total = red[16];
         for (int w = 1; w < 16; ++w) { chi_total += red[w]; md_total = fmax(md_total, red[16 + w]); }
         lin_finalize_update(st, chi_total, md_total);
+    }
+}
+
+// Optimizer/Framework=1: the tail of EVERY linearisation (iteration zero and after each accepted step).  One workgroup: sums Hpp / b_p,
+// the cost, ||g||_inf and ||x|| of the reduced program; at iteration zero also the Jacobi scaling 1 / (1 + sqrt(H_ii)) of every variable
+// ([ceres-upstream] TrustRegionMinimizer::IterationZero / EstimateScale).
+template <class Src>
+__global__ __launch_bounds__(1024) void k_ceres_lin_finalize(const Src src) {
+    const DeviceGraph& g = graph_of(src);
+    LmState* st = g.st;
+    if (!(st->mode & MODE_LIN)) return;
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
+    __shared__ double red[48];
+    const int tid = threadIdx.x;
+    const bool first = st->phase_iter == 0;
+    double gm = 0.0, chi = 0.0, xn = 0.0;
+    for (int t = tid; t < g.Npf * 42; t += 1024) {
+        const int a = t / 42, q = t % 42;
+        const double v = hpp_entry(g, L, a, q);
+        if (q < 36) { g.Hpp[36 * (size_t)a + q] = v; if (first && q % 7 == 0) { const double s = 1.0 / (1.0 + sqrt(v)); g.s2p[6 * (size_t)a + q / 7] = s * s; } }
+        else { g.bp[6 * (size_t)a + (q - 36)] = v; gm = fmax(gm, fabs(v)); }
+    }
+    for (int t = tid; t < 3 * g.Nl; t += 1024) {
+        const int l = t / 3, c = t % 3;
+        if (g.pt_fixed[l]) continue;
+        gm = fmax(gm, fabs(L.bl[t]));
+        if (first) { const double s = 1.0 / (1.0 + sqrt(L.Hll[6 * (size_t)l + (c == 0 ? 0 : c == 1 ? 3 : 5)])); g.s2l[t] = s * s; }
+        if (g.lm_ptr[l + 1] > g.lm_ptr[l]) { const double v = g.pt[st->sel][t]; xn += v * v; }
+    }
+    for (int t = tid; t < POSE_STRIDE * g.Np; t += 1024) {
+        const int ip = t / POSE_STRIDE, c = t % POSE_STRIDE;
+        if (c < 7 && ceres_pose_in_x(g, ip)) { const double v = g.pose[st->sel][t]; xn += v * v; }
+    }
+    const int nparts = g.n_lin_a + 1;
+    for (int w = tid; w < nparts; w += 1024) chi += g.lin_part[2 * w];
+    const int wave = tid >> 6, lane = tid & 63;
+    chi = wave_sum(chi); xn = wave_sum(xn); gm = wave_max(gm);
+    if (lane == 0) { red[wave] = chi; red[16 + wave] = gm; red[32 + wave] = xn; }
+    __syncthreads();
+    if (tid == 0) {
+        double chi_total = red[0], gm_total = red[16], xn_total = red[32];
+        for (int w = 1; w < 16; ++w) { chi_total += red[w]; gm_total = fmax(gm_total, red[16 + w]); xn_total += red[32 + w]; }
+        ceres_lin_update(st, chi_total, gm_total, sqrt(xn_total));
     }
 }
 
@@ -879,7 +1042,8 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
     tile_core(Tj.R, pb, b1.y, K, Nb);
     double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
     if (have) {
-        h[0] = H[0] + lambda; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + lambda; h[4] = H[4]; h[5] = H[5] + lambda;
+        h[0] = H[0] + damp_of(g, lambda, H[0], g.s2l, 3 * (size_t)pr.z); h[1] = H[1]; h[2] = H[2];
+        h[3] = H[3] + damp_of(g, lambda, H[3], g.s2l, 3 * (size_t)pr.z + 1); h[4] = H[4]; h[5] = H[5] + damp_of(g, lambda, H[5], g.s2l, 3 * (size_t)pr.z + 2);
         if (diag) { const double* Bl = L.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
     }
     double D[6];
@@ -1059,7 +1223,7 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     const bool pin = (nz == 0ull);
     double val = 0.0;
     if (lane < 36) {
-        val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? lambda : 0.0) - part);
+        val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? damp_of(g, lambda, hv, g.s2p, 6 * (size_t)i + r) : 0.0) - part);
         g.S[36 * (size_t)b + lane] = val;
         g.Hpp[36 * (size_t)i + lane] = hv;
     } else if (lane < 42) {
@@ -2118,14 +2282,15 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
     if (lvalid && lfree && any != 0.0) {
         const double* H = L.Hll + 6 * (size_t)l;
         const double* B = L.bl + 3 * (size_t)l;
-        const double h[6] = { H[0] + lambda, H[1], H[2], H[3] + lambda, H[4], H[5] + lambda };
+        const double a0 = damp_of(g, lambda, H[0], g.s2l, 3 * (size_t)l), a1 = damp_of(g, lambda, H[3], g.s2l, 3 * (size_t)l + 1), a2 = damp_of(g, lambda, H[5], g.s2l, 3 * (size_t)l + 2);
+        const double h[6] = { H[0] + a0, H[1], H[2], H[3] + a1, H[4], H[5] + a2 };
         double D[6];
         sym3_inverse(h, D);
         const double c0 = B[0] - t0, c1 = B[1] - t1, c2 = B[2] - t2;
         d0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
         d1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
         d2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
-        if (sub == 0) scale_acc += d0 * (lambda * d0 + B[0]) + d1 * (lambda * d1 + B[1]) + d2 * (lambda * d2 + B[2]);
+        if (sub == 0) scale_acc += d0 * (a0 * d0 + B[0]) + d1 * (a1 * d1 + B[1]) + d2 * (a2 * d2 + B[2]);
     }
     const Vec3 pn{ pw.x + d0, pw.y + d1, pw.z + d2 };         // VertexPointXYZ::oplus
     if (lvalid && sub == 0) {
@@ -2140,7 +2305,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
         const Vec3 e = stereo_error(T, pn, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
         const double c2 = chi2_of(e, iv);
         double rho0 = c2, rho1 = 1.0;
-        if (delta > 0.0) huber(c2, delta, rho0, rho1);
+        robustify(g, c2, delta, rho0, rho1);
         chi_acc += rho0;
     }
 }
@@ -2276,7 +2441,10 @@ __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, con
     } else {
         const int k = bid * 256 + tid;
         if (k < g.No) {
-            const bool active = (g.obs_level[k] == 0) && g.obs_ok[k];
+            // (Ceres flavour, Optimizer.cpp:529-540: EVERY stereo residual block is tested, those between two constant blocks included,
+            // with error . (pixelInfo error) — not the objective's ||info error||^2)
+            const bool in_objective = (g.obs_level[k] == 0) && g.obs_ok[k];
+            const bool active = g.ceres ? true : in_objective;
             double c2 = 0.0;
             if (active) {
                 const int l = g.obs_pt[k];
@@ -2285,8 +2453,9 @@ __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, con
                 const Vec3 e = stereo_error(T, Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] }, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
                 c2 = chi2_of(e, iv);
                 double rho0 = c2, rho1 = 1.0;
-                if (delta > 0.0) huber(c2, delta, rho0, rho1);
-                chi_acc = rho0;
+                robustify(g, c2, delta, rho0, rho1);
+                chi_acc = in_objective ? rho0 : 0.0;
+                if (g.ceres) c2 = chi2_of(e, g.inv_pixel_var_out);
                 if (mark && delta > 0.0 && c2 > delta) { g.obs_level[k] = 1; g.obs_outlier[k] = 1; n_out = 1; }
             }
             if (mark) g.obs_chi2_out[k] = c2;
@@ -2305,7 +2474,8 @@ __device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st,
         st->chi2_phase1 = chi; st->chi2_final = chi;
         st->pcg_phase1 = st->pcg_total;
         if (st->max_iter <= 0) st->chi2_initial = chi;        // optimize(0): nothing linearised
-        if (chi != chi) st->status = 3;                                   // VISFS_BA_ERR_NAN_CHI2
+        if (g.ceres) { }                                                  // the Ceres branch has no chi2 guards (Optimizer.cpp:504-540)
+        else if (chi != chi) st->status = 3;                              // VISFS_BA_ERR_NAN_CHI2
         else if (chi > 1000000000000.0 || !(chi <= DBL_MAX)) st->status = 4; // VISFS_BA_ERR_HUGE_CHI2_1
         st->n_outliers = (int)nout;
         // arm phase 2: initializeOptimization(0) + optimize(iterations/2) re-initialise lambda and the PCG residual
@@ -2315,7 +2485,7 @@ __device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st,
         st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL);
     } else {
         st->chi2_final = chi;
-        if (chi > 1000000000000.0) st->status = 5;                       // VISFS_BA_ERR_HUGE_CHI2_2
+        if (!g.ceres && chi > 1000000000000.0) st->status = 5;           // VISFS_BA_ERR_HUGE_CHI2_2
     }
 }
 
@@ -2360,6 +2530,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         st->done = (max_iter <= 0) ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->solver_failed = 0;
         st->pcg_iter = 0; st->pcg_total = 0; st->gauss_newton = gauss_newton; st->status = 0;
         st->n_outliers = 0; st->n_trace = 0;
+        st->tr_radius = 1e4; st->tr_x_norm = 0.0; st->tr_invalid = 0; st->tr_reason = 0;
         st->iterations_run[0] = st->iterations_run[1] = 0; st->trials_run[0] = st->trials_run[1] = 0;
     }
 }
@@ -2874,7 +3045,7 @@ __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const in
                     const Vec3 e = stereo_error(load_Rt(sRt, g.obs_pose[k]), Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] }, g.obs_uvr[3 * k], g.obs_uvr[3 * k + 1], g.obs_uvr[3 * k + 2], K, pc);
                     c2 = chi2_of(e, iv);
                     double rho0 = c2, rho1 = 1.0;
-                    if (delta > 0.0) huber(c2, delta, rho0, rho1);
+                    robustify(g, c2, delta, rho0, rho1);
                     chi += rho0;
                     if (mark && delta > 0.0 && c2 > delta) { g.obs_level[k] = 1; g.obs_outlier[k] = 1; nout += 1.0; }
                 }
@@ -3002,6 +3173,10 @@ static void launch_lin_finalize_src(const Src& src, int force, int B, hipStream_
     TIMED_LAUNCH((k_lin_finalize<Src>), dim3(1, B), dim3(1024), 0, s, src, force);
 }
 template <class Src>
+static void launch_ceres_lin_finalize_src(const Src& src, int B, hipStream_t s) {
+    TIMED_LAUNCH((k_ceres_lin_finalize<Src>), dim3(1, B), dim3(1024), 0, s, src);
+}
+template <class Src>
 static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     if (d.sch_wgs <= 0) return;
     if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
@@ -3061,6 +3236,7 @@ void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
 void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 0, s); }
 void launch_linearize_decide(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 1, s); }
 void launch_lin_finalize(const DeviceGraph& g, int force, hipStream_t s) { launch_lin_finalize_src(One{ g }, force, 1, s); }
+void launch_ceres_lin_finalize(const DeviceGraph& g, hipStream_t s) { launch_ceres_lin_finalize_src(One{ g }, 1, s); }
 void launch_schur_partial(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_src(One{ g }, dims_of(g), 1, s); }
 void launch_schur_finalize(const DeviceGraph& g, hipStream_t s) { launch_schur_finalize_src(One{ g }, dims_of(g), 1, s); }
 void launch_pcg(const DeviceGraph& g, hipStream_t s) { launch_pcg_src(One{ g }, dims_of(g), 1, s); }

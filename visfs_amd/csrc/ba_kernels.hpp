@@ -28,6 +28,7 @@ void launch_pcg(const DeviceGraph& g, hipStream_t s);                // persiste
 void launch_direct(const DeviceGraph& g, hipStream_t s);             // dense assemble + Cholesky
 void launch_backsub(const DeviceGraph& g, hipStream_t s);
 void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s);   // speculative unit with odometry / laser edges: also linearises them at the trial poses
+void launch_ceres_lin_finalize(const DeviceGraph& g, hipStream_t s);  // Optimizer/Framework=1: cost, ||g||_inf, ||x||, Jacobi scaling after every linearisation
 void launch_backsub_decide(const DeviceGraph& g, hipStream_t s);    // gated unit: the launch also takes the LM decision (no k_decide)
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
@@ -45,6 +46,8 @@ void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s)
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
 void launch_eval_mark(const DeviceGraph& g, hipStream_t s);           // stage hook: outlier pass on the committed estimate, ungated
 // test hook: one phase of the LM state machine on the host, through the functions the kernels run, on scripted trial outcomes
+int ceres_script_host(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc, const double* cand_cost,
+                      const double* step_norm, const double* grad_max, const double* x_norm, LmState* st);
 int lm_script_host(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi, const double* scale, const int32_t* ok, LmState* st);
 
 }  // namespace visfs_ba

@@ -263,6 +263,13 @@ BA_HD void huber(double e2, double delta, double& rho0, double& rho1) {
     if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
     else { const double s = sqrt(e2); rho0 = 2.0 * s * delta - dsqr; rho1 = delta / s; }
 }
+// [ceres-upstream] HuberLoss(a)::Evaluate on s = ||residual||^2: the same function for a > 0; the Ceres branch attaches it whatever
+// robustKernelDelta is (Optimizer.cpp:370,469), so a <= 0 is defined too (rho' clamped to the smallest positive double).
+BA_HD void huber_ceres(double s, double a, double& rho0, double& rho1) {
+    const double b = a * a;
+    if (s > b) { const double r = sqrt(s); rho0 = 2.0 * a * r - b; rho1 = fmax(2.2250738585072014e-308, a / r); }
+    else { rho0 = s; rho1 = 1.0; }
+}
 
 // Inverse of a symmetric 3x3 given as (xx xy xz yy yz zz), cofactor form (Eigen's fixed-size 3x3 inverse).
 BA_HD void sym3_inverse(const double h[6], double o[6]) {
