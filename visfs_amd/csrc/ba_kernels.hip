@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
 // forming both 6x3 tiles.  A lane without a pair (have = false) produces exact zeros.
 // ACC: ADD the contribution to G / gb (a lane's later pairs of a multi-pass chunk) instead of writing it — only the pair's own top
 // half (18 values, which its bottom half is built from) is live beside the accumulators, not a second 36 + 6.
-template <bool ACC>
+template <bool ACC, bool CERES = false>
 __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L, const int4 pr, const bool have, const bool diag, const Rt& Ti, const Rt& Tj,
                                            const double lambda, double G[36], double gb[6]) {
     if (!ACC) {
@@ -1042,8 +1042,10 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
     tile_core(Tj.R, pb, b1.y, K, Nb);
     double h[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 }, B[3] = { 0.0, 0.0, 0.0 };
     if (have) {
-        h[0] = H[0] + damp_of(g, lambda, H[0], g.s2l, 3 * (size_t)pr.z); h[1] = H[1]; h[2] = H[2];
-        h[3] = H[3] + damp_of(g, lambda, H[3], g.s2l, 3 * (size_t)pr.z + 1); h[4] = H[4]; h[5] = H[5] + damp_of(g, lambda, H[5], g.s2l, 3 * (size_t)pr.z + 2);
+        // (the flavour is a template parameter here: as a run-time branch the three dampings cost the VALU-bound gather 3-4 %)
+        double a0 = lambda, a1 = lambda, a2 = lambda;
+        if (CERES) { a0 = damp_of(g, lambda, H[0], g.s2l, 3 * (size_t)pr.z); a1 = damp_of(g, lambda, H[3], g.s2l, 3 * (size_t)pr.z + 1); a2 = damp_of(g, lambda, H[5], g.s2l, 3 * (size_t)pr.z + 2); }
+        h[0] = H[0] + a0; h[1] = H[1]; h[2] = H[2]; h[3] = H[3] + a1; h[4] = H[4]; h[5] = H[5] + a2;
         if (diag) { const double* Bl = L.bl + 3 * (size_t)pr.z; B[0] = Bl[0]; B[1] = Bl[1]; B[2] = Bl[2]; }
     }
     double D[6];
@@ -1090,7 +1092,7 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
 
 // One wavefront, one chunk (<= 64 pairs of one block, MULTI: <= DeviceGraph::sch_chunk): shared by k_schur_partial and the
 // fused small-window kernel.
-template <bool MULTI>
+template <bool MULTI, bool CERES = false>
 __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& L, const int ch, const int lane, const double lambda, const double* __restrict__ pose,
                                             const int4 dsc, const int4 pr) {
     // (dsc = sch_desc[ch] and pr = the lane's first pair come from the caller: neither depends on the LM state, so a kernel can
@@ -1105,14 +1107,14 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     const bool have = e < e_end;
     // pair = (tile of pose i, tile of pose j, landmark): every load below depends only on this one
     double G[36], gb[6];
-    schur_pair<false>(g, L, pr, have, diag, Ti, Tj, lambda, G, gb);
+    schur_pair<false, CERES>(g, L, pr, have, diag, Ti, Tj, lambda, G, gb);
     if (MULTI) {
         // chunks of more than 64 pairs: the lane adds its later pairs (e + 64, e + 128, ...) serially, in that fixed order, so one
         // reduce-scatter serves the whole chunk (the cross-lane reduction costs about as much VALU time as a pair product)
         for (int e2 = e + 64; e2 - lane < e_end; e2 += 64) {
             const bool have2 = e2 < e_end;
             const int4 pr2 = have2 ? g.blk_pairs[e2] : make_int4(0, 0, 0, 0);
-            schur_pair<true>(g, L, pr2, have2, diag, Ti, Tj, lambda, G, gb);
+            schur_pair<true, CERES>(g, L, pr2, have2, diag, Ti, Tj, lambda, G, gb);
         }
     }
     // two halves of 21 sums (block rows 0-2 + b_s 0-2, block rows 3-5 + b_s 3-5): halves the live accumulator registers
@@ -1139,7 +1141,7 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     schur_chunk<MULTI>(g, L, ch, lane, lambda, pose, dsc, e < dsc.y ? g.blk_pairs[e] : make_int4(0, 0, 0, 0));
 }
 
-template <bool MULTI, class Src>
+template <bool MULTI, class Src, bool CERES = false>
 __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src src) {
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     const int4 pr = e0 < dsc.y ? g.blk_pairs[e0] : make_int4(0, 0, 0, 0);
     if (!(st->mode & MODE_TRIAL)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
-    schur_chunk<MULTI>(g, L, ch, lane, st->lambda, g.pose[st->sel], dsc, pr);
+    schur_chunk<MULTI, CERES>(g, L, ch, lane, st->lambda, g.pose[st->sel], dsc, pr);
 }
 
 // k_schur_finalize: one wavefront per stored block:
@@ -2282,7 +2284,8 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
     if (lvalid && lfree && any != 0.0) {
         const double* H = L.Hll + 6 * (size_t)l;
         const double* B = L.bl + 3 * (size_t)l;
-        const double a0 = damp_of(g, lambda, H[0], g.s2l, 3 * (size_t)l), a1 = damp_of(g, lambda, H[3], g.s2l, 3 * (size_t)l + 1), a2 = damp_of(g, lambda, H[5], g.s2l, 3 * (size_t)l + 2);
+        double a0 = lambda, a1 = lambda, a2 = lambda;
+        if (g.ceres) { a0 = damp_of(g, lambda, H[0], g.s2l, 3 * (size_t)l); a1 = damp_of(g, lambda, H[3], g.s2l, 3 * (size_t)l + 1); a2 = damp_of(g, lambda, H[5], g.s2l, 3 * (size_t)l + 2); }
         const double h[6] = { H[0] + a0, H[1], H[2], H[3] + a1, H[4], H[5] + a2 };
         double D[6];
         sym3_inverse(h, D);
@@ -2443,7 +2446,7 @@ __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, con
         if (k < g.No) {
             // (Ceres flavour, Optimizer.cpp:529-540: EVERY stereo residual block is tested, those between two constant blocks included,
             // with error . (pixelInfo error) — not the objective's ||info error||^2)
-            const bool in_objective = (g.obs_level[k] == 0) && g.obs_ok[k];
+            const bool in_objective = g.ceres ? (g.obs_ok[k] != 0) : ((g.obs_level[k] == 0) && g.obs_ok[k]);   // (no levels in the Ceres branch: one pass)
             const bool active = g.ceres ? true : in_objective;
             double c2 = 0.0;
             if (active) {
@@ -3179,6 +3182,11 @@ static void launch_ceres_lin_finalize_src(const Src& src, int B, hipStream_t s) 
 template <class Src>
 static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     if (d.sch_wgs <= 0) return;
+    if (LinSel<Src>::two_sets && graph_of_host(src).ceres) {               // Optimizer/Framework=1: single windows only
+        if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, One, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, One{ graph_of_host(src) });
+        else TIMED_LAUNCH((k_schur_partial<false, One, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, One{ graph_of_host(src) });
+        return;
+    }
     if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
     else TIMED_LAUNCH((k_schur_partial<false, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
 }
