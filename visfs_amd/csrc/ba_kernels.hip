@@ -252,7 +252,7 @@ __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x
 // The robust kernel of a stereo term: g2o's Huber when delta > 0 (Optimizer.cpp:212-216), Ceres' HuberLoss always (:370,469).
 __device__ __forceinline__ void robustify(const DeviceGraph& g, const double c2, const double delta, double& rho0, double& rho1) {
     if (g.ceres) huber_ceres(c2, delta, rho0, rho1);
-    else robustify(g, c2, delta, rho0, rho1);
+    else if (delta > 0.0) huber(c2, delta, rho0, rho1);
 }
 // Damping added to diagonal entry H_ii of variable idx (s2: the Jacobi scaling squared of its block): lambda for g2o's
 // (H + lambda I); for the Ceres flavour lambda * clamp(H_ii s2, 1e-6, 1e32) / s2 — LevenbergMarquardtStrategy's diagonal
