@@ -87,3 +87,27 @@ def test_ceres_dogleg_is_refused_and_stage_hooks_are_g2o_only(olib):
     chi, md = C.c_double(), C.c_double()
     assert s.lib.visfs_ba_stage_linearize(s.h, C.byref(chi), C.byref(md)) == abi.ERR_UNSUPPORTED
     s.close()
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_random_window_matches_oracle_ceres_branch(olib, i):
+    """The random windows of test_gpu_random (ragged tracks, fixed fractions, laser, delta 8 / 2 / 0, iteration caps 2 ... 20) through the
+    Ceres branch at the window level."""
+    from visfs_amd import backend
+    import test_gpu_random as T
+    w, kw = T.random_case(i)
+    prm = abi.default_params(**dict(kw, framework=1, trust_region=0))
+    wb_o, wb_g = abi.WindowBuffers(w), abi.WindowBuffers(w)
+    rb_o = abi.ResultBuffers(wb_o.struct.n_poses, wb_o.struct.n_refs)
+    rc_o = olib.oracle_solve_window(C.byref(prm), C.byref(wb_o.struct), C.byref(rb_o.struct), 1)
+    s = backend.Solver(prm)
+    rc_g, rb_g = s.solve_window(wb_g)
+    s.close()
+    assert rc_g == rc_o and rb_g.struct.n_poses_out == rb_o.struct.n_poses_out
+    assert rb_g.outliers() == rb_o.outliers()
+    assert list(rb_g.struct.iterations_run) == list(rb_o.struct.iterations_run)
+    if rc_o == abi.OK:
+        n = rb_o.struct.n_poses_out
+        et, er = synth.pose_errors(rb_g.pose_Twr_out[:n], rb_o.pose_Twr_out[:n])
+        assert et < 1e-7 and er < 1e-7, (et, er, kw)
+        assert rel_err(wb_g.point_xyz, wb_o.point_xyz) < 1e-6

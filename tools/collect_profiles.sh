@@ -13,6 +13,10 @@ timeout -k 10 400 python3 bench.py > "$OUT/${TAG}_c2_bench.json" 2> "$OUT/${TAG}
 for CFG in C4 C4R; do
   timeout -k 10 300 python3 bench.py --config $CFG --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_$CFG.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
+# Optimizer/Framework=1 (the Ceres branch): C2 and the production window, one pass of <= 20 trust-region iterations
+for CFG in C2 PROD; do
+  timeout -k 10 300 python3 bench.py --config $CFG --framework 1 --steps 20 --warmup 3 > "$OUT/${TAG}_bench_ceres_$CFG.json" 2>> "$OUT/${TAG}_c2_bench.err"
+done
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats_c2" -o c2 -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/${TAG}_c2_bench_under_rocprof.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats_c4r" -o c4r -- python3 "$ROOT/bench.py" --config C4R --steps 6 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_c4r_bench_under_rocprof.json"
