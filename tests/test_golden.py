@@ -11,7 +11,7 @@ from helpers import rel_err
 from visfs_amd import abi, synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith("g2o_"))
+FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith(("g2o_", "ref_ceres_")))
 
 
 def load_case(path):
@@ -64,7 +64,7 @@ def test_hip_matches_golden(path):
 
 # ---------------------------------------------------------------- the g2o cross-check hand-off (tools/g2o_crosscheck.cpp)
 GRAPHS = sorted(glob.glob(os.path.join(HERE, "golden", "graphs", "*.vbag")))
-G2O_FILES = sorted(glob.glob(os.path.join(HERE, "golden", "g2o_*.npz")))
+G2O_FILES = sorted(glob.glob(os.path.join(HERE, "golden", "g2o_*.npz")) + glob.glob(os.path.join(HERE, "golden", "ref_ceres_*.npz")))
 
 
 def test_graph_dumps_are_what_the_tools_generate(hiplib, tmp_path):
@@ -102,8 +102,8 @@ def test_oracle_solves_the_dumped_graphs_and_results_round_trip(olib, path, tmp_
     assert np.array_equal(r["pose_tq"], pose) and np.array_equal(r["point_xyz"], pts) and np.array_equal(r["obs_outlier"], outl)
 
 
-@pytest.mark.skipif(not G2O_FILES, reason="PARITY UNPINNED: no machine with the real g2o has run tools/g2o_crosscheck.cpp on "
-                                          "tests/golden/graphs/*.vbag yet (none in this image or on the GPU box: profiles/r02_probe_box.log)")
+@pytest.mark.skipif(not G2O_FILES, reason="PARITY UNPINNED: no machine with the real g2o / Ceres has run tools/g2o_crosscheck.cpp / ceres_crosscheck.cpp "
+                                          "on tests/golden/graphs/*.vbag yet (neither library is in this image or on the GPU box: profiles/r02_probe_box.log)")
 @pytest.mark.parametrize("path", G2O_FILES, ids=[os.path.basename(f) for f in G2O_FILES])
 def test_oracle_matches_real_g2o_fixture(olib, path):
     """Fixtures imported by tools/g2o_golden_import.py from a run of the real g2o: the oracle must reproduce them."""

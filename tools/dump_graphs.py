@@ -1,6 +1,7 @@
 """Writes the flat factor graphs of the cross-check set as .vbag files (visfs_amd/graphio.py) under tests/golden/graphs/.
 These are INPUTS (synthetic windows of visfs_amd.synth packed by the product's host graph build); a machine with the real g2o
-turns them into .vbar results with tools/g2o_crosscheck.cpp, and tools/g2o_golden_import.py makes fixtures of those."""
+turns them into .vbar results with tools/g2o_crosscheck.cpp (the ceres_* ones: a machine with Ceres <= 2.1, tools/ceres_crosscheck.cpp),
+and tools/g2o_golden_import.py makes fixtures of those."""
 import os
 import sys
 
@@ -20,6 +21,11 @@ CASES = {
     "ragged_odo_pcg": (lambda: ragged_window(seed=7), dict(iterations=20, solver=2)),
     "hard_rejected_steps": (lambda: hard_window(), dict(iterations=20, solver=3)),
     "no_kernel": (lambda: synth.make_window("C1", window_index=1), dict(iterations=10, solver=3, robust_kernel_delta=0.0)),
+    # Optimizer/Framework=1 (the Ceres branch): inputs for tools/ceres_crosscheck.cpp
+    "ceres_c1": (lambda: synth.make_window("C1"), dict(framework=1, iterations=20)),
+    "ceres_prod": (lambda: synth.make_window("PROD"), dict(framework=1, iterations=10)),
+    "ceres_hard_rejected_steps": (lambda: hard_window(), dict(framework=1, iterations=20)),
+    "ceres_ragged": (lambda: ragged_window(seed=7), dict(framework=1, iterations=20, solver=1)),
 }
 
 

@@ -1,5 +1,5 @@
-"""Turns .vbar results of tools/g2o_crosscheck.cpp (the REAL g2o run on tests/golden/graphs/*.vbag) into fixtures
-tests/golden/g2o_<name>.npz with provenance, and reports how far the CPU oracle is from each (the pin the oracle lacks:
+"""Turns .vbar results of tools/g2o_crosscheck.cpp (the REAL g2o run on tests/golden/graphs/*.vbag) — and of tools/ceres_crosscheck.cpp (the REAL
+Ceres on the ceres_*.vbag dumps) — into fixtures tests/golden/g2o_<name>.npz / ref_ceres_<name>.npz with provenance, and reports how far the CPU oracle is from each (the pin the oracle lacks:
 VERDICT r01 "parity unpinned").  tests/test_golden.py::test_g2o_fixtures picks the fixtures up automatically.
 
 usage: python tools/g2o_golden_import.py tests/golden/graphs/*.vbar"""
@@ -22,7 +22,8 @@ def main(paths):
         res = graphio.load_result(p)
         name = os.path.splitext(os.path.basename(p))[0]
         prm, gb = graphio.load_graph(os.path.splitext(p)[0] + ".vbag")
-        out = os.path.join(ROOT, "tests", "golden", f"g2o_{name}.npz")
+        # fixtures of the real libraries: g2o_<name>.npz (tools/g2o_crosscheck.cpp) / ref_ceres_<name>.npz (tools/ceres_crosscheck.cpp)
+        out = os.path.join(ROOT, "tests", "golden", f"ref_{name}.npz" if name.startswith("ceres_") else f"g2o_{name}.npz")
         np.savez_compressed(out, provenance=res["provenance"], graph=name + ".vbag", status=res["status"], iterations_run=res["iterations_run"],
                             n_outliers=res["n_outliers"], chi2=[res["chi2_initial"], res["chi2_phase1"], res["chi2_final"]],
                             pose_tq=res["pose_tq"], point_xyz=res["point_xyz"], obs_outlier=res["obs_outlier"], obs_chi2=res["obs_chi2"])

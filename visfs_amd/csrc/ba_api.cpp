@@ -597,8 +597,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
     // members keep the gated form.
     { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (!w.batch_member && No <= 150000)) && Np <= MAX_STAGED_POSES; }
-    // Optimizer/Framework=1 runs the plain gated unit with the direct solver: one unit = one iteration of Ceres' minimizer loop
-    if (ceres) { w.small_solve = false; w.fused = false; w.spec = false; }
+    // Optimizer/Framework=1 runs the plain gated unit with the direct solver (k_small_solve's Cholesky for reduced systems <= 64 x 64):
+    // one unit = one iteration of Ceres' minimizer loop
+    if (ceres) { w.fused = false; w.spec = false; }
     // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
     { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
     w.n_pairs = npairs; w.device_bytes = total_bytes;

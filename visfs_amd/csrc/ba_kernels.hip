@@ -2825,7 +2825,7 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
         const bool pin = hd[0] == 0.0 && hd[7] == 0.0 && hd[14] == 0.0 && hd[21] == 0.0 && hd[28] == 0.0 && hd[35] == 0.0;
         if (q < 36) {
             const int r = q / 6, c = q - 6 * r;
-            const double val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? lambda : 0.0) - part);
+            const double val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? damp_of(g, lambda, hv, g.s2p, 6 * (size_t)a + r) : 0.0) - part);
             g.S[36 * (size_t)sDiag[a] + q] = val;
             g.Hpp[36 * (size_t)a + q] = hv;
             sA[(6 * a + r) * SM_LD + 6 * a + c] = val;
