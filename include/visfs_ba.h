@@ -197,6 +197,13 @@ int visfs_ba_solve_window(visfs_ba_handle* h, const visfs_ba_window* w, visfs_ba
  * reference solves one window per frame. */
 int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r);
 
+/* BASELINE config 5 inside ONE process: n independent windows over n_handles handles — normally one per GPU of the node.  The
+ * windows are dealt in contiguous blocks, window i to handle i / ceil(n / n_handles) (the partition of SURVEY §8e and of
+ * visfs_amd/dist.py's one-process-per-GPU form); every handle solves its block with visfs_ba_solve_batch on its own host thread.
+ * No data-path exchange between devices: results land in the caller's buffers.  Returns the worst status of the blocks. */
+int visfs_ba_solve_batch_sharded(visfs_ba_handle* const* handles, int32_t n_handles, int32_t n,
+                                 const visfs_ba_window* const* w, visfs_ba_result* const* r);
+
 /* Host-only graph build, exported so that CPU tests can check it without a GPU
  * (Optimizer.cpp:100-223: Twr→Tcw :104-109, link → T_c1c2 :131-140, float
  * disparity :187-188).  Caller allocates: pose_tq[n_poses*7], pose_fixed[n_poses],

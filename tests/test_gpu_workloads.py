@@ -144,3 +144,26 @@ def test_the_three_pcg_kernels_agree(olib, monkeypatch, cfg):
         assert st0.pcg_iterations == st1.pcg_iterations, name
         assert np.array_equal(out0[2], out1[2]), name
         assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10, name
+
+
+def test_batch_sharded_over_handles_equals_one_handle(olib):
+    """visfs_ba_solve_batch_sharded: config 5 inside one process — the windows in contiguous blocks over several handles (one per GPU
+    on a node; two on this one-GPU box), each block solved by visfs_ba_solve_batch on its own host thread.  Results are those of one
+    handle solving all of them, bit for bit; a handle listed twice is refused."""
+    from visfs_amd import backend
+    import ctypes as C
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("custom", n_kf=20, n_lm=500, n_obs=4000, seed=80 + i) for i in range(7)]
+    one = backend.Solver(prm)
+    ref = one.solve_batch([abi.WindowBuffers(w) for w in ws])
+    a, b, c = backend.Solver(prm), backend.Solver(prm), backend.Solver(prm)
+    rc, got = backend.Solver.solve_batch_sharded([a, b, c], [abi.WindowBuffers(w) for w in ws])          # blocks of 3, 3, 1
+    assert rc == abi.OK
+    for x, y in zip(ref, got):
+        assert x.struct.status == y.struct.status == abi.OK
+        assert np.array_equal(x.pose_Twr_out, y.pose_Twr_out) and x.outliers() == y.outliers() and x.struct.chi2_final == y.struct.chi2_final
+    rc, _ = backend.Solver.solve_batch_sharded([a, a], [abi.WindowBuffers(w) for w in ws[:2]])
+    assert rc == abi.ERR_BAD_ARGUMENT
+    rc, got = backend.Solver.solve_batch_sharded([a, b, c], [abi.WindowBuffers(ws[0])])                    # fewer windows than handles
+    assert rc == abi.OK and np.array_equal(got[0].pose_Twr_out, ref[0].pose_Twr_out)
+    for s in (one, a, b, c): s.close()

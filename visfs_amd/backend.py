@@ -24,7 +24,7 @@ EXPORTS = [
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
     "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
-    "visfs_ba_create_error", "visfs_ba_hook_lm_script", "visfs_ba_hook_ceres_script", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
+    "visfs_ba_create_error", "visfs_ba_hook_lm_script", "visfs_ba_hook_ceres_script", "visfs_ba_solve_batch_sharded", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
 ]
 
 _lib = None
@@ -55,6 +55,8 @@ def load_library():
     lib.visfs_ba_solve_window.restype = C.c_int
     lib.visfs_ba_solve_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.Window)), C.POINTER(C.POINTER(abi.Result))]
     lib.visfs_ba_solve_batch.restype = C.c_int
+    lib.visfs_ba_solve_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.POINTER(abi.Window)), C.POINTER(C.POINTER(abi.Result))]
+    lib.visfs_ba_solve_batch_sharded.restype = C.c_int
     lib.visfs_ba_pack_window.argtypes = abi.PACK_ARGTYPES
     lib.visfs_ba_pack_window.restype = C.c_int
     lib.visfs_ba_unpack_pose.argtypes = [_pd, _pd, _pd]
@@ -240,6 +242,17 @@ class Solver:
         if rc in (abi.ERR_DEVICE, abi.ERR_NOT_LOADED):
             self._check(rc, "solve_window")
         return rc, rb
+
+    @staticmethod
+    def solve_batch_sharded(solvers, wbs):
+        """visfs_ba_solve_batch_sharded: the windows in contiguous blocks over the solvers' handles (one per GPU), one host thread each."""
+        n = len(wbs)
+        rbs = [abi.ResultBuffers(w.struct.n_poses, w.struct.n_refs) for w in wbs]
+        wa = (C.POINTER(abi.Window) * n)(*[C.pointer(w.struct) for w in wbs])
+        ra = (C.POINTER(abi.Result) * n)(*[C.pointer(r.struct) for r in rbs])
+        hs = (C.c_void_p * len(solvers))(*[s.h for s in solvers])
+        rc = solvers[0].lib.visfs_ba_solve_batch_sharded(hs, len(solvers), n, wa, ra)
+        return rc, rbs
 
     def solve_batch(self, wbs):
         n = len(wbs)

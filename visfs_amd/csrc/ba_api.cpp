@@ -1252,6 +1252,29 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
     });
 }
 
+int visfs_ba_solve_batch_sharded(visfs_ba_handle* const* handles, int32_t n_handles, int32_t n, const visfs_ba_window* const* w, visfs_ba_result* const* r) {
+    if (!handles || n_handles < 1 || n < 0 || (n > 0 && (!w || !r))) return VISFS_BA_ERR_BAD_ARGUMENT;
+    for (int k = 0; k < n_handles; ++k) if (!handles[k]) return VISFS_BA_ERR_BAD_ARGUMENT;
+    for (int k = 0; k < n_handles; ++k) for (int m = 0; m < k; ++m) if (handles[k] == handles[m]) return VISFS_BA_ERR_BAD_ARGUMENT;   // a handle is not thread-safe
+    if (n == 0) return VISFS_BA_OK;
+    const int per = (n + n_handles - 1) / n_handles;          // contiguous blocks: window i -> handle i / per (visfs_amd/dist.py:shard_windows)
+    std::vector<int> rc(n_handles, VISFS_BA_OK);
+    std::vector<std::thread> th;
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{ th };
+    try {
+        th.reserve(n_handles);
+        for (int k = 0; k < n_handles; ++k) {
+            const int lo = std::min(n, k * per), hi = std::min(n, lo + per);
+            if (lo >= hi) continue;
+            th.emplace_back([&, k, lo, hi]() noexcept { rc[k] = visfs_ba_solve_batch(handles[k], hi - lo, w + lo, r + lo); });
+        }
+    } catch (...) { return VISFS_BA_ERR_DEVICE; }              // thread creation failed: the joiner waits for what was started
+    for (auto& x : th) x.join();
+    int worst = VISFS_BA_OK;
+    for (int k = 0; k < n_handles; ++k) if (rc[k] != VISFS_BA_OK) worst = rc[k];
+    return worst;
+}
+
 // GRAPH layer for a batch: n graphs resident side by side, optimised by one sequence of batched launches (bench config 5).
 int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* const* graphs) {
     if (!h || n < 0 || (n > 0 && !graphs)) return VISFS_BA_ERR_BAD_ARGUMENT;
