@@ -167,3 +167,31 @@ def test_batch_sharded_over_handles_equals_one_handle(olib):
     rc, got = backend.Solver.solve_batch_sharded([a, b, c], [abi.WindowBuffers(ws[0])])                    # fewer windows than handles
     assert rc == abi.OK and np.array_equal(got[0].pose_Twr_out, ref[0].pose_Twr_out)
     for s in (one, a, b, c): s.close()
+
+
+def test_batches_of_sixteen_and_more_use_the_single_workgroup_pcg(olib, monkeypatch):
+    """From 16 windows on, the members of a batch solve their reduced systems with k_pcg_cu (one workgroup per window, no
+    cross-workgroup hand-off: 16 C2 windows 68.0 -> 70.6 k it/s, 32 windows 66.6 -> 74.3 k; 8 windows would lose).  Its mat-vec sums
+    associate differently from k_pcg1's: the batch equals single-window solves to rounding with identical iteration counts and
+    outlier sets; with VISFS_BA_PCG_CU=0 it is bit-identical again."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("custom", n_kf=14, n_lm=300, n_obs=2400, seed=120 + i) for i in range(16)]
+    s = backend.Solver(prm)
+    singles = [s.solve_window(abi.WindowBuffers(w)) for w in ws]
+    got = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    s.close()
+    exact = 0
+    for (rc, a), b in zip(singles, got):
+        assert rc == b.struct.status == abi.OK
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run) and a.outliers() == b.outliers()
+        et, er = synth.pose_errors(b.pose_Twr_out[:14], a.pose_Twr_out[:14])
+        assert et < 1e-9 and er < 1e-9
+        exact += int(np.array_equal(a.pose_Twr_out, b.pose_Twr_out))
+    assert exact < 16                                            # a different kernel really ran
+    monkeypatch.setenv("VISFS_BA_PCG_CU", "0")
+    s = backend.Solver(prm)
+    got0 = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    s.close()
+    for (rc, a), b in zip(singles, got0):
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()

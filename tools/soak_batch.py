@@ -1,5 +1,7 @@
 """Soak: visfs_ba_solve_batch against one visfs_ba_solve_window per window over random windows (tests/test_gpu_random.py's
-generator): every output must be bit-identical — batched launches, per-window gates and the one-read schedule change nothing."""
+generator): every output must be bit-identical — batched launches, per-window gates and the one-read schedule change nothing.
+(Batches of 12 by default: from 16 windows on, the members of a batch run the single-workgroup PCG kernel, whose sums associate
+differently — such batches equal single solves to rounding, tests/test_gpu_workloads.py.)"""
 import os
 import sys
 
@@ -12,7 +14,7 @@ from visfs_amd import abi, backend
 
 
 def main():
-    lo, hi, bsz = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    lo, hi, bsz = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 12
     by_prm = {}
     for i in range(lo, hi):
         try:

@@ -49,6 +49,7 @@ struct Workspace {
     bool loaded = false;
     bool batch_member = false;                     // one of visfs_ba_solve_batch / visfs_ba_batch_upload's windows (shares its launches)
     bool fused = false;                            // the resident window runs on k_small_optimize
+    int batch_hint = 1;                            // windows of the batch this workspace was uploaded for (kernel choices that depend on it)
     bool spec = false;                             // units end with the speculative linearisation + LM decision launch
     bool fused_decide = true;                      // gated units: k_backsub carries the LM decision (VISFS_BA_DECIDE_FUSED=0: k_decide, A/B runs and tests)
     int extra_units[2] = { 0, 0 };                 // rejected trials per phase of the previous solve: units enqueued on top of `half`
@@ -398,8 +399,14 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
             for (int n = row_ptr[a]; n < row_ptr[a + 1]; ++n) pcg1_code[(size_t)a * Npf + row_col[n]] = row_blk[n];
     }
     // k_pcg_cu: the whole PCG in one workgroup when every block row is short enough to sit in registers (3 threads per scalar row)
+    // One window: slower than k_pcg1 (34.7 vs 21.6 us per solve at C2, profiles/r02_pcg_cu_vs_handoff.log).  Many windows sharing every
+    // launch: nothing spins and no hand-off is paid — 16 C2 windows 68.0 -> 70.6 k it/s, 32 windows 66.6 -> 74.3 k, but 8 windows
+    // 58.8 -> 55.6 k (profiles/r02_v3_pcg_cu_batches.log): the default for members of a batch of >= 16 windows; VISFS_BA_PCG_CU=0|1
+    // overrides.  Its mat-vec sums associate differently from k_pcg1's: such a batch agrees with single-window solves to rounding
+    // (same iteration counts: test_the_three_pcg_kernels_agree), not bit for bit like the smaller ones.
     const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
-                                return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && e && e[0] == '1'; }();   // opt-in: measured slower than k_pcg1 for one window (34.7 vs 21.6 us per solve at C2, profiles/r02_pcg_cu_vs_handoff.log)
+                                const bool want = e ? (e[0] == '1') : (w.batch_member && w.batch_hint >= 16);
+                                return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && want; }();
     lap("pair count");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -1191,6 +1198,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
     // stream: their persistent-PCG / panel launches would gain nothing from overlapping and PCG grids must not (pcg_device_mutex).
     return guarded(h, [&]() -> int {
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
+        for (int i = 0; i < n; ++i) h->batch[i]->batch_hint = n;
         const int lanes = std::max(1, std::min<int>(n, 8));
         std::vector<PackedWindow> pk(n);
         std::vector<int> need(n, 0), rcs(n, VISFS_BA_OK);
@@ -1283,6 +1291,7 @@ int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* c
     if (h->prm.framework == 1) { h->err = "batched launches are implemented for Optimizer/Framework=0 only: solve Ceres-flavour windows one by one (visfs_ba_solve_batch does)"; return VISFS_BA_ERR_UNSUPPORTED; }
     return guarded(h, [&]() -> int {
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
+        for (int i = 0; i < n; ++i) h->batch[i]->batch_hint = n;
         h->n_batch = 0;
         for (int i = 0; i < n; ++i) { const int rc = ws_upload(h, *h->batch[i], graphs[i]); if (rc != VISFS_BA_OK) return rc; }
         // the resident batch is reset and optimised on the handle's stream: drain the per-window upload streams once, here
