@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--batch-mode", default="launch", choices=("launch", "streams"),
                     help="--windows-per-gpu > 1: 'launch' = one sequence of batched launches for all resident windows "
                          "(blockIdx.y = window), 'streams' = one host thread + HIP stream per window")
+    ap.add_argument("--handles", type=int, default=1, help="with --windows-per-gpu B > 1 in launch mode: split the B resident windows over this many handles "
+                    "(each its own stream and host thread, B / handles windows sharing every launch of a handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,10 +110,18 @@ def main():
             s.upload(gb)                                                                  # inputs resident in HBM
             solvers.append(s)
             descs.append(s.describe())
+    H = max(1, min(args.handles, B)) if batched else 1
     if batched:
-        solvers[0].batch_upload(gbs)                                                      # all windows resident side by side
+        per = (B + H - 1) // H
+        for k in range(1, H):
+            solvers.append(backend.Solver(prm, device=dev))
+        for k in range(H):
+            solvers[k].batch_upload(gbs[k * per:(k + 1) * per])                           # the handle's windows resident side by side
 
     pool = None
+    if batched and H > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=H)
     if B > 1 and not batched:
         # independent windows: one host thread per resident window, each on its own HIP stream (ctypes drops the GIL),
         # so their kernels overlap on the device — BASELINE config 5 puts 8 windows on every GPU
@@ -127,11 +137,19 @@ def main():
     def step():
         if B == 1:
             return solve_one(solvers[0])
-        if batched:
+        if batched and H == 1:
             solvers[0].batch_reset()
             rc, stats = solvers[0].batch_optimize()
             assert rc == abi.OK, rc
             return sum(st.iterations_run[0] + st.iterations_run[1] for st in stats), stats[0]
+        if batched:
+            def run(s):
+                s.batch_reset()
+                rc, stats = s.batch_optimize()
+                assert rc == abi.OK, rc
+                return sum(st.iterations_run[0] + st.iterations_run[1] for st in stats), stats[0]
+            res = list(pool.map(run, solvers[:H]))
+            return sum(r[0] for r in res), res[0][1]
         res = list(pool.map(solve_one, solvers))
         return sum(r[0] for r in res), res[0][1]
 
@@ -211,7 +229,8 @@ def main():
                    "windows_per_gpu": B, "solver": args.solver, "iterations_per_solve": int(total_iters / (args.steps * world * B)),
                    "pcg_iterations_per_solve": int(last.pcg_iterations) if last is not None else 0,
                    "parallelism": f"{world} rank(s) x {B} independent window(s), no data-path collective"
-                                  + (f"; windows of a rank share every launch (blockIdx.y = window)" if batched else "")},
+                                  + (f"; windows of a rank share every launch (blockIdx.y = window)" if batched else "")
+                                  + (f"; {H} handles (streams / host threads) of {(B + H - 1) // H} windows each" if batched and H > 1 else "")},
         "roofline": roofline,
         "roofline_other_kernels": roofline_kernels,
         "result_gather": gathered,
@@ -250,7 +269,11 @@ def gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_
     the kernels are run-to-run and device-to-device deterministic (fixed-order reductions, no floating-point atomics)."""
     poses = []
     for b in range(B):
-        pose = (solvers[0].batch_download(b) if batched else solvers[b].download())[0]
+        if batched:
+            per = (B + max(1, min(args.handles, B)) - 1) // max(1, min(args.handles, B))     # windows per handle (--handles)
+            pose = solvers[b // per].batch_download(b % per)[0]
+        else:
+            pose = solvers[b].download()[0]
         poses.append(pose)
     local = torch.from_numpy(np.stack(poses, 0))
     if world == 1:

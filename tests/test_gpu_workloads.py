@@ -103,6 +103,40 @@ def test_two_handles_with_persistent_pcg_on_two_threads(olib):
         solvers[k].close()
 
 
+def test_one_wave_pcg_grids_of_two_handles_run_side_by_side(olib):
+    """Grids of the one-wave PCG kernel (k_pcg1: C2-size windows, 49 block rows each) are homogeneous — 1024 of their waves are
+    resident together wherever the dispatcher puts them — so the per-device budget admits them concurrently (two handles, two host
+    threads, two streams: their kernels overlap on the device).  Results must be those of sequential runs, bit for bit, every time."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=20, solver=2)
+    solvers, refs = [], []
+    for i in range(2):
+        s = backend.Solver(prm)
+        gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(synth.make_window("C5", window_index=i)))
+        s.upload(gb)
+        assert s.describe()["n_free_poses"] == 49
+        rc, st = s.optimize()
+        assert rc == abi.OK
+        refs.append(s.download()); solvers.append(s)
+    results = [None, None]
+
+    def run(k):
+        out = []
+        for _ in range(8):
+            solvers[k].reset()
+            rc, st = solvers[k].optimize()
+            out.append((rc, solvers[k].download()))
+        results[k] = out
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(2):
+        for rc, out in results[k]:
+            assert rc == abi.OK and all(np.array_equal(a, b) for a, b in zip(out, refs[k]))
+        solvers[k].close()
+
+
 def test_batch_above_the_residency_cap_splits_and_stays_bit_identical(olib, monkeypatch):
     """A batched launch sequence may carry only as many PCG block rows as the device holds at once (occupancy query x CUs); a
     larger batch is cut into several sequences.  VISFS_BA_PCG_CAPACITY forces a tiny cap: six 29-row windows then run as batches

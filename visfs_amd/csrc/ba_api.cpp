@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -678,9 +679,46 @@ void fill_stats(const LmState& st, visfs_ba_stats* out) {
 // two partially resident grids starve each other until the bounded spins give up (VISFS_BA_ERR_DEVICE).  So every solve that
 // carries a persistent PCG holds this per-device lock from its first launch to its last state read.  Other PROCESSES sharing the
 // GPU are not covered: the library assumes exclusive use of the device for Optimizer/Solver=2 (include/visfs_ba.h).
-std::mutex& pcg_device_mutex(int device) {
-    static std::mutex m[64];
-    return m[(unsigned)device % 64u];
+//
+// Round 2: a budget instead of a mutex.  Grids of the ONE-WAVE kernel (k_pcg1: 64-thread workgroups, no LDS, 248 VGPRs) are
+// homogeneous: every SIMD of the device holds two such waves, so 1024 of them (counted conservatively: one per SIMD) are resident
+// together wherever the dispatcher puts them — several handles / host threads may run such solves side by side as long as their
+// block rows sum to <= 1024 (two 4-window batches of C2 size overlap: the hand-off waits of one hide behind the gathers of the
+// other).  Grids of the four-wave kernel (k_pcg: LDS, one workgroup per CU) stay exclusive: a placement of one-wave grids that
+// fills one SIMD of many CUs could otherwise keep a four-wave workgroup from ever fitting.
+struct PcgBudget { std::mutex m; std::condition_variable cv; int used = 0; static constexpr int CAP = 1024; };
+PcgBudget& pcg_device_budget(int device) {
+    static PcgBudget b[64];
+    return b[(unsigned)device % 64u];
+}
+class PcgLease {
+public:
+    PcgLease() = default;
+    PcgLease(const PcgLease&) = delete;
+    PcgLease& operator=(const PcgLease&) = delete;
+    ~PcgLease() { release(); }
+    void acquire(int device, int cost) {                       // cost <= 0 or > CAP: exclusive
+        b_ = &pcg_device_budget(device);
+        cost_ = (cost <= 0 || cost > PcgBudget::CAP) ? PcgBudget::CAP : cost;
+        std::unique_lock<std::mutex> lk(b_->m);
+        b_->cv.wait(lk, [&]() { return b_->used + cost_ <= PcgBudget::CAP; });
+        b_->used += cost_;
+    }
+    void release() {
+        if (!b_) return;
+        { std::lock_guard<std::mutex> lk(b_->m); b_->used -= cost_; }
+        b_->cv.notify_all();
+        b_ = nullptr;
+    }
+private:
+    PcgBudget* b_ = nullptr;
+    int cost_ = 0;
+};
+// Wavefront slots a solve's persistent PCG grid needs (0: exclusive use of the budget).
+static int pcg_wave_cost(const LaunchDims& d, int members) {
+    static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 1; }();
+    if (!d.pcg_one_wave || gv == 3) return 0;                  // four-wave kernel (or the 8x grid of the XCD-local variant): exclusive
+    return d.pcg_rows * std::max(1, members);
 }
 
 // Members of one batched launch sequence: rows x members workgroups of the persistent PCG must be resident together.
@@ -701,8 +739,8 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     // g2o branch: optimize(iterations / 2) twice (Optimizer.cpp:265,311); Ceres branch: one Solve with max_num_iterations = iterations (:521)
     const int half = w.g.ceres ? h->prm.iterations : h->prm.iterations / 2;
-    std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
-    if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lock.lock();   // persistent PCG: one grid at a time per device
+    PcgLease pcg_lease;                                                                         // persistent PCG: co-residency budget of the device
+    if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lease.acquire(h->device, pcg_wave_cost(dims_of(w.g), 1));
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
     { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     if (w.fused) {
@@ -959,8 +997,8 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         d = dims_max(d, dims_of(w.g));
         fused = fused && w.fused; small_solve = small_solve && w.small_solve; fused_decide = fused_decide && w.fused_decide;
     }
-    std::unique_lock<std::mutex> pcg_lock(pcg_device_mutex(h->device), std::defer_lock);
-    if (!fused && !small_solve && !d.pcg_cu) pcg_lock.lock();                       // persistent PCG: one grid at a time per device
+    PcgLease pcg_lease;                                                                // persistent PCG: co-residency budget of the device
+    if (!fused && !small_solve && !d.pcg_cu && h->prm.solver == 2) pcg_lease.acquire(h->device, pcg_wave_cost(d, B));
     HIP_TRY(h, hipMemcpyAsync(bs.d_graphs, hg.data(), (size_t)B * sizeof(DeviceGraph), hipMemcpyHostToDevice, stream));
     const int half = h->prm.iterations / 2;
     launch_reset_batch(bs.d_graphs, B, d, half, h->prm.trust_region == 1, 0, stream);
@@ -1195,7 +1233,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
     // threads, one workspace per window; the optimisation itself is ONE sequence of launches per group of windows with the
     // same launch-geometry class, blockIdx.y = window (batch_optimize).  Windows that cannot share launches (direct solver on
     // reduced systems above 64 x 64, or VISFS_BA_BATCH=0) are optimised one after another on the calling thread, each on its own
-    // stream: their persistent-PCG / panel launches would gain nothing from overlapping and PCG grids must not (pcg_device_mutex).
+    // stream: their persistent-PCG / panel launches would gain nothing from overlapping and PCG grids must fit the device together (PcgLease).
     return guarded(h, [&]() -> int {
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         for (int i = 0; i < n; ++i) h->batch[i]->batch_hint = n;
