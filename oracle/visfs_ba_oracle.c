@@ -377,7 +377,14 @@ static void laser_functor(const jet6 pose[7], const double P[3], const double Tc
  * coordinate of the range point.  The Jacobian the reference uses is that of the functor with q.w := point.x (no
  * normalisation), taken w.r.t. (t, qx, qy, qz) and fed to the 6-dof oplus as is.  Reproduced here; the error itself
  * (computeError) uses the true 7-vector. */
+static void laser_edge_impl(const double tq[7], const double Tcr[12], const double P[3], const visfs_ba_grid* g, double* e, double J[6], int true_w);
 void oracle_laser_edge(const double tq[7], const double Tcr[12], const double P[3], const visfs_ba_grid* g, double* e, double J[6]) {
+    laser_edge_impl(tq, Tcr, P, g, e, J, 0);
+}
+/* true_w: the Ceres factor (OccupiedSpace2dFactor.cpp:22-49, :93-97): AutoDiffCostFunction<..., DYNAMIC, 7> differentiates the same
+ * functor over the FULL pose, q.w included, and PoseLocalParameterization's [I6; 0] Jacobian then drops the q.w column — the first six
+ * partials with the pose's own q.w, no aliasing. */
+static void laser_edge_impl(const double tq[7], const double Tcr[12], const double P[3], const visfs_ba_grid* g, double* e, double J[6], int true_w) {
     jet6 pose[7], r, c;
     if (e) {
         for (int i = 0; i < 7; ++i) pose[i] = jc(tq[i]);
@@ -386,7 +393,7 @@ void oracle_laser_edge(const double tq[7], const double Tcr[12], const double P[
     }
     if (J) {
         for (int i = 0; i < 6; ++i) { pose[i] = jc(tq[i]); pose[i].v[i] = 1.0; }
-        pose[6] = jc(P[0]);                                               /* the aliasing described above */
+        pose[6] = jc(true_w ? tq[6] : P[0]);                              /* the aliasing described above (g2o edge only) */
         laser_functor(pose, P, Tcr, g, &r, &c);
         double f, dfdr, dfdc;
         oracle_bicubic(g, r.a, c.a, &f, &dfdr, &dfdc);
@@ -810,7 +817,7 @@ void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag) 
     const double inv_laser = s->w_laser;
     for (int k = 0; k < s->Nz; ++k) {
         double e, J[6];
-        oracle_laser_edge(s->pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, J);
+        laser_edge_impl(s->pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, J, s->ceres);
         const int a = s->pose_idx[s->laser_pose];
         hpp_add(s, a, a, J, J, 1, inv_laser);
         for (int r = 0; r < 6; ++r) s->bp[6 * a + r] -= J[r] * inv_laser * e;

@@ -144,3 +144,36 @@ def test_window_level_write_back(olib):
     assert np.isnan(wb.point_xyz[-1]).all() and np.isfinite(wb.point_xyz[:-1]).all()
     et, er = synth.pose_errors(rb.pose_Twr_out[:12], np.asarray(w["truth_Twr"]).reshape(-1, 12)[:12])
     assert et < 0.05 and er < 0.02                                             # the solve pulls the window towards the truth
+
+
+def test_laser_factor_gradient_is_the_ceres_factor_s(olib):
+    """OccupiedSpace2dFactor.cpp:22-49, :93-97: AutoDiffCostFunction<..., DYNAMIC, 7> differentiates the functor over the full pose
+    (t, qx, qy, qz, qw) and PoseLocalParameterization's [I6; 0] Jacobian keeps the first six columns — partials with respect to the
+    RAW parameters t and (qx, qy, qz) at the pose's own q.w, not the g2o edge's aliased q.w := point.x (a15).  Checked against central
+    differences of the branch's cost (sum of (info * interp)^2) over those raw parameters."""
+    w = synth.make_laser_window(with_visual=False, n_points=600, seed=4)
+    prm = abi.default_params(framework=1, iterations=5)
+    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+    o = oracle_lib.OracleSystem(olib, prm, gb)
+    chi0, _ = o.linearize()
+    bp = o.fetch(abi.BUF_BP).copy()
+    o.close()
+    ip = int(gb.struct.laser_pose)
+    a = int(np.sum(1 - np.asarray(gb.pose_fixed)[:ip]))                   # free index of the laser pose
+    base = np.asarray(gb.pose_tq).reshape(-1, 7).copy()
+    for i in range(6):
+        h = 2e-5                                                          # (the grid holds float costs: smaller steps drown in cancellation noise)
+        vals = []
+        for sgn in (+1, -1):
+            gb.pose_tq.reshape(-1, 7)[:] = base
+            gb.pose_tq.reshape(-1, 7)[ip, i] += sgn * h
+            o = oracle_lib.OracleSystem(olib, prm, gb)
+            vals.append(o.linearize()[0]); o.close()
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - (-2.0 * bp[6 * a + i])) <= 1e-4 * 2.0 * np.abs(bp).max(), (i, fd, -2.0 * bp[6 * a + i])       # (1e-4 of the gradient's size)
+    gb.pose_tq.reshape(-1, 7)[:] = base
+    # the g2o branch's edge on the same window does NOT have that property (weights: 1 / laserCovariance there, its square here: x 10)
+    prm0 = abi.default_params(framework=0, iterations=5, solver=0)
+    o = oracle_lib.OracleSystem(olib, prm0, gb); o.linearize(); bp0 = o.fetch(abi.BUF_BP).copy(); o.close()
+    # (its Jacobian is that of the functor with q.w := point.x, which changes the un-normalised rotation matrix and with it every column)
+    assert np.abs(bp0[6 * a:6 * a + 6] * 10.0 - bp[6 * a:6 * a + 6]).max() > 0.1 * np.abs(bp[6 * a:6 * a + 6]).max()

@@ -748,7 +748,7 @@ __device__ __forceinline__ double laser_point_terms(const DeviceGraph& g, const 
     const Vec3 P{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] };
     const double e = laser_error(tq, g.Tcr, P, g.grid);
     double J[6];
-    laser_jacobian(tq, g.Tcr, P, g.grid, J);
+    laser_jacobian(tq, g.Tcr, P, g.grid, J, g.ceres != 0);
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)

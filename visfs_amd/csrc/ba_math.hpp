@@ -432,9 +432,12 @@ BA_HD double laser_error(const double* tq, const double* Tcr, const Vec3& P, con
 // the pose block carries six jets (t, qx, qy, qz), so the functor's pose[6] aliases the first coordinate of the range
 // point.  Its Jacobian is therefore that of the functor with q.w := P.x, w.r.t. (t1 t2 t3 qx qy qz), evaluated at the
 // grid position that aliased pose maps to.  Reproduced analytically: Po = R^T m, dPo/dt = -R^T, dPo/dq = (dR^T/dq) m.
-BA_HD void laser_jacobian(const double* tq, const double* Tcr, const Vec3& P, const GridView& g, double J[6]) {
+// true_w: differentiate with the pose's own q.w (the Ceres factor: AutoDiffCostFunction<..., 7> over the full pose, then the
+// [I6; 0] Jacobian of PoseLocalParameterization drops the q.w column, OccupiedSpace2dFactor.cpp:93-97) instead of the g2o edge's
+// aliased value (TypeOccupiedSpace2D.h: the six-jet block makes the functor's pose[6] read the range point's x).
+BA_HD void laser_jacobian(const double* tq, const double* Tcr, const Vec3& P, const GridView& g, double J[6], const bool true_w = false) {
     double r, c, f, dfdr, dfdc; Mat3 R; Vec3 m;
-    const double w = P.x;
+    const double w = true_w ? tq[6] : P.x;
     laser_grid_coords(tq, w, Tcr, P, g, r, c, R, m);
     bicubic(g, r, c, f, dfdr, dfdc);
     const double x = tq[3], y = tq[4], z = tq[5];
