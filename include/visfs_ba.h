@@ -157,7 +157,10 @@ typedef struct visfs_ba_graph {
     double Tcr[12];               /* transformRobotToImage_ = getTansformImageToRobot().inverse() (TypeOccupiedSpace2D.h:81-82) */
 } visfs_ba_graph;
 
-/* Per-solve statistics of the two optimise phases (Optimizer.cpp:261-318). */
+/* Per-solve statistics of the two optimise phases (Optimizer.cpp:261-318).
+ * Optimizer/Framework=1 (the Ceres branch, one ceres::Solve): iterations_run[0] = passes of the minimizer loop (successful, unsuccessful
+ * and invalid steps alike, as Solver::Summary::iterations counts them), trials_run[0] = linear solves, [1] = 0; chi2_* = 2 x cost (the sum
+ * of rho over the residual blocks), chi2_phase1 = chi2_final; trace_lambda = the trust-region radius after each iteration. */
 #define VISFS_BA_MAX_TRACE 64
 typedef struct visfs_ba_stats {
     int32_t status;
