@@ -207,7 +207,9 @@ def main():
         avg_us = 1e3 * p["active_ms"] / p["active_launches"]
         byts = algorithmic_bytes(kernel, d)
         achieved = byts / (avg_us * 1e-6) / 1e9
-        return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+        symbol = {1: "k_pcg1", 2: "k_pcg", 3: "k_pcg", 4: "k_pcg_cu", 5: "k_small_solve", 6: "k_chol_update + k_chol_solve + ..."}.get(d.get("solver_kernel"), kernel) \
+            if kernel in ("k_pcg", "k_direct") else kernel
+        return {"bound": "hbm", "kernel": kernel, "kernel_symbol": symbol, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(args.config, kernel), "bytes_per_launch": byts,
                 "avg_launch_us": round(avg_us, 3), "event_pair_null_us": round(null_us, 3), "launches": p["active_launches"]}
 

@@ -1401,7 +1401,8 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     out->n_poses = w.g.Np; out->n_free_poses = w.g.Npf; out->n_points = w.g.Nl; out->n_obs = w.g.No; out->n_odo = w.g.Ne;
     out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->n_schur_chunks = w.g.n_sch;
     out->device_bytes = (int64_t)w.device_bytes;
-    out->fused_path = w.fused ? 1 : 0; out->reserved = 0;
+    out->fused_path = w.fused ? 1 : 0;
+    out->solver_kernel = w.small_solve ? 5 : h->prm.solver != 2 ? 6 : w.g.pcg_cu ? 4 : w.g.pcg1_code ? 1 : w.g.Npf > MAX_PCG_ONE_ROW_POSES ? 3 : 2;
     return VISFS_BA_OK;
 }
 
