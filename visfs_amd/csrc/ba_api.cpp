@@ -128,8 +128,8 @@ struct visfs_ba_handle {
     std::vector<Workspace*> batch;
     int n_batch = 0;                               // graphs resident through visfs_ba_batch_upload
     BatchScratch scratch;
-    BatchScratch scratch2;                         // second half of a split batch (batch_optimize_group)
-    hipStream_t stream2 = nullptr;
+    std::vector<BatchScratch> part_scratch;        // further parts of a split batch (batch_optimize_group): scratch and stream of part k + 1
+    std::vector<hipStream_t> part_stream;
 };
 
 namespace {
@@ -1040,40 +1040,60 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     return VISFS_BA_OK;
 }
 
-// One group of windows that share launches.  8 to 15 members under the one-wave PCG (from 16 on the group runs k_pcg_cu, which has no
-// hand-off to hide) are cut into two halves that run side by side — second stream, second host thread, both within the device's
-// co-residency budget — so that the hand-off waits of one half hide behind the gathers of the other: 8 C2 windows 58.7 -> 61.6 k it/s
-// when driven as two handles (bench.py --handles 2).  No result depends on how a batch is cut (every member's solve
+// One group of windows that share launches.  Groups of 8 and more members (PCG kernels k_pcg1 or k_pcg_cu) are cut into two halves
+// that run side by side — second stream, second host thread, both within the device's co-residency budget — so that the
+// latency-bound stretches of one half (PCG hand-offs, launch ramps) hide behind the gathers of the other: 8 C2 windows 58.7 -> 61.3 k
+// it/s, 16 windows (k_pcg_cu) 70.5 -> 75.1 k, 32 windows 73.8 -> 77.6 k (bench.py --handles 2 shows the same from outside).  No result depends on how a batch is cut (every member's solve
 // is bit-identical to its single-window solve).  VISFS_BA_BATCH_SPLIT=0 keeps one sequence.
 int batch_optimize_group(visfs_ba_handle* h, const std::vector<int>& members) {
-    static const bool split_on = []() { const char* e = std::getenv("VISFS_BA_BATCH_SPLIT"); return !(e && e[0] == '0'); }();
+    static const int parts_env = []() { const char* e = std::getenv("VISFS_BA_BATCH_SPLIT"); return e ? std::atoi(e) : -1; }();   // 0 / 1: one sequence; n: n parts
     const int B = (int)members.size();
-    bool one_wave = h->prm.solver == 2;
-    for (int i : members) { const Workspace& w = *h->batch[i]; one_wave = one_wave && w.g.pcg1_code && !w.g.pcg_cu && !w.small_solve && !w.fused; }
-    if (!split_on || !one_wave || B < 8) return batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
+    bool one_wave = h->prm.solver == 2, one_cu = h->prm.solver == 2;      // every member on k_pcg1 / every member on k_pcg_cu
+    for (int i : members) {
+        const Workspace& w = *h->batch[i];
+        one_wave = one_wave && w.g.pcg1_code && !w.g.pcg_cu && !w.small_solve && !w.fused;
+        one_cu = one_cu && w.g.pcg_cu && !w.small_solve && !w.fused;
+    }
+    int K = parts_env >= 0 ? parts_env : 2;
+    K = std::min(K, B / 4);                                     // at least four windows per part
+    if (K < 2 || !(one_wave || one_cu) || B < 8) return batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    HIP_TRY(h, hipStreamSynchronize(h->ws.stream));           // a batch reset queued on the handle's stream precedes both halves
-    const std::vector<int> first(members.begin(), members.begin() + (B + 1) / 2), second(members.begin() + (B + 1) / 2, members.end());
-    int rc2 = VISFS_BA_OK;
-    std::string err2;
-    std::thread t;
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{ t };
+    while ((int)h->part_stream.size() < K - 1) {
+        hipStream_t st = nullptr;
+        HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->part_stream.push_back(st);
+        h->part_scratch.emplace_back();
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->ws.stream));           // a batch reset queued on the handle's stream precedes every part
+    const int per = (B + K - 1) / K;
+    std::vector<std::vector<int>> part(K);
+    for (int k = 0; k < K; ++k) part[k].assign(members.begin() + std::min(B, k * per), members.begin() + std::min(B, (k + 1) * per));
+    std::vector<int> rc(K, VISFS_BA_OK);
+    std::vector<std::string> errs(K);
+    std::vector<std::thread> th;
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{ th };
     try {
-        t = std::thread([&]() noexcept {
-            try {
-                (void)hipSetDevice(h->device);
-                visfs_ba_handle local;                            // per-thread error string; shares params / device
-                local.prm = h->prm; local.device = h->device;
-                rc2 = batch_optimize(&local, h->scratch2, h->batch, second, h->stream2);
-                err2 = local.err;
-            } catch (...) { rc2 = VISFS_BA_ERR_DEVICE; }
-        });
-    } catch (...) { return batch_optimize(h, h->scratch, h->batch, members, h->ws.stream); }     // no second thread: one sequence
-    const int rc1 = batch_optimize(h, h->scratch, h->batch, first, h->ws.stream);
-    t.join();
-    if (rc1 == VISFS_BA_OK && rc2 != VISFS_BA_OK && !err2.empty()) h->err = err2;
-    return rc1 != VISFS_BA_OK ? rc1 : rc2;
+        th.reserve(K - 1);
+        for (int k = 1; k < K; ++k) {
+            if (part[k].empty()) continue;
+            th.emplace_back([&, k]() noexcept {
+                try {
+                    (void)hipSetDevice(h->device);
+                    visfs_ba_handle local;                        // per-thread error string; shares params / device
+                    local.prm = h->prm; local.device = h->device;
+                    rc[k] = batch_optimize(&local, h->part_scratch[k - 1], h->batch, part[k], h->part_stream[k - 1]);
+                    errs[k] = local.err;
+                } catch (...) { rc[k] = VISFS_BA_ERR_DEVICE; }
+            });
+        }
+    } catch (...) {                                             // a thread could not be started: the joiner waits for the others, then one sequence
+        for (auto& x : th) if (x.joinable()) x.join();
+        return batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
+    }
+    rc[0] = batch_optimize(h, h->scratch, h->batch, part[0], h->ws.stream);
+    for (auto& x : th) x.join();
+    for (int k = 1; k < K; ++k) if (rc[0] == VISFS_BA_OK && rc[k] != VISFS_BA_OK) { rc[0] = rc[k]; if (!errs[k].empty()) h->err = errs[k]; }
+    return rc[0];
 }
 
 
@@ -1137,10 +1157,12 @@ void visfs_ba_destroy(visfs_ba_handle* h) {
     if (h->scratch.d_lm) (void)hipFree(h->scratch.d_lm);
     if (h->scratch.h_lm) (void)hipHostFree(h->scratch.h_lm);
     if (h->scratch.d_all) (void)hipFree(h->scratch.d_all);
-    if (h->scratch2.d_graphs) (void)hipFree(h->scratch2.d_graphs);
-    if (h->scratch2.d_lm) (void)hipFree(h->scratch2.d_lm);
-    if (h->scratch2.h_lm) (void)hipHostFree(h->scratch2.h_lm);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    for (BatchScratch& b : h->part_scratch) {
+        if (b.d_graphs) (void)hipFree(b.d_graphs);
+        if (b.d_lm) (void)hipFree(b.d_lm);
+        if (b.h_lm) (void)hipHostFree(b.h_lm);
+    }
+    for (hipStream_t st : h->part_stream) if (st) (void)hipStreamDestroy(st);
     delete h;
 }
 
