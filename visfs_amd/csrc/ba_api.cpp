@@ -1048,6 +1048,8 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
 int batch_optimize_group(visfs_ba_handle* h, const std::vector<int>& members) {
     static const int parts_env = []() { const char* e = std::getenv("VISFS_BA_BATCH_SPLIT"); return e ? std::atoi(e) : -1; }();   // 0 / 1: one sequence; n: n parts
     const int B = (int)members.size();
+    // (production-size windows on k_small_solve LOSE when cut: 8 windows 156.5 -> 130.9 k it/s, 16 windows 284 -> 178 k — their
+    // launches are too short for a second host thread to feed a second stream beside them)
     bool one_wave = h->prm.solver == 2, one_cu = h->prm.solver == 2;      // every member on k_pcg1 / every member on k_pcg_cu
     for (int i : members) {
         const Workspace& w = *h->batch[i];
