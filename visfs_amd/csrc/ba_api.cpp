@@ -499,6 +499,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.trial_gran = A.take<unsigned long long>((size_t)n_parts * 4);
+        g.aux_part = A.take<double>((size_t)n_parts);
         g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.s2p = A.take<double>(std::max<size_t>(n6, 1));
         g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);

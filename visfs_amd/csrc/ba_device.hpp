@@ -198,6 +198,7 @@ struct DeviceGraph {
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
     // Optimizer/Framework=1: Jacobi scaling squared, fixed at iteration zero (k_ceres_lin_finalize): the damping of variable i is
     // lambda * clamp(H_ii s2_i, 1e-6, 1e32) / s2_i instead of lambda (damp_of)
+    double* aux_part;           // [n_lin_a + 1] per-workgroup partials of the Ceres flavour: ||x||^2 shares (k_linearize), ||step||^2 shares (k_backsub)
     double* s2l;                // [Nl][3]
     double* s2p;                // [Npf][6]
     unsigned long long* trial_gran; // [n_lin_a + 1][4] the same two sums as {epoch:32 | half:32} hand-off words (k_backsub with the LM decision on board)

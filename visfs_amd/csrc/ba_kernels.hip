@@ -325,7 +325,7 @@ __device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k
 template <int G, bool STG = true>
 __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> P,
                                              const double* __restrict__ pt, const Intrinsics& K, const double iv, const double delta,
-                                             double& chi_acc, double& md) {
+                                             double& chi_acc, double& md, double* xn_acc = nullptr) {
     int k0 = 0, k1 = 0;
     Vec3 pw{ 0, 0, 0 };
     bool lfree = false;
@@ -334,6 +334,12 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
         pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
         lfree = !g.pt_fixed[l];
     }
+    // Optimizer/Framework=1: this pass also feeds the minimizer's bookkeeping (k_ceres_lin_finalize only adds the partials up): md
+    // collects ||b_l||_inf instead of max |diag H_ll| (there is no lambda to initialise), xn_acc the landmark's share of ||x||^2, and at
+    // iteration zero the Jacobi scaling of its three columns is written
+    const bool ceres = g.ceres != 0;
+    const bool ceres_first = ceres && g.st->phase_iter == 0;
+    if (ceres && xn_acc && sub == 0 && lfree && k1 > k0) *xn_acc += pw.x * pw.x + pw.y * pw.y + pw.z * pw.z;
     double hb[9];                          // Hll (xx xy xz yy yz zz) then b_l
 #pragma unroll
     for (int q = 0; q < 9; ++q) hb[q] = 0.0;
@@ -401,9 +407,13 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
             if (j < len) {
                 if (idx < 6) {
                     L.Hll[6 * (size_t)l + idx] = hb[j];
-                    if (lfree && (idx == 0 || idx == 3 || idx == 5)) md = fmax(md, fabs(hb[j]));
+                    if (lfree && (idx == 0 || idx == 3 || idx == 5)) {
+                        if (!ceres) md = fmax(md, fabs(hb[j]));
+                        else if (ceres_first) { const double q = 1.0 / (1.0 + sqrt(hb[j])); g.s2l[3 * (size_t)l + (idx == 0 ? 0 : idx == 3 ? 1 : 2)] = q * q; }
+                    }
                 } else {
                     L.bl[3 * (size_t)l + (idx - 6)] = hb[j];
+                    if (ceres && lfree) md = fmax(md, fabs(hb[j]));
                 }
             }
         }
@@ -539,7 +549,7 @@ __device__ __forceinline__ void ceres_decide_role(const DeviceGraph& g, LmState*
     const int tid = threadIdx.x;
     double n2 = 0.0;
     if (ok) {
-        for (int t = tid; t < 3 * g.Nl; t += 256) { const double d = g.dxl[t]; n2 += d * d; }       // 0 for constant / unobserved landmarks
+        for (int w = tid; w < g.n_lin_a; w += 256) n2 += g.aux_part[w];                  // the landmarks' shares, summed per workgroup by k_backsub
         const double* pa = g.pose[st->sel];
         const double* pb = g.pose[st->sel ^ 1];
         for (int t = tid; t < POSE_STRIDE * g.Np; t += 256) {
@@ -687,11 +697,12 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
         constexpr int LPW = 256 / G;
         const int l = bid * LPW + tid / G, sub = tid % G;
         const bool lvalid = l < g.Nl;
-        double chi_acc = 0.0, md = 0.0;
-        lin_landmark<G, STG>(g, L, l, lvalid, sub, P, pt, K, iv, delta, chi_acc, md);
+        double chi_acc = 0.0, md = 0.0, xn = 0.0;
+        lin_landmark<G, STG>(g, L, l, lvalid, sub, P, pt, K, iv, delta, chi_acc, md, &xn);
         const double chi_tot = block_sum_256(chi_acc, red);
         const double md_tot = block_max_256(md, red);
         if (tid == 0) { g.lin_part[2 * bid] = chi_tot; g.lin_part[2 * bid + 1] = md_tot; }
+        if (g.ceres) { const double xn_tot = block_sum_256(xn, red); if (tid == 0) g.aux_part[bid] = xn_tot; }
     } else {
         // ---- role B: pose-major chunk: upper triangle of Jx^T (rho' Omega) Jx and -Jx^T (rho' Omega) e
         const int c = bid - g.n_lin_a;
@@ -929,13 +940,8 @@ __global__ __launch_bounds__(1024) void k_ceres_lin_finalize(const Src src) {
         if (q < 36) { g.Hpp[36 * (size_t)a + q] = v; if (first && q % 7 == 0) { const double s = 1.0 / (1.0 + sqrt(v)); g.s2p[6 * (size_t)a + q / 7] = s * s; } }
         else { g.bp[6 * (size_t)a + (q - 36)] = v; gm = fmax(gm, fabs(v)); }
     }
-    for (int t = tid; t < 3 * g.Nl; t += 1024) {
-        const int l = t / 3, c = t % 3;
-        if (g.pt_fixed[l]) continue;
-        gm = fmax(gm, fabs(L.bl[t]));
-        if (first) { const double s = 1.0 / (1.0 + sqrt(L.Hll[6 * (size_t)l + (c == 0 ? 0 : c == 1 ? 3 : 5)])); g.s2l[t] = s * s; }
-        if (g.lm_ptr[l + 1] > g.lm_ptr[l]) { const double v = g.pt[st->sel][t]; xn += v * v; }
-    }
+    // (the landmark part — ||b_l||_inf, the landmarks' share of ||x||^2, their Jacobi scaling — was done by k_linearize's landmark pass)
+    for (int w = tid; w < g.n_lin_a; w += 1024) { gm = fmax(gm, g.lin_part[2 * w + 1]); xn += g.aux_part[w]; }
     for (int t = tid; t < POSE_STRIDE * g.Np; t += 1024) {
         const int ip = t / POSE_STRIDE, c = t % POSE_STRIDE;
         if (c < 7 && ceres_pose_in_x(g, ip)) { const double v = g.pose[st->sel][t]; xn += v * v; }
@@ -2246,7 +2252,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
 template <int G, bool STG = true>
 __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> Pt, const PoseSrc<STG> P0,
                                                  const double* __restrict__ pt, double* __restrict__ pt_t, const double lambda, const Intrinsics& K,
-                                                 const double iv, const double delta, double& chi_acc, double& scale_acc) {
+                                                 const double iv, const double delta, double& chi_acc, double& scale_acc, double* step_acc = nullptr) {
     int k0 = 0, k1 = 0;
     Vec3 pw{ 0, 0, 0 };
     bool lfree = false;
@@ -2294,6 +2300,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
         d1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
         d2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
         if (sub == 0) scale_acc += d0 * (a0 * d0 + B[0]) + d1 * (a1 * d1 + B[1]) + d2 * (a2 * d2 + B[2]);
+        if (sub == 0 && step_acc) *step_acc += d0 * d0 + d1 * d1 + d2 * d2;          // Optimizer/Framework=1: the landmark's share of ||x - candidate||^2
     }
     const Vec3 pn{ pw.x + d0, pw.y + d1, pw.z + d2 };         // VertexPointXYZ::oplus
     if (lvalid && sub == 0) {
@@ -2388,10 +2395,11 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     constexpr int LPW = 256 / G;
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
-    double chi_acc = 0.0, scale_acc = 0.0;
-    backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc);
+    double chi_acc = 0.0, scale_acc = 0.0, step_acc = 0.0;
+    backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc, &step_acc);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
+    if (g.ceres) { const double st_tot = block_sum_256(step_acc, red); if (tid == 0) g.aux_part[bid] = st_tot; }
     if (tid == 0) { if (DEC) publish_trial(g, bid, st->decide_epoch + 1u, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
 }
 
