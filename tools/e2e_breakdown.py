@@ -4,6 +4,8 @@ import time
 
 import numpy as np
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visfs_amd import abi, backend, synth
 
 

@@ -50,6 +50,8 @@ struct Workspace {
     bool loaded = false;
     bool batch_member = false;                     // one of visfs_ba_solve_batch / visfs_ba_batch_upload's windows (shares its launches)
     bool fused = false;                            // the resident window runs on k_small_optimize
+    bool want_outputs = false;                     // solve_window: the state read of a solve also fetches the outputs (one synchronisation less)
+    bool outputs_staged = false;                   // ... they are in the staging arena (both estimate buffers; LmState::sel picks)
     int batch_hint = 1;                            // windows of the batch this workspace was uploaded for (kernel choices that depend on it)
     bool spec = false;                             // units end with the speculative linearisation + LM decision launch
     bool fused_decide = true;                      // gated units: k_backsub carries the LM decision (VISFS_BA_DECIDE_FUSED=0: k_decide, A/B runs and tests)
@@ -631,9 +633,35 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     return VISFS_BA_OK;
 }
 
+// Layout of the outputs in the staging arena when they travel with the state read: both pose buffers, both landmark buffers, outliers.
+struct OutputStage { size_t pose[2], pt[2], out, end; };
+static OutputStage output_stage_of(const DeviceGraph& g) {
+    OutputStage o;
+    const size_t b_pose = (size_t)g.Np * POSE_STRIDE * 8, b_pt = (size_t)g.Nl * 24;
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    o.pose[0] = 0; o.pose[1] = up(b_pose); o.pt[0] = o.pose[1] + up(b_pose); o.pt[1] = o.pt[0] + up(b_pt); o.out = o.pt[1] + up(b_pt);
+    o.end = o.out + (size_t)g.No;
+    return o;
+}
+
 int ws_read_state(visfs_ba_handle* h, Workspace& w) {
     HIP_TRY(h, hipMemcpyAsync(w.h_state, w.g.st, sizeof(LmState), hipMemcpyDeviceToHost, w.stream));
+    w.outputs_staged = false;
+    const OutputStage os = output_stage_of(w.g);
+    // (the arena is also the source of the upload's H2D copy: that copy precedes these on the same stream, so it has read its data)
+    const bool with_outputs = w.want_outputs && w.h_base && os.end <= w.h_cap;
+    if (with_outputs) {
+        // which estimate buffer is the final one is only known from the state that is coming back: fetch both (poses are tiny, landmarks
+        // 24 bytes each) — the caller's download then needs neither a copy nor a second synchronisation
+        const DeviceGraph& g = w.g;
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(h, hipMemcpyAsync(w.h_base + os.pose[k], g.pose[k], (size_t)g.Np * POSE_STRIDE * 8, hipMemcpyDeviceToHost, w.stream));
+            if (g.Nl) HIP_TRY(h, hipMemcpyAsync(w.h_base + os.pt[k], g.pt[k], (size_t)g.Nl * 24, hipMemcpyDeviceToHost, w.stream));
+        }
+        if (g.No) HIP_TRY(h, hipMemcpyAsync(w.h_base + os.out, g.obs_outlier, (size_t)g.No, hipMemcpyDeviceToHost, w.stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(w.stream));
+    w.outputs_staged = with_outputs;
     if (!w.recs.empty()) prof_harvest(w);
     return VISFS_BA_OK;
 }
@@ -836,6 +864,16 @@ int ws_download(visfs_ba_handle* h, Workspace& w, double* pose_tq, double* point
     if (!state_fresh) { int rc = ws_read_state(h, w); if (rc != VISFS_BA_OK) return rc; }
     const int sel = w.h_state->sel;
     const DeviceGraph& g = w.g;
+    if (state_fresh && w.outputs_staged && !obs_chi2) {
+        // the outputs came back with the state (ws_read_state): no copy, no synchronisation
+        const OutputStage os = output_stage_of(g);
+        const double* ps = reinterpret_cast<const double*>(w.h_base + os.pose[sel]);
+        if (pose_tq) for (int i = 0; i < g.Np; ++i) for (int q = 0; q < 7; ++q) pose_tq[7 * i + q] = ps[POSE_STRIDE * i + q];
+        if (point_xyz && g.Nl) std::memcpy(point_xyz, w.h_base + os.pt[sel], (size_t)g.Nl * 24);
+        if (obs_outlier && g.No) std::memcpy(obs_outlier, w.h_base + os.out, (size_t)g.No);
+        w.outputs_staged = false;
+        return VISFS_BA_OK;
+    }
     // every copy is enqueued first, ONE synchronisation at the end.  The copies land in the workspace's PINNED staging arena (idle
     // between uploads) and are moved to the caller's pageable buffers by the host: a device-to-pageable copy is staged and
     // serialised by the runtime chunk by chunk.
@@ -960,7 +998,9 @@ int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win
     PackedWindow pk;
     if (!prepare_window(h, w, win, r, pk)) return r->status;
     visfs_ba_stats st;
+    w.want_outputs = true;                          // the outputs travel with the solve's state read
     const int rc = ws_optimize(h, w, &st);
+    w.want_outputs = false;
     return finish_window(h, w, win, r, pk, rc, st);
 }
 
