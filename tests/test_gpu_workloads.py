@@ -229,3 +229,17 @@ def test_batches_of_sixteen_and_more_use_the_single_workgroup_pcg(olib, monkeypa
     s.close()
     for (rc, a), b in zip(singles, got0):
         assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+
+
+def test_describe_names_the_kernel_that_solves_the_reduced_system(olib):
+    """visfs_ba_graph_info::solver_kernel: the symbol a kernel trace shows for the solver class (bench.py's roofline.kernel_symbol)."""
+    from visfs_amd import backend
+    cases = [("PROD", dict(solver=2), 5), ("PROD", dict(solver=0), 5), ("C2", dict(solver=2), 1), ("C2", dict(solver=0), 6),
+             ("C2", dict(solver=2, framework=1), 6), ("C4", dict(solver=2), 2)]
+    for cfg, kw, want in cases:
+        prm = abi.default_params(iterations=2, **kw)
+        s = backend.Solver(prm)
+        gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(synth.make_window(cfg)))
+        s.upload(gb)
+        assert s.describe()["solver_kernel"] == want, (cfg, kw, s.describe()["solver_kernel"])
+        s.close()
