@@ -243,3 +243,42 @@ def test_describe_names_the_kernel_that_solves_the_reduced_system(olib):
         s.upload(gb)
         assert s.describe()["solver_kernel"] == want, (cfg, kw, s.describe()["solver_kernel"])
         s.close()
+
+
+@pytest.mark.timeout(300)
+def test_shared_and_exclusive_pcg_leases_interleave_without_deadlock(olib):
+    """One thread keeps solving a 12-window batch (two concurrent parts of one-wave PCG grids: shared leases on the device budget), another
+    a C4-size window (four-wave PCG: exclusive lease), on two handles of the same device.  Everything must finish and every result must
+    equal its reference — the budget admits the small grids together and makes the big one wait for all of them (and vice versa)."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    small = [synth.make_window("custom", n_kf=20, n_lm=400, n_obs=3200, seed=200 + i) for i in range(12)]
+    sa, sb = backend.Solver(prm), backend.Solver(prm)
+    ref_small = sa.solve_batch([abi.WindowBuffers(w) for w in small])
+    big = synth.make_window("C4")
+    gb, *_ = abi.pack_window_with(sb.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(big))
+    sb.upload(gb); rc, _ = sb.optimize(); assert rc == abi.OK
+    ref_big = sb.download()
+    out = {}
+
+    def run_small():
+        res = []
+        for _ in range(4):
+            res.append(sa.solve_batch([abi.WindowBuffers(w) for w in small]))
+        out["small"] = res
+
+    def run_big():
+        res = []
+        for _ in range(4):
+            sb.reset(); rc, _ = sb.optimize(); res.append((rc, sb.download()))
+        out["big"] = res
+
+    th = [threading.Thread(target=run_small), threading.Thread(target=run_big)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for res in out["small"]:
+        for a, b in zip(ref_small, res):
+            assert a.struct.status == b.struct.status == abi.OK and np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+    for rc, d in out["big"]:
+        assert rc == abi.OK and all(np.array_equal(x, y) for x, y in zip(d, ref_big))
+    sa.close(); sb.close()
