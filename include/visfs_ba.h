@@ -298,7 +298,8 @@ typedef struct visfs_ba_graph_info {
     int32_t fused_path;           /* 1: the window runs on the fused single-workgroup kernel (small windows, opt-in with VISFS_BA_FUSED=1) */
     int32_t solver_kernel;        /* which kernel solves the reduced system (the symbol a kernel trace shows for the VISFS_BA_K_PCG / _DIRECT class):
                                    * 1 k_pcg1 (PCG, one wavefront per block row), 2 k_pcg (PCG, four waves per row), 3 k_pcg, several rows per
-                                   * workgroup, 4 k_pcg_cu (PCG, one workgroup), 5 k_small_solve, 6 k_chol_* (blocked dense Cholesky) */
+                                   * workgroup, 4 k_pcg_cu (PCG, one workgroup), 5 k_small_solve, 6 k_chol_* (blocked dense Cholesky),
+                                   * 7 k_band_chol (block-banded Cholesky in one workgroup) */
 } visfs_ba_graph_info;
 /* GRAPH layer for a batch of independent windows (BASELINE config 5): n graphs resident side by side; one optimise call runs
  * them through ONE sequence of launches (blockIdx.y = window, each window gated by its own LM state).  Needs

@@ -234,8 +234,8 @@ def test_batches_of_sixteen_and_more_use_the_single_workgroup_pcg(olib, monkeypa
 def test_describe_names_the_kernel_that_solves_the_reduced_system(olib):
     """visfs_ba_graph_info::solver_kernel: the symbol a kernel trace shows for the solver class (bench.py's roofline.kernel_symbol)."""
     from visfs_amd import backend
-    cases = [("PROD", dict(solver=2), 5), ("PROD", dict(solver=0), 5), ("C2", dict(solver=2), 1), ("C2", dict(solver=0), 6),
-             ("C2", dict(solver=2, framework=1), 6), ("C4", dict(solver=2), 2)]
+    cases = [("PROD", dict(solver=2), 5), ("PROD", dict(solver=0), 5), ("C2", dict(solver=2), 1), ("C2", dict(solver=0), 7),
+             ("C2", dict(solver=2, framework=1), 7), ("C4", dict(solver=2), 2)]
     for cfg, kw, want in cases:
         prm = abi.default_params(iterations=2, **kw)
         s = backend.Solver(prm)
@@ -282,3 +282,61 @@ def test_shared_and_exclusive_pcg_leases_interleave_without_deadlock(olib):
     for rc, d in out["big"]:
         assert rc == abi.OK and all(np.array_equal(x, y) for x, y in zip(d, ref_big))
     sa.close(); sb.close()
+
+
+# ---------------------------------------------------------------- banded direct solver (k_band_chol)
+def _direct_trial(olib, w, env, lam_scale=1e-3, **prm_kw):
+    """One damped direct solve of window `w` under the environment overrides `env`: (oracle dx, GPU dx, GPU trial chi2, solver kernel)."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        o, s, gb = make_pair(olib, w, **prm_kw)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    chi, md = o.linearize(); s.linearize()
+    lam = lam_scale * md
+    ot, gt = o.trial(lam), s.trial(lam)
+    assert ot[3] == gt[3] == 1
+    out = (o.fetch(abi.BUF_DX_POSE), s.fetch(abi.BUF_DX_POSE), s.fetch(abi.BUF_POSE_TRIAL), gt[0])
+    s.close(); o.close()
+    return out
+
+
+def test_banded_cholesky_matches_dense_fallback_and_oracle(olib):
+    """Optimizer/Solver=0 at C2: S is block-banded (49 block rows, half-bandwidth 9).  The banded Cholesky in one workgroup
+    (whole band in LDS), its streaming form (a 12-row window, the factor through HBM — what C4 runs) and the dense blocked
+    Cholesky (VISFS_BA_BAND=0) solve the same system: the two banded forms bit for bit, all three with the oracle to 1e-9."""
+    w = synth.make_window("C2")
+    ox, band, pose_b, chi_b = _direct_trial(olib, w, {"VISFS_BA_BAND": "1"}, iterations=20, solver=0)
+    _, stream, pose_s, chi_s = _direct_trial(olib, w, {"VISFS_BA_BAND": "1", "VISFS_BA_BAND_ROWS": "12"}, iterations=20, solver=0)
+    _, dense, pose_d, chi_d = _direct_trial(olib, w, {"VISFS_BA_BAND": "0"}, iterations=20, solver=0)
+    assert np.array_equal(band, stream) and np.array_equal(pose_b, pose_s) and chi_b == chi_s
+    assert rel_err(band, ox) < 1e-9 and rel_err(dense, ox) < 1e-9 and rel_err(band, dense) < 1e-9
+    assert abs(chi_b - chi_d) <= 1e-9 * abs(chi_d)
+
+
+def test_banded_cholesky_on_odd_shapes(olib):
+    """Ragged tracks with odometry (12 poses: the band is almost the whole matrix), a hard start, a window whose newest poses see
+    no landmark (pinned identity blocks inside the band), and the tail handling of a band wider than the rows that are left."""
+    from helpers import hard_window, ragged_window
+    for w, kw in ((ragged_window(seed=7), {}), (hard_window(seed=5), {}), (synth.make_window("C3", n_kf=24, n_lm=400, n_obs=3200), {})):
+        ox, gx, _, _ = _direct_trial(olib, w, {"VISFS_BA_BAND": "1", "VISFS_BA_SMALL_SOLVE": "0"}, iterations=10, solver=0, **kw)
+        assert rel_err(gx, ox) < 1e-9
+    # a streaming window that is shorter than the band allows at the bottom of the matrix
+    w = synth.make_window("custom", n_kf=40, n_lm=600, n_obs=6000, seed=11)
+    ox, gx, _, _ = _direct_trial(olib, w, {"VISFS_BA_BAND": "1", "VISFS_BA_BAND_ROWS": "12"}, iterations=10, solver=0)
+    assert rel_err(gx, ox) < 1e-9
+
+
+def test_banded_cholesky_reports_a_failed_factorisation(olib):
+    """A non-positive pivot (undamped Gauss-Newton on a window whose gauge is free: no fixed landmark, lambda = 0) must reject the trial
+    (g2o: solver returns false), not produce numbers: solver_ok = 0 on both sides or an identical finite solve."""
+    w = synth.make_window("custom", n_kf=16, n_lm=200, n_obs=1600, seed=3, fixed_frac=0.0)
+    o, s, gb = make_pair(olib, w, iterations=10, solver=0)
+    o.linearize(); s.linearize()
+    ot, gt = o.trial(-1e12), s.trial(-1e12)             # H - 1e12 I: indefinite by construction
+    assert ot[3] == 0 and gt[3] == 0
+    s.close(); o.close()

@@ -1,0 +1,23 @@
+"""Diagnostic: where the banded Cholesky (k_band_chol) spends a solve (needs libvisfs_ba_hip_stamps.so built with -DVISFS_BA_STAMPS)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from visfs_amd import abi, backend, synth
+backend.LIB_PATH = os.path.join(ROOT, "visfs_amd", "lib", "libvisfs_ba_hip_stamps.so")
+lib = backend.load_library()
+for CFG in sys.argv[1:] or ["C2"]:
+    w = synth.make_window(CFG); prm = abi.default_params(iterations=10, solver=0)
+    gb, *_ = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s = backend.Solver(prm); s.upload(gb)
+    for _ in range(2):
+        s.reset(); s.optimize()
+    out = np.zeros(128)
+    s.lib.visfs_ba_stage_fetch(s.h, 100, out.ctypes.data_as(C.POINTER(C.c_double)), 128)
+    st = out.view(np.uint64).astype(np.int64)
+    ns = lambda a, b: int(st[a] - st[b]) * 10
+    print(f"{CFG}: free poses {s.describe()['n_free_poses']}  load {ns(1, 0)} ns | factor loop {ns(110, 1)} | backward {ns(111, 110)} | epilogue {ns(112, 111)} | total {ns(112, 0)}")
+    for k in range(1, 16, 2):
+        prev = 1 if k == 0 else 5 + 6 * (k - 1)
+        print(f"   step {k:2d}: A diag {ns(2 + 6 * k, prev):5d} rest {ns(3 + 6 * k, prev):5d} -> barrier {ns(4 + 6 * k, prev):5d} | B trsm+barrier {ns(5 + 6 * k, 4 + 6 * k):5d} | step {ns(5 + 6 * k, prev)}")
+    s.close()

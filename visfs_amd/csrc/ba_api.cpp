@@ -412,6 +412,22 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
                                 const bool want = e ? (e[0] == '1') : (w.batch_member && w.batch_hint >= 16);
                                 return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && want; }();
+    // direct solver (Optimizer/Solver 0, 1, 3 and every solve of the Ceres branch): S of a sliding window is block-banded — the banded
+    // Cholesky in one workgroup (k_band_chol) when the band is narrow enough, the dense blocked Cholesky otherwise (VISFS_BA_BAND=0 forces it)
+    int band_B = -1, band_rows = 0, band_lds = 0;
+    std::vector<int32_t> band_code;
+    if (prm.solver != 2 && Npf >= 1) {
+        int Bw = 0;
+        for (int b = 0; b < n_blk; ++b) Bw = std::max(Bw, blk_j[b] - blk_i[b]);
+        const char* e = std::getenv("VISFS_BA_BAND");
+        if (!(e && e[0] == '0') && band_plan(Npf, Bw, &band_rows, &band_lds)) {
+            { const char* er = std::getenv("VISFS_BA_BAND_ROWS"); const int q = er ? std::atoi(er) : 0;          // tests: force the streaming form
+              if (q >= Bw + 3 && q < band_rows) { band_rows = q; band_lds = (int)band_lds_bytes(Npf, Bw, q); } }
+            band_B = Bw;
+            band_code.assign((size_t)Npf * (Bw + 1), -1);
+            for (int b = 0; b < n_blk; ++b) band_code[(size_t)blk_j[b] * (Bw + 1) + (blk_j[b] - blk_i[b])] = b;
+        }
+    }
     lap("pair count");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
@@ -459,6 +475,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.row_col = A.take<int32_t>(std::max<size_t>(row_col.size(), 1));
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
         g.pcg1_code = pcg1 ? A.take<int32_t>((size_t)Npf * Npf) : nullptr;
+        g.band_code = band_B >= 0 ? A.take<int32_t>(band_code.size()) : nullptr;
         g.laser_xyz = A.take<double>((size_t)std::max(Nz, 1) * 3);
         g.grid.cost = A.take<float>(std::max<size_t>(grid_cells, 1));
     };
@@ -504,8 +521,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.aux_part = A.take<double>((size_t)n_parts);
         g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.s2p = A.take<double>(std::max<size_t>(n6, 1));
-        g.dense = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
-        g.chol_f = A.take<double>(prm.solver == 2 ? 1 : chol_np * chol_np);
+        const bool dense_chol = prm.solver != 2 && band_B < 0;
+        g.dense = A.take<double>(dense_chol ? chol_np * chol_np : 1);
+        g.chol_f = A.take<double>(dense_chol ? chol_np * chol_np : 1);
+        g.band_L = A.take<double>(band_B >= 0 && band_rows < Npf ? (size_t)Npf * (band_B + 1) * 36 : 1);
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
         g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
@@ -571,6 +590,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
         if (pcg1) std::memcpy(const_cast<int32_t*>(hg.pcg1_code), pcg1_code.data(), pcg1_code.size() * 4);
+        if (band_B >= 0) std::memcpy(const_cast<int32_t*>(hg.band_code), band_code.data(), band_code.size() * 4);
         if (Nz) {
             std::memcpy(const_cast<double*>(hg.laser_xyz), gr->laser_xyz, (size_t)Nz * 24);
             std::memcpy(const_cast<float*>(hg.grid.cost), gr->grid->correspondence_cost, grid_cells * 4);
@@ -586,6 +606,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     dg.n_pose_obs = cnt[Npf];
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_pixel_var_out = dg.inv_pixel_var;
@@ -1510,7 +1531,7 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->n_schur_chunks = w.g.n_sch;
     out->device_bytes = (int64_t)w.device_bytes;
     out->fused_path = w.fused ? 1 : 0;
-    out->solver_kernel = w.small_solve ? 5 : h->prm.solver != 2 ? 6 : w.g.pcg_cu ? 4 : w.g.pcg1_code ? 1 : w.g.Npf > MAX_PCG_ONE_ROW_POSES ? 3 : 2;
+    out->solver_kernel = w.small_solve ? 5 : h->prm.solver != 2 ? (w.g.band_B >= 0 ? 7 : 6) : w.g.pcg_cu ? 4 : w.g.pcg1_code ? 1 : w.g.Npf > MAX_PCG_ONE_ROW_POSES ? 3 : 2;
     return VISFS_BA_OK;
 }
 

@@ -114,6 +114,10 @@ struct DeviceGraph {
     int32_t pcg_cu;         // 1: the reduced system is solved by ONE workgroup (k_pcg_cu: S in registers, no cross-workgroup hand-off)
     int32_t pcg_lds_bytes;
     int32_t chol_np;        // padded order of the dense reduced camera matrix (direct solver)
+    int32_t band_B;         // direct solver: block half-bandwidth of S (max j - i over the stored blocks) when the banded Cholesky
+                            //   (k_band_chol) serves this window, -1: dense blocked Cholesky (k_chol_*)
+    int32_t band_rows;      // ... block rows of the band resident in LDS at once (== Npf: the whole factor stays in LDS)
+    int32_t band_lds_bytes; // ... dynamic LDS of k_band_chol
     int32_t n_lin_a;        // workgroups of the landmark-major role
     int32_t n_edges_ok;     // stereo edges whose two ends are not both fixed (the active set before the outlier pass)
     int32_t group;          // lanes per landmark (4/8/16/32/64)
@@ -166,6 +170,7 @@ struct DeviceGraph {
     const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)
     const int32_t* row_col;     // [..] column block
     const int32_t* row_blk;     // [..] stored block id * 2 + transposed
+    const int32_t* band_code;   // [Npf][band_B + 1] stored block id of S(I - d, I) (the lower block (I, I - d) is its transpose), -1: no such block
     const int32_t* pcg1_code;   // [Npf][Npf] stored block id * 2 + transposed of S(i, a), -1: no block — only for <= 64 free poses with PCG
                                 //   (k_pcg1: one wavefront per block row); nullptr otherwise
 
@@ -206,6 +211,7 @@ struct DeviceGraph {
     double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)
     double* chol_y;             // [chol_np]
     double* chol_linv;          // [2][32][32] inverse of the diagonal block of panel p in half p & 1
+    double* band_L;             // [Npf][band_B + 1][36] the banded factor when it does not stay in LDS: block (I, I - d) at [I][d], d = 0: L_II^-1
 
     LmState* st;
     unsigned long long* stamps;  // [128] diagnostic build (-DVISFS_BA_STAMPS) only: real-time stamps of one PCG workgroup

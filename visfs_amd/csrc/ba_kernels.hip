@@ -2247,6 +2247,390 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
     }
 }
 
+// ================================================================= K6 (direct, banded): block-banded factorisation of S in ONE workgroup
+// The reference's default linear solver is a SPARSE Cholesky of the block-sparse reduced camera matrix (CSparse,
+// Parameters.h:185, Optimizer.cpp:76-91).  In a sliding window a landmark is seen from a run of consecutive key-frames, so S is
+// block-BANDED: block (i, j) exists only for |i - j| <= B, B = longest track - 1 (C2 / C4: B = 9 of 49 / 199 block rows), and a
+// triangular factor keeps that band.  This kernel factors the band block column by block column inside one workgroup — no dense
+// matrix, no launch per panel — and solves in the same launch.  The factorisation is the BLOCK form S = L D L^T (6x6 blocks, L unit
+// lower, D block diagonal: the SPD analogue of Cholesky with the square roots left out): its sequential chain per block column is one
+// 6x6 SPD inverse through two closed-form 3x3 inverses (~35 dependent fp64 operations at ~8 ns each) instead of six dependent
+// pivots with rsqrt + Newton (~100).
+//   ring  [rows][B + 1][36]  LDS: block (I, I - d) of the lower band at [(I mod rows)][d]; rows == Npf when the whole band fits
+//                            (C2: 141 KB), else a sliding window of rows >= B + 2 block rows and the factor streams to band_L (HBM);
+//   step k:  A  wave 0: D_k^-1 (every lane redundantly, operands by LDS broadcast: no cross-lane traffic), positive-definiteness
+//               by Sylvester's criterion on the two 3x3 stages;  wave 1: forward-substitution step k - 1, hidden behind it;
+//            B  L_ik = G_ik D_k^-1 for the <= B blocks below (G = the updated, unscaled block; two threads per block row),
+//               G kept aside for step C;
+//            C  A_ij -= L_ik G_jk^T for k < j <= i <= k + B (a thread per 3x3 tile); the next block row of S enters the ring;
+//   then the backward substitution on one wavefront (right-looking: x_k final, z_j -= L_kj^T x_k) and K8 (pose oplus).
+// Every sum has a fixed order: results are bitwise reproducible.  A block D_k that is not positive definite (what a non-positive
+// Cholesky pivot is) or not finite sets LmState::solver_failed: g2o's solver returns false and the LM trial is rejected.
+constexpr int BAND_T = 256;
+constexpr int BAND_MAX_W = 22;                                  // (B + 1) <= 22: a (B + 2)-row ring of 6x6 blocks fits the LDS budget
+size_t band_lds_bytes(const int npf, const int B, const int rows) {
+    const size_t W = (size_t)B + 1;
+    // ring + two unscaled columns + right-hand side + two D^-1 + G_{k+1,k} + flags, then the table of stored block ids and the pair table
+    return ((size_t)rows * W * 36 + 2 * W * 36 + 6 * (size_t)npf + 2 * 36 + 36 + 8) * sizeof(double) + ((size_t)npf * W * 4 + 15) / 16 * 16 + (((size_t)B * (B + 1)) + 15) / 16 * 16;
+}
+// The plan for a reduced system of npf block rows with block half-bandwidth B: how many block rows stay in LDS (all of them when the
+// band fits), or false when even a (B + 2)-row window does not fit (wide bands: the dense blocked Cholesky takes those).
+bool band_plan(const int npf, const int B, int* rows, int* lds_bytes) {
+    if (npf < 1 || B < 0 || B + 1 > BAND_MAX_W) return false;
+    int r = npf;
+    if (band_lds_bytes(npf, B, r) > (size_t)BAND_LDS_BUDGET) {
+        const size_t fixed = band_lds_bytes(npf, B, 0);
+        if (fixed >= (size_t)BAND_LDS_BUDGET) return false;
+        r = (int)(((size_t)BAND_LDS_BUDGET - fixed) / ((size_t)(B + 1) * 36 * sizeof(double)));
+        while (r > 0 && band_lds_bytes(npf, B, r) > (size_t)BAND_LDS_BUDGET) --r;
+        if (r < B + 3) return false;                            // the row that enters replaces block row k - 1 while row k + B is live
+    }
+    *rows = r; *lds_bytes = (int)band_lds_bytes(npf, B, r);
+    return true;
+}
+
+// 1 / x: v_rcp_f64 seed + two Newton steps (an IEEE division is ~10 dependent operations more)
+__device__ __forceinline__ double fast_rcp(const double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+// Inverse of the symmetric 3x3 [a b c; b d e; c e f] (h = a b c d e f) in cofactor form; returns whether it is positive definite
+// (Sylvester: the nested principal minors f, d f - e^2 and the determinant).
+__device__ __forceinline__ bool spd3_inverse(const double h[6], double o[6]) {
+    const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = fast_rcp(det);
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
+    return f > 0.0 && c00 > 0.0 && det > 0.0 && det <= DBL_MAX;
+}
+__device__ __forceinline__ int sym3(const int r, const int c) { return r <= c ? (r * (5 - r)) / 2 + c : (c * (5 - c)) / 2 + r; }   // index of (r, c) in (00 01 02 11 12 22)
+// Inverse of the SPD 6x6 block D = [P Q; Q^T R] (row-major; only its lower triangle is read) through two 3x3 inverses:
+//   Pi = P^-1, T = Pi Q, Sc = R - Q^T T, Si = Sc^-1, U = -T Si, V = Pi - U T^T;  D^-1 = [V U; U^T Si].
+// Every lane computes the whole inverse (operands arrive as LDS broadcasts); returns false when D is not positive definite.
+__device__ __forceinline__ bool band_inv6(const double* __restrict__ D, double inv[36]) {
+    double P[6], R[6], Q[9];                                   // Q[3 m + a] = D[3 + a][m]
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = r; c < 3; ++c) { P[sym3(r, c)] = D[6 * c + r]; R[sym3(r, c)] = D[6 * (3 + c) + 3 + r]; }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2) Q[3 * m + a2] = D[6 * (3 + a2) + m];
+    double Pi[6], T[9], Sc[6], Si[6], U[9];
+    const bool okP = spd3_inverse(P, Pi);
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) T[3 * m + b2] = Pi[sym3(m, 0)] * Q[b2] + Pi[sym3(m, 1)] * Q[3 + b2] + Pi[sym3(m, 2)] * Q[6 + b2];
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+        for (int b2 = a2; b2 < 3; ++b2) Sc[sym3(a2, b2)] = R[sym3(a2, b2)] - (Q[a2] * T[b2] + Q[3 + a2] * T[3 + b2] + Q[6 + a2] * T[6 + b2]);
+    const bool okS = spd3_inverse(Sc, Si);
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) U[3 * m + b2] = -(T[3 * m] * Si[sym3(0, b2)] + T[3 * m + 1] * Si[sym3(1, b2)] + T[3 * m + 2] * Si[sym3(2, b2)]);
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+        for (int b2 = a2; b2 < 3; ++b2) {
+            const double v = Pi[sym3(a2, b2)] - (U[3 * a2] * T[3 * b2] + U[3 * a2 + 1] * T[3 * b2 + 1] + U[3 * a2 + 2] * T[3 * b2 + 2]);
+            inv[6 * a2 + b2] = v; inv[6 * b2 + a2] = v;
+            inv[6 * (3 + a2) + 3 + b2] = Si[sym3(a2, b2)]; inv[6 * (3 + b2) + 3 + a2] = Si[sym3(a2, b2)];
+        }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) { inv[6 * m + 3 + b2] = U[3 * m + b2]; inv[6 * (3 + b2) + m] = U[3 * m + b2]; }
+    return okP && okS;
+}
+
+template <class Src>
+__global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
+    const DeviceGraph& g = graph_of(src);
+    LmState* st = g.st;
+    if (!(st->mode & MODE_TRIAL)) return;
+    extern __shared__ __attribute__((aligned(16))) double band_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef VISFS_BA_STAMPS
+    // (stamps go to LDS and leave for HBM at the end: a global store per stamp would make every barrier wait for it)
+    __shared__ unsigned long long sstamp[128];
+#define BAND_STAMP(slot) do { if (tid == 0 && (slot) < 126) sstamp[(slot)] = wall_clock64(); } while (0)
+#else
+#define BAND_STAMP(slot) do { } while (0)
+#endif
+    BAND_STAMP(0);
+    // Barrier of the factor loop: LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave — the
+    // streaming form keeps loads of the entering block row and stores of the factor in flight across steps on purpose.
+#define BAND_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    const int Npf = g.Npf, B = g.band_B, W = B + 1, RR = g.band_rows;
+    const bool resident = RR >= Npf;
+    const int rowsz = W * 36;
+    double* ring = band_lds;                                   // [RR][W][36]
+    double* gk = ring + (size_t)RR * rowsz;                    // [2][W][36] the unscaled blocks G_ik of column k in half k & 1 (slot m = i - k)
+    double* cvec = gk + 2 * rowsz;                             // [6 Npf] right-hand side -> L^-1 b -> D^-1 L^-1 b -> x
+    double* dinv = cvec + 6 * Npf;                             // [2][36] D_k^-1 of the current / previous step
+    double* g1buf = dinv + 72;                                 // [36] G_{k+1,k}, read by every thread of step B while its slot is being overwritten
+    int* sflag = reinterpret_cast<int*>(g1buf + 36);           // (8 doubles reserved)
+    int* scode = reinterpret_cast<int*>(g1buf + 36 + 8);       // [Npf][W] stored block ids (DeviceGraph::band_code)
+    unsigned char* pij = reinterpret_cast<unsigned char*>(scode) + ((size_t)Npf * W * 4 + 15) / 16 * 16;   // [(B - 1) B / 2][2] (i, j), 2 <= j <= i <= B
+    // ---- the first RR block rows of S: the lower block (I, I - d) is the transpose of the stored upper block (I - d, I).  The block
+    // ids go to LDS first, so that the element loads below are independent of each other and many are in flight per thread.
+    const int nrows0 = min(RR, Npf), nslots0 = nrows0 * W;
+    for (int t = tid; t < Npf * W; t += BAND_T) scode[t] = g.band_code[t];
+    for (int t = tid; t < 6 * Npf; t += BAND_T) cvec[t] = g.bs[t];
+    if (tid == 0) sflag[0] = 0;
+    for (int p = tid; p < (B - 1) * B / 2; p += BAND_T) {
+        int i = 2; while ((i - 1) * i / 2 <= p) ++i;           // p = (i - 1) (i - 2) / 2 + (j - 2)
+        pij[2 * p] = (unsigned char)i; pij[2 * p + 1] = (unsigned char)(p - (i - 1) * (i - 2) / 2 + 2);
+    }
+    __syncthreads();
+    {
+        const int total = nslots0 * 18;                        // double2 elements: (q, q + 1) of a block never straddle two blocks
+        constexpr int U = 12;
+        for (int t0 = tid; t0 < total; t0 += BAND_T * U) {
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + BAND_T * u;
+                v[u] = make_double2(0.0, 0.0);
+                if (t < total) { const int sl = t / 18, h = t - 18 * sl, b = scode[sl]; if (b >= 0) v[u] = reinterpret_cast<const double2*>(g.S + 36 * (size_t)b)[h]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + BAND_T * u;
+                if (t < total) {
+                    const int sl = t / 18, h = t - 18 * sl, q = 2 * h, r0 = q / 6, c0 = q - 6 * r0;     // stored entry (r0, c0) and (r0, c0 + 1)
+                    double* dst = ring + 36 * (size_t)sl;
+                    dst[6 * c0 + r0] = v[u].x; dst[6 * (c0 + 1) + r0] = v[u].y;                        // transposed
+                }
+            }
+        }
+    }
+    __syncthreads();
+    BAND_STAMP(1);
+    // ring row of block row k + i (0 <= i <= B) when block row k sits in ring row kk
+    auto ring_row = [&](const int kk, const int i) -> double* { int r = kk + i; r -= (r >= RR) ? RR : 0; return ring + (size_t)r * rowsz; };
+    // forward-substitution step s on one wavefront: c_i -= L_is c_s for the blocks below, then c_s <- D_s^-1 c_s
+    auto fwd_step = [&](const int s_, const int ks) {
+        const double* Di = dinv + 36 * (s_ & 1);
+        double cs[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cs[c] = cvec[6 * s_ + c];
+        const int nb = min(B, Npf - 1 - s_);
+        double z = 0.0;
+        if (lane < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) z += Di[6 * lane + c] * cs[c];
+        }
+        for (int e = lane; e < 6 * nb; e += 64) {
+            const int m = e / 6 + 1, rr = e - 6 * (m - 1);
+            const double* L = ring_row(ks, m) + 36 * m + 6 * rr;
+            double acc = cvec[6 * (s_ + m) + rr];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc -= L[c] * cs[c];
+            cvec[6 * (s_ + m) + rr] = acc;
+        }
+        if (lane < 6) cvec[6 * s_ + lane] = z;
+    };
+    // the part of the trailing update of column s that does not touch the next column: A_ij -= L_is G_js^T for 2 <= j <= i <= nb(s), on
+    // 3x3 tiles, by the threads of waves 1..3 (it runs beside the inverse of the NEXT diagonal block, which needs column s + 1 only)
+    auto syrk_rest = [&](const int s_, const int ks) {
+        const int nb = min(B, Npf - 1 - s_);
+        const int P = (nb - 1) * nb / 2;
+        const double* G = gk + (size_t)(s_ & 1) * rowsz;
+        for (int t = tid - 64; t < 4 * P; t += BAND_T - 64) {
+            const int p = t >> 2, ta = (t >> 1) & 1, tb = t & 1;
+            const int i = pij[2 * p], j = pij[2 * p + 1];
+            if ((i == j) & (tb > ta)) continue;                // a diagonal block: its upper 3x3 tile is never read
+            double* rowi = ring_row(ks, i);
+            const double* Li = rowi + 36 * i + 18 * ta;        // rows 3 ta .. of L_is
+            const double* Gj = G + 36 * j + 18 * tb;           // rows 3 tb .. of G_js
+            double* C = rowi + 36 * (i - j) + 18 * ta + 3 * tb;
+            double li[18], gj[18];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) { li[q] = Li[q]; gj[q] = Gj[q]; }
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    double acc = C[6 * rr + cc];
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) acc -= li[6 * rr + m] * gj[6 * cc + m];
+                    C[6 * rr + cc] = acc;
+                }
+        }
+    };
+    int kk = 0, kp = 0;                                        // ring rows of block rows k and k - 1
+    constexpr int NPEND = (BAND_MAX_W * 36 + (BAND_T - 64) - 1) / (BAND_T - 64);
+    double pend[NPEND];                                        // streaming form: the block row of S on its way into the ring (waves 1..3)
+    int pend_row = -1;
+    for (int k = 0; k < Npf; ++k) {
+        const int nb = min(B, Npf - 1 - k);
+        double* Dk = dinv + 36 * (k & 1);
+        double* rowk = ring + (size_t)kk * rowsz;
+        // ---- A: wave 0 inverts D_k (and sets G_{k+1,k} aside); beside it waves 1..3 run the part of the trailing update of column
+        // k - 1 that D_k does not depend on; the block row of S that enters the ring replaces row k - 1
+        if (wave == 0) {
+            double g1 = 0.0;
+            if (nb > 0 && lane < 36) g1 = (ring_row(kk, 1) + 36)[lane];
+            double inv[36];
+            const bool ok = band_inv6(rowk, inv);
+            if (nb > 0 && lane < 36) g1buf[lane] = g1;
+            if (lane == 0) {
+                if (!ok) sflag[0] = 1;
+                double2* o2 = reinterpret_cast<double2*>(Dk);
+#pragma unroll
+                for (int q = 0; q < 18; ++q) o2[q] = make_double2(inv[2 * q], inv[2 * q + 1]);
+            }
+#ifdef VISFS_BA_STAMPS
+            if (lane == 0 && k < 16) sstamp[2 + 6 * k] = wall_clock64();
+#endif
+        } else if (k > 0) {
+            // the block row of S that entered the registers one step ago goes to the ring row it replaces (its loads have had a whole
+            // step to arrive), then the loads of the next one are issued: block row k - 1 + RR, into the ring row of block row k - 1
+            if (pend_row >= 0) {
+                double* dst = ring + (size_t)pend_row * rowsz;
+#pragma unroll
+                for (int u = 0; u < NPEND; ++u) { const int t = tid - 64 + (BAND_T - 64) * u; if (t < rowsz) dst[t] = pend[u]; }
+                pend_row = -1;
+            }
+            const int Inew = k - 1 + RR;
+            if (!resident && Inew < Npf) {
+                const int* code = scode + Inew * W;             // (from LDS: a block id fetched from HBM first would be a second dependent global round trip)
+#pragma unroll
+                for (int u = 0; u < NPEND; ++u) {
+                    const int t = tid - 64 + (BAND_T - 64) * u;
+                    pend[u] = 0.0;
+                    if (t < rowsz) { const int d = t / 36, q = t - 36 * d, b = code[d]; if (b >= 0) pend[u] = g.S[36 * (size_t)b + 6 * (q % 6) + q / 6]; }
+                }
+                pend_row = kp;
+            }
+            syrk_rest(k - 1, kp);
+#ifdef VISFS_BA_STAMPS
+            if (tid == 64 && k < 16) sstamp[3 + 6 * k] = wall_clock64();
+#endif
+        }
+        BAND_SYNC();
+        if (k < 16) BAND_STAMP(4 + 6 * k);
+        if (sflag[0]) { if (tid == 0) st->solver_failed = 1; return; }
+        // ---- B: L_ik = G_ik D_k^-1, two threads per block row (three columns each), G_ik kept aside for the trailing update; the same
+        // threads then take L_ik G_{k+1,k}^T out of block (i, k + 1) — the one column the next diagonal block depends on
+        {
+            if (wave == 3 && k > 0) fwd_step(k - 1, kp);           // the forward substitution of the previous column rides on the idle wave
+            double* G = gk + (size_t)(k & 1) * rowsz;
+            for (int t = tid; t < 12 * nb; t += BAND_T) {
+                const int m = t / 12 + 1, u = t - 12 * (m - 1), rr = u >> 1, hf = u & 1;
+                double* rowi = ring_row(kk, m);
+                double* row = rowi + 36 * m + 6 * rr;
+                double* C = rowi + 36 * (m - 1) + 6 * rr + 3 * hf;    // block (k + m, k + 1), columns 3 hf ..
+                const double* dcol = Dk + 18 * hf;                    // rows 3 hf .. of the symmetric D^-1 = its columns
+                const double* g1r = g1buf + 18 * hf;                  // rows 3 hf .. of G_{k+1,k}
+                // every load first (one LDS round trip), static register indices throughout (hf only ever enters addresses and selects)
+                double a[6], dc[18], g1[18], cv[3];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a[c] = row[c];
+#pragma unroll
+                for (int q = 0; q < 18; ++q) { dc[q] = dcol[q]; g1[q] = g1r[q]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cv[c] = C[c];
+                double o[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    o[c] = ((a[0] * dc[6 * c] + a[1] * dc[6 * c + 1]) + (a[2] * dc[6 * c + 2] + a[3] * dc[6 * c + 3])) + (a[4] * dc[6 * c + 4] + a[5] * dc[6 * c + 5]);
+                double* gr = G + 36 * m + 6 * rr + 3 * hf;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { gr[c] = hf ? a[3 + c] : a[c]; row[3 * hf + c] = o[c]; }   // (the partner lane has read the row: same wavefront, program order)
+                if (!resident) {
+                    double* h = g.band_L + (size_t)(k + m) * rowsz + 36 * m + 6 * rr + 3 * hf;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) h[c] = o[c];
+                }
+                // the whole row of L_ik: the partner lane (t ^ 1) holds the other three columns
+                double l[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const double other = xor_lane<1>(o[c]); l[c] = hf ? other : o[c]; l[3 + c] = hf ? o[c] : other; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    C[c] = cv[c] - (((l[0] * g1[6 * c] + l[1] * g1[6 * c + 1]) + (l[2] * g1[6 * c + 2] + l[3] * g1[6 * c + 3])) + (l[4] * g1[6 * c + 4] + l[5] * g1[6 * c + 5]));
+            }
+        }
+        BAND_SYNC();
+        if (k < 16) BAND_STAMP(5 + 6 * k);
+        kp = kk;
+        if (++kk == RR) kk = 0;
+    }
+    BAND_STAMP(110);
+    // ---- backward substitution, one wavefront (the other waves only help to bring chunks of the factor back from HBM)
+    if (wave == 0) fwd_step(Npf - 1, kp);                      // the last forward step: no blocks below
+    __syncthreads();
+    for (int k1 = Npf; k1 > 0;) {
+        const int k0 = resident ? 0 : max(0, k1 - RR);
+        if (!resident) {
+            // rows [k0, k1) of the factor: contiguous in band_L, RR rows at most -> distinct ring rows
+            const int cnt = (k1 - k0) * rowsz;
+            const double* srcp = g.band_L + (size_t)k0 * rowsz;
+            constexpr int U = 8;
+            for (int t0 = tid; t0 < cnt; t0 += BAND_T * U) {
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int t = t0 + BAND_T * u; v[u] = t < cnt ? srcp[t] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + BAND_T * u;
+                    if (t < cnt) { const int r = t / rowsz, c = t - rowsz * r; ring[(size_t)((k0 + r) % RR) * rowsz + c] = v[u]; }
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            int kr = (k1 - 1) % RR;
+            for (int k = k1 - 1; k >= k0; --k) {
+                // x_k is final (every row below has been taken out of it): z_j -= L_kj^T x_k for the blocks to the left
+                const double* rowk = ring + (size_t)kr * rowsz;
+                double xk[6];
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) xk[rr] = cvec[6 * k + rr];
+                const int nbk = min(B, k);
+                for (int e = lane; e < 6 * nbk; e += 64) {
+                    const int m = e / 6 + 1, cc = e - 6 * (m - 1);
+                    const double* L = rowk + 36 * m;           // L_kj, j = k - m
+                    double acc = cvec[6 * (k - m) + cc];
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) acc -= L[6 * rr + cc] * xk[rr];
+                    cvec[6 * (k - m) + cc] = acc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (--kr < 0) kr = RR - 1;
+            }
+        }
+        __syncthreads();
+        k1 = k0;
+    }
+    BAND_STAMP(111);
+    for (int t = tid; t < 6 * Npf; t += BAND_T) g.x[t] = cvec[t];
+    const int sel = st->sel;
+    for (int a = tid; a < Npf; a += BAND_T) {
+        const int ip = g.free_pose[a];
+        double dx[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dx[q] = cvec[6 * a + q];
+        pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+    }
+    BAND_STAMP(112);
+#ifdef VISFS_BA_STAMPS
+    __syncthreads();
+    if (tid < 126) g.stamps[tid] = sstamp[tid];
+#endif
+}
+
 // K7 + trial chi2 for one landmark handled by G lanes: dl = (Hll + lambda I)^-1 (b_l - sum_i Hpl_il^T x_i), the trial point,
 // and the robust chi2 of its edges at the trial state.  sRt = trial poses, sRt0 = poses of the linearisation point.
 template <int G, bool STG = true>
@@ -3280,6 +3664,11 @@ void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream
 }
 
 void launch_direct(const DeviceGraph& g, hipStream_t s) {
+    if (g.band_B >= 0) {                                                      // block-banded S: one workgroup, one launch
+        ensure_lds(k_band_chol<One>, (size_t)g.band_lds_bytes);
+        TIMED_LAUNCH((k_band_chol<One>), dim3(1), dim3(BAND_T), (size_t)g.band_lds_bytes, s, One{ g });
+        return;
+    }
     const int NP = g.chol_np;
     int grid = (g.n_blk * 36 + 255) / 256;
     if (grid > 1024) grid = 1024;

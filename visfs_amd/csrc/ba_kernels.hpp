@@ -32,6 +32,9 @@ void launch_ceres_lin_finalize(const DeviceGraph& g, hipStream_t s);  // Optimiz
 void launch_backsub_decide(const DeviceGraph& g, hipStream_t s);    // gated unit: the launch also takes the LM decision (no k_decide)
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
+size_t band_lds_bytes(int npf, int B, int rows);                       // dynamic LDS of the banded direct solver (k_band_chol) with `rows` block rows resident
+constexpr int BAND_LDS_BUDGET = 156 * 1024;
+bool band_plan(int npf, int B, int* rows, int* lds_bytes);             // false: the band is too wide for k_band_chol (dense blocked Cholesky instead)
 bool pcg_cu_fits(int npf, int max_row);                               // the reduced system fits the single-workgroup PCG (k_pcg_cu)
 bool small_solve_fits(const DeviceGraph& g);                         // 6 Npf <= 64: S is finalised and solved by one workgroup
 void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s);   // k_schur_finalize + solver + K8 in one launch
