@@ -203,33 +203,35 @@ def test_batch_sharded_over_handles_equals_one_handle(olib):
     for s in (one, a, b, c): s.close()
 
 
-def test_batches_of_sixteen_and_more_use_the_single_workgroup_pcg(olib, monkeypatch):
-    """From 16 windows on, the members of a batch solve their reduced systems with k_pcg_cu (one workgroup per window, no
-    cross-workgroup hand-off: 16 C2 windows 68.0 -> 70.6 k it/s, 32 windows 66.6 -> 74.3 k; 8 windows would lose).  Its mat-vec sums
-    associate differently from k_pcg1's: the batch equals single-window solves to rounding with identical iteration counts and
-    outlier sets; with VISFS_BA_PCG_CU=0 it is bit-identical again."""
+def test_a_window_s_result_never_depends_on_the_size_of_its_batch(olib, monkeypatch):
+    """the PCG kernel of a window must not follow the number of OTHER windows submitted with it.  A 16-window batch, its two
+    sharded halves and sixteen single solves give the same bytes.  k_pcg_cu (the whole PCG in one workgroup: +3..+10 % throughput
+    from 16 C2 windows on, mat-vec sums in a different order) is opt-in (VISFS_BA_PCG_CU=1): it then equals single-window solves to
+    rounding, with identical iteration counts and outlier sets."""
     from visfs_amd import backend
     prm = abi.default_params(iterations=10, solver=2)
     ws = [synth.make_window("custom", n_kf=14, n_lm=300, n_obs=2400, seed=120 + i) for i in range(16)]
     s = backend.Solver(prm)
     singles = [s.solve_window(abi.WindowBuffers(w)) for w in ws]
     got = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    halves = s.solve_batch([abi.WindowBuffers(w) for w in ws[:8]]) + s.solve_batch([abi.WindowBuffers(w) for w in ws[8:]])
+    s.close()
+    for (rc, a), b, c in zip(singles, got, halves):
+        assert rc == b.struct.status == c.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert np.array_equal(b.pose_Twr_out, c.pose_Twr_out) and b.outliers() == c.outliers()
+    monkeypatch.setenv("VISFS_BA_PCG_CU", "1")
+    s = backend.Solver(prm)
+    got1 = s.solve_batch([abi.WindowBuffers(w) for w in ws])
     s.close()
     exact = 0
-    for (rc, a), b in zip(singles, got):
-        assert rc == b.struct.status == abi.OK
+    for (rc, a), b in zip(singles, got1):
+        assert b.struct.status == abi.OK
         assert list(a.struct.iterations_run) == list(b.struct.iterations_run) and a.outliers() == b.outliers()
         et, er = synth.pose_errors(b.pose_Twr_out[:14], a.pose_Twr_out[:14])
         assert et < 1e-9 and er < 1e-9
         exact += int(np.array_equal(a.pose_Twr_out, b.pose_Twr_out))
     assert exact < 16                                            # a different kernel really ran
-    monkeypatch.setenv("VISFS_BA_PCG_CU", "0")
-    s = backend.Solver(prm)
-    got0 = s.solve_batch([abi.WindowBuffers(w) for w in ws])
-    s.close()
-    for (rc, a), b in zip(singles, got0):
-        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
-
 
 def test_describe_names_the_kernel_that_solves_the_reduced_system(olib):
     """visfs_ba_graph_info::solver_kernel: the symbol a kernel trace shows for the solver class (bench.py's roofline.kernel_symbol)."""

@@ -197,3 +197,83 @@ def test_estimator_loop_on_gpu_matches_localmap_plus_oracle(wlib, olib):
             assert rel_err(f["pose"], np.array(g["pose"])) < 1e-7
     s.close()
     assert solved >= 20
+
+
+@pytest.mark.gpu
+def test_a_handle_that_lives_across_frames_equals_fresh_uploads(wlib, monkeypatch):
+    """The per-frame call path (Estimator.cpp:254): ONE handle serves 30 consecutive windows of the sliding map — its device arenas,
+    pinned staging and host threads survive from frame to frame while poses, landmarks and observations enter and leave — and every
+    result must be the bytes of (a) a fresh handle solving that window alone and (b) the GRAPH layer fed by the serial graph build
+    (visfs_ba_pack_window -> visfs_ba_graph_upload -> optimize -> download): nothing a previous frame left behind may leak into the next."""
+    import types
+    from visfs_amd import backend
+    fe = FrontEnd(seed=33, n_tracks=180, p_no_wheel=0.1)
+    wm = window.WindowMap(lib=wlib)
+    prm = abi.default_params(iterations=10, solver=2)
+    keep = backend.Solver(prm)
+    solved = 0
+    for _ in range(30):
+        insert_native(wm, fe.frame())
+        if wm.available():
+            wm.build(fe.Trc, fe.fx, fe.fy, fe.cx, fe.cy, fe.baseline, 2, True)
+            win = types.SimpleNamespace(struct=wm.struct, point_xyz=np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3)),
+                                        point_fixed=np.ctypeslib.as_array(wm.struct.point_fixed, shape=(wm.struct.n_points,)), laser_xyz=np.zeros((0, 3)), grid=None)
+            xyz0 = np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3)).copy()
+            rc_a, rb_a = keep.solve_window(win)
+            xyz_a = np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3)).copy()
+            np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3))[:] = xyz0           # localOptimize writes the landmarks in place
+            fresh = backend.Solver(prm)
+            rc_b, rb_b = fresh.solve_window(win)
+            xyz_b = np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3)).copy()
+            np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3))[:] = xyz0
+            assert rc_a == rc_b and rb_a.outliers() == rb_b.outliers()
+            n = rb_a.struct.n_poses_out
+            assert n == rb_b.struct.n_poses_out and np.array_equal(rb_a.pose_Twr_out[:n], rb_b.pose_Twr_out[:n])
+            assert np.array_equal(xyz_a, xyz_b, equal_nan=True)
+            # the GRAPH layer on the serial graph build
+            gb, used, oref, mono = abi.pack_window_with(fresh.lib.visfs_ba_pack_window, prm, win)
+            fresh.upload(gb)
+            rc_c, st_c = fresh.optimize()
+            pose_c, pt_c, out_c, _ = fresh.download()
+            fresh.close()
+            if rc_a == abi.OK:
+                assert rc_c == abi.OK
+                twr = np.zeros((len(pose_c), 12))
+                trc = np.ascontiguousarray(fe.Trc, np.float64).reshape(12)
+                for i in range(len(pose_c)):
+                    keep.lib.visfs_ba_unpack_pose(np.ascontiguousarray(pose_c[i]).ctypes.data_as(C.POINTER(C.c_double)), trc.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  twr[i].ctypes.data_as(C.POINTER(C.c_double)))
+                assert np.array_equal(twr, rb_a.pose_Twr_out[:n])
+                assert [(int(wm.struct.ref_feature[oref[k]]), int(wm.struct.ref_pose[oref[k]])) for k in np.nonzero(out_c)[0]] == rb_a.outliers()
+                if rb_a.struct.n_poses_out == wm.struct.n_poses:
+                    np.ctypeslib.as_array(wm.struct.point_xyz, shape=(wm.struct.n_points, 3))[:] = xyz_a
+                    wm.apply(rb_a.struct)
+                    solved += 1
+        wm.remove()
+    keep.close()
+    assert solved >= 15
+
+
+@pytest.mark.gpu
+def test_graph_build_on_host_threads_gives_the_serial_bytes(monkeypatch):
+    """BASELINE C2 through visfs_ba_solve_window with one host thread and with four (references shared out at feature boundaries,
+    structure summary per thread): identical poses, landmarks and outlier lists — and identical to the GRAPH layer on the serial build."""
+    from visfs_amd import backend, synth
+    w = synth.make_window("C2")
+    prm = abi.default_params(iterations=10, solver=2)
+    res = {}
+    for nthreads in ("1", "4"):
+        monkeypatch.setenv("VISFS_BA_THREADS", nthreads)
+        s = backend.Solver(prm)
+        wb = abi.WindowBuffers(w)
+        rc, rb = s.solve_window(wb)
+        assert rc == abi.OK
+        res[nthreads] = (rb.pose_Twr_out.copy(), wb.point_xyz.copy(), rb.outliers())
+        if nthreads == "4":
+            gb, used, oref, mono = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+            s.upload(gb); rcg, _ = s.optimize(); pose_g, pt_g, out_g, _ = s.download()
+            assert rcg == abi.OK
+            wbg = abi.WindowBuffers(w)
+            assert [(int(wbg.ref_feature[oref[k]]), int(wbg.ref_pose[oref[k]])) for k in np.nonzero(out_g)[0]] == res["4"][2]
+        s.close()
+    assert np.array_equal(res["1"][0], res["4"][0]) and np.array_equal(res["1"][1], res["4"][1], equal_nan=True) and res["1"][2] == res["4"][2]

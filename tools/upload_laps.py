@@ -15,6 +15,9 @@ def main():
         for rep in range(3):
             print(f"== {cfg} upload #{rep}", file=sys.stderr, flush=True)
             s.upload(gb)
+        for rep in range(3):
+            print(f"== {cfg} solve_window #{rep}", file=sys.stderr, flush=True)
+            s.solve_window(abi.WindowBuffers(w))
         s.close()
 
 

@@ -8,7 +8,7 @@ CSRC = os.path.join(ROOT, "visfs_amd", "csrc")
 LIB_DIR = os.path.join(ROOT, "visfs_amd", "lib")
 LIB = os.path.join(LIB_DIR, "libvisfs_ba_hip.so")
 SOURCES = ["ba_kernels.hip", "ba_api.cpp"]
-HEADERS = ["ba_math.hpp", "ba_device.hpp", "ba_kernels.hpp", os.path.join("..", "..", "include", "visfs_ba.h")]
+HEADERS = ["ba_math.hpp", "ba_device.hpp", "ba_kernels.hpp", "worker_pool.hpp", os.path.join("..", "..", "include", "visfs_ba.h")]
 
 
 def _stale(target, deps):

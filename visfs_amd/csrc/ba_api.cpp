@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <functional>
 #include <map>
+#include <memory>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -21,6 +24,7 @@
 
 #include "../../include/visfs_ba.h"
 #include "ba_kernels.hpp"
+#include "worker_pool.hpp"
 
 using namespace visfs_ba;
 
@@ -40,11 +44,23 @@ struct Arena {
     }
 };
 
+// Host scratch of the window layer that survives from call to call (a fresh std::vector of this size is an mmap, a page fault per
+// 4 KiB on first touch and an munmap, every frame — and page faults from several threads at once serialise in the kernel).
+struct SummaryPart { std::vector<int32_t> cnt, run, pc; int64_t pairs = 0; int ok = 0; bool any_run = false, used = false; const char* bad = nullptr; };
+struct PackedWindow {
+    std::vector<uint8_t> pose_fixed, point_used;
+    std::vector<int32_t> obs_ref;
+    visfs_ba_graph g{};               // its arrays live in the workspace's primary staging arena (the device layout)
+    int32_t mono = 0;
+};
+
 // One resident window: device arena + host mirrors of what the host needs later.
 struct Workspace {
     hipStream_t stream = nullptr;
     char* d_base = nullptr;  size_t d_cap = 0;
-    char* h_base = nullptr;  size_t h_cap = 0;     // pinned staging, same layout as the static part
+    char* h_base = nullptr;  size_t h_cap = 0;     // pinned staging: the index section (same layout as on the device), later the outputs of a solve
+    char* d_prim = nullptr;  size_t d_prim_cap = 0;   // the primary section (poses, landmarks, observations, odometry / laser measurements) ...
+    char* h_prim = nullptr;  size_t h_prim_cap = 0;   // ... and its pinned staging arena: the window layer packs straight into it
     LmState* h_state = nullptr;                    // pinned
     DeviceGraph g{};
     bool loaded = false;
@@ -64,6 +80,9 @@ struct Workspace {
     bool upload_in_flight = false;                 // ws_upload no longer drains its stream: whoever uses the graph from ANOTHER stream must (batch_optimize)
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
+    PackedWindow pk;                               // window layer: what the graph build leaves on the host (persistent buffers)
+    std::vector<SummaryPart> sum_part;             // per-thread accumulators of summarize_graph (persistent buffers)
+    std::vector<int32_t> sum_run;
     int64_t n_pairs = 0;
     size_t device_bytes = 0;
     // measurement: hipEvent pairs around the launches of the enabled kernel classes
@@ -132,6 +151,8 @@ struct visfs_ba_handle {
     BatchScratch scratch;
     std::vector<BatchScratch> part_scratch;        // further parts of a split batch (batch_optimize_group): scratch and stream of part k + 1
     std::vector<hipStream_t> part_stream;
+    std::unique_ptr<WorkerPool> pool;              // host threads of the window layer (created at the first visfs_ba_solve_window)
+    bool pool_tried = false;
 };
 
 namespace {
@@ -147,6 +168,18 @@ namespace {
 
 int bad(visfs_ba_handle* h, const char* msg) { h->err = msg; return VISFS_BA_ERR_BAD_ARGUMENT; }
 
+// Host threads for the O(N_obs) passes of a window solve: VISFS_BA_THREADS in total (default: min(4, hardware threads)), 1 = none.
+WorkerPool* host_pool(visfs_ba_handle* h) {
+    if (!h->pool_tried) {
+        h->pool_tried = true;
+        const char* e = std::getenv("VISFS_BA_THREADS");
+        int n = e ? std::atoi(e) : (int)std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+        n = std::max(1, std::min(n, 16));
+        if (n > 1) { try { h->pool.reset(new WorkerPool(n - 1)); } catch (...) { h->pool.reset(); } }
+    }
+    return h->pool.get();
+}
+
 // No exception may cross the C ABI: host allocations (std::vector, std::string, std::thread) can throw.
 template <typename F>
 int guarded(visfs_ba_handle* h, F&& f) noexcept {
@@ -159,6 +192,8 @@ int guarded(visfs_ba_handle* h, F&& f) noexcept {
 void ws_release(Workspace& w) {
     if (w.d_base) (void)hipFree(w.d_base);
     if (w.h_base) (void)hipHostFree(w.h_base);
+    if (w.d_prim) (void)hipFree(w.d_prim);
+    if (w.h_prim) (void)hipHostFree(w.h_prim);
     if (w.h_state) (void)hipHostFree(w.h_state);
     for (hipEvent_t e : w.ev_pool) (void)hipEventDestroy(e);
     if (w.graph_exec) (void)hipGraphExecDestroy(w.graph_exec);
@@ -174,8 +209,155 @@ int ws_init(visfs_ba_handle* h, Workspace& w) {
     return VISFS_BA_OK;
 }
 
+// bytes of the pinned arena a solve's outputs need when they travel with its state read (layout: output_stage_of, below)
+size_t output_stage_bytes(const DeviceGraph& g) {
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    return 2 * up((size_t)g.Np * POSE_STRIDE * 8) + 2 * up((size_t)g.Nl * 24) + (size_t)g.No;
+}
+
 // ------------------------------------------------------------------ graph → device structures
-int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
+// The PRIMARY section: what localOptimize's inputs carry (poses, landmarks, observations, odometry / laser measurements), in its own
+// device allocation and pinned staging arena.  Its layout depends only on the sizes below, so (a) the window layer packs straight
+// into the staging arena (no second copy of anything of size N_obs) and (b) its host-to-device copy starts before the structure of
+// S has been worked out.
+struct PrimSizes { int Np = 0, Nl = 0, cap_obs = 0, cap_odo = 0, Nz = 0; size_t grid_cells = 0; };
+void layout_prim(Arena& A, DeviceGraph& g, const PrimSizes& z) {
+    g.pose0 = A.take<double>((size_t)z.Np * POSE_STRIDE);
+    g.pt0 = A.take<double>((size_t)std::max(z.Nl, 1) * 3);
+    g.pose_free = A.take<int32_t>(z.Np);
+    g.free_pose = A.take<int32_t>(z.Np);
+    g.pt_fixed = A.take<uint8_t>(std::max(z.Nl, 1));
+    g.obs_pose = A.take<int32_t>(std::max(z.cap_obs, 1));
+    g.obs_pt = A.take<int32_t>(std::max(z.cap_obs, 1));
+    g.obs_uvr = A.take<double>((size_t)std::max(z.cap_obs, 1) * 3);
+    g.odo_i = A.take<int32_t>(std::max(z.cap_odo, 1));
+    g.odo_j = A.take<int32_t>(std::max(z.cap_odo, 1));
+    g.odo_tq = A.take<double>((size_t)std::max(z.cap_odo, 1) * 7);
+    g.laser_xyz = A.take<double>((size_t)std::max(z.Nz, 1) * 3);
+    g.grid.cost = A.take<float>(std::max<size_t>(z.grid_cells, 1));
+}
+size_t prim_bytes(const PrimSizes& z) { Arena a{ nullptr, 0, 0 }; DeviceGraph g{}; layout_prim(a, g, z); return (a.used + 255) & ~size_t(255); }
+int ensure_prim(visfs_ba_handle* h, Workspace& w, size_t bytes) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (w.h_prim_cap < bytes) {
+        // (the previous upload's host-to-device copy reads the arena that is about to be replaced)
+        if (w.stream) HIP_TRY(h, hipStreamSynchronize(w.stream));
+        if (w.h_prim) (void)hipHostFree(w.h_prim);
+        w.h_prim = nullptr; w.h_prim_cap = 0;
+        const size_t want = bytes + bytes / 4;                                                   // a sliding window grows and shrinks by a few observations per frame
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&w.h_prim), want, hipHostMallocDefault));
+        w.h_prim_cap = want;
+    }
+    if (w.d_prim_cap < bytes) {
+        if (w.stream) HIP_TRY(h, hipStreamSynchronize(w.stream));
+        if (w.d_prim) (void)hipFree(w.d_prim);
+        w.d_prim = nullptr; w.d_prim_cap = 0;
+        const size_t want = bytes + bytes / 4;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&w.d_prim), want));
+        w.d_prim_cap = want;
+    }
+    return VISFS_BA_OK;
+}
+
+// What the host has to know about the O(N_obs) part of the graph: observations per free pose and co-observation pairs per block of S.
+struct GraphSummary {
+    std::vector<int32_t> cnt;          // [Npf + 1] prefix: observations of free pose a at pose-major positions [cnt[a], cnt[a + 1])
+    std::vector<int32_t> pcount;       // [Npf][Npf] (a <= b): free landmarks observed by both
+    int64_t pairs_seen = 0;
+    int n_edges_ok = 0;
+    const char* bad = nullptr;
+};
+// One pass over the observations (landmark-major), shared out over the pool at landmark boundaries.
+// A landmark seen by the free poses {a_1 < ... < a_k} adds one pair to every block (a_i, a_j), i <= j.  Tracks are runs of consecutive
+// key-frames almost always (a feature is tracked frame to frame and never re-acquired), so a landmark whose free poses form the
+// contiguous range [s, e] only bumps run[s][e]; the blocks are then counted by one 2-D inclusion sum, pcount[a][b] = sum over s <= a,
+// e >= b of run[s][e] — O(Nl + Npf^2) instead of O(sum k^2).  Landmarks with gaps in their track take the pairwise loop.
+void summarize_graph(const visfs_ba_graph* gr, const int32_t* pose_free, const int Npf, WorkerPool* pool, const bool check, GraphSummary& S,
+                     std::vector<SummaryPart>& part, std::vector<int32_t>& run) {
+    const int No = gr->n_obs, Nl = gr->n_points, Np = gr->n_poses;
+    const size_t nn = (size_t)Npf * Npf;
+    // several tasks per thread (a worker that wakes late still finds work); accumulators per THREAD, not per task
+    const int NT = (pool && No >= 16384 && nn <= ((size_t)1 << 17)) ? pool->size() : 1;
+    const int T = NT > 1 ? 4 * NT : 1;
+    std::vector<int> cut(T + 1, No);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        int k = (int)((int64_t)No * t / T);
+        k = std::max(k, cut[t - 1]);
+        while (k > 0 && k < No && gr->obs_point[k] == gr->obs_point[k - 1]) ++k;     // a landmark's observations stay with one task
+        cut[t] = k;
+    }
+    typedef SummaryPart Part;
+    if ((int)part.size() < NT) part.resize(NT);
+    for (int t = 0; t < NT; ++t) { Part& P = part[t]; P.used = false; P.pairs = 0; P.ok = 0; P.any_run = false; P.bad = nullptr; P.pc.clear(); }
+    auto body = [&](int t, int slot) {
+        Part& P = part[slot];
+        if (!P.used) { P.used = true; P.cnt.assign(Npf + 1, 0); P.run.assign(nn, 0); }
+        if (P.bad) return;
+        const int k_lo = cut[t], k_hi = cut[t + 1];
+        int k = k_lo;
+        while (k < k_hi) {
+            const int l = gr->obs_point[k];
+            if (check && (l < 0 || l >= Nl)) { P.bad = "observation index out of range"; return; }
+            if (check && k > 0 && l < gr->obs_point[k - 1]) { P.bad = "observations must be sorted by (point, pose) and unique"; return; }
+            const bool lfix = gr->point_fixed[l] != 0;
+            int first = -1, last = -1, c = 0, ks = k;
+            for (; k < k_hi && gr->obs_point[k] == l; ++k) {
+                const int cp = gr->obs_pose[k];
+                if (check && (cp < 0 || cp >= Np)) { P.bad = "observation index out of range"; return; }
+                if (check && k > ks && cp <= gr->obs_pose[k - 1]) { P.bad = "observations must be sorted by (point, pose) and unique"; return; }
+                const int a = pose_free[cp];
+                P.ok += !(a < 0 && lfix);
+                if (a >= 0) { P.cnt[a + 1]++; if (first < 0) first = a; last = a; ++c; }
+            }
+            if (lfix || c == 0) continue;
+            P.pairs += (int64_t)c * (c + 1) / 2;
+            if (last - first + 1 == c) { P.run[(size_t)first * Npf + last]++; P.any_run = true; continue; }   // (observations ascend by pose)
+            if (P.pc.empty()) P.pc.assign(nn, 0);                    // tracks with gaps are rare: their pairwise table only exists when one shows up
+            for (int k1 = ks; k1 < k; ++k1) {
+                const int a = pose_free[gr->obs_pose[k1]];
+                if (a < 0) continue;
+                int32_t* row = P.pc.data() + (size_t)a * Npf;
+                for (int k2 = k1; k2 < k; ++k2) { const int b2 = pose_free[gr->obs_pose[k2]]; if (b2 >= 0) row[b2]++; }
+            }
+        }
+    };
+    if (T > 1) pool->run(T, body); else body(0, 0);
+    S.cnt.assign(Npf + 1, 0); S.pcount.assign(nn, 0); S.pairs_seen = 0; S.n_edges_ok = 0; S.bad = nullptr;
+    run.assign(nn, 0);
+    bool any_run = false;
+    for (int t = 0; t < NT; ++t) {
+        const Part& P = part[t];
+        if (!P.used) continue;
+        if (P.bad) { S.bad = P.bad; return; }
+        for (int a = 0; a <= Npf; ++a) S.cnt[a] += P.cnt[a];
+        if (!P.pc.empty()) for (size_t q = 0; q < nn; ++q) S.pcount[q] += P.pc[q];
+        for (size_t q = 0; q < nn; ++q) run[q] += P.run[q];
+        S.pairs_seen += P.pairs; S.n_edges_ok += P.ok; any_run = any_run || P.any_run;
+    }
+    for (int a = 0; a < Npf; ++a) S.cnt[a + 1] += S.cnt[a];
+    if (any_run) {
+        // in place: run[a][b] <- sum_{s <= a, e >= b} run[s][e]
+        for (int a = 0; a < Npf; ++a)
+            for (int b2 = Npf - 1; b2 >= 0; --b2) {
+                int64_t v = run[(size_t)a * Npf + b2];
+                if (a > 0) v += run[(size_t)(a - 1) * Npf + b2];
+                if (b2 + 1 < Npf) v += run[(size_t)a * Npf + b2 + 1];
+                if (a > 0 && b2 + 1 < Npf) v -= run[(size_t)(a - 1) * Npf + b2 + 1];
+                run[(size_t)a * Npf + b2] = (int32_t)v;
+            }
+        for (int a = 0; a < Npf; ++a) for (int b2 = a; b2 < Npf; ++b2) S.pcount[(size_t)a * Npf + b2] += run[(size_t)a * Npf + b2];
+    }
+}
+
+struct UploadOpts {
+    bool in_staging = false;   // the graph's arrays already live in the workspace's primary staging arena, laid out for `cap` (window layer)
+    PrimSizes cap;             // ... the sizes that layout was made for
+    bool trusted = false;      // ... and were produced by the library's own graph build: no validation pass
+    WorkerPool* pool = nullptr;
+};
+
+int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const UploadOpts& opt = UploadOpts()) {
     const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (timing) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "  upload %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
@@ -184,12 +366,6 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // (Optimizer.cpp:405-422: the Ceres branch never adds a wheel-odometry factor — links between two window poses fall in its "TODO" arm)
     const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = ceres ? 0 : gr->n_odo;
     if (Np < 1 || Nl < 0 || No < 0 || Ne < 0) return bad(h, "negative sizes");
-    for (int k = 0; k < No; ++k) {
-        const int p = gr->obs_point[k], c = gr->obs_pose[k];
-        if (p < 0 || p >= Nl || c < 0 || c >= Np) return bad(h, "observation index out of range");
-        if (k > 0 && (p < gr->obs_point[k - 1] || (p == gr->obs_point[k - 1] && c <= gr->obs_pose[k - 1])))
-            return bad(h, "observations must be sorted by (point, pose) and unique");
-    }
     for (int e = 0; e < Ne; ++e)
         if (gr->odo_from[e] < 0 || gr->odo_from[e] >= Np || gr->odo_to[e] < 0 || gr->odo_to[e] >= Np || gr->odo_from[e] == gr->odo_to[e])
             return bad(h, "odometry edge index out of range");
@@ -209,25 +385,61 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     if (rc != VISFS_BA_OK) return rc;
     if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; w.graph_units[0] = w.graph_units[1] = -1; }   // kernel arguments change
     w.solves_since_upload = 0;
-    HIP_TRY(h, hipStreamSynchronize(w.stream));            // the previous upload's H2D copy reads the pinned staging arena filled below
+    HIP_TRY(h, hipSetDevice(h->device));
 
+    // ---- the primary section: staged (or already there), then on its way to the device while the structure of S is worked out
+    PrimSizes pz;
+    if (opt.in_staging) pz = opt.cap;
+    else {
+        pz.Np = Np; pz.Nl = Nl; pz.cap_obs = No; pz.cap_odo = Ne; pz.Nz = Nz; pz.grid_cells = grid_cells;
+        HIP_TRY(h, hipStreamSynchronize(w.stream));        // the previous upload's H2D copy reads the pinned staging arenas filled below
+    }
+    const size_t pbytes = prim_bytes(pz);
+    rc = ensure_prim(h, w, pbytes);
+    if (rc != VISFS_BA_OK) return rc;
+    DeviceGraph hg{};                 // pointers into the pinned staging arenas
+    { Arena hp{ w.h_prim, w.h_prim_cap, 0 }; layout_prim(hp, hg, pz); }
+    if (!opt.in_staging) {
+        double* p0 = const_cast<double*>(hg.pose0);
+        for (int i = 0; i < Np; ++i) { for (int q = 0; q < 7; ++q) p0[POSE_STRIDE * i + q] = gr->pose_tq[7 * i + q]; p0[POSE_STRIDE * i + 7] = 0.0; }
+        if (Nl) std::memcpy(const_cast<double*>(hg.pt0), gr->point_xyz, (size_t)Nl * 24);
+        if (Nl) std::memcpy(const_cast<uint8_t*>(hg.pt_fixed), gr->point_fixed, Nl);
+        if (No) {
+            std::memcpy(const_cast<int32_t*>(hg.obs_pose), gr->obs_pose, (size_t)No * 4);
+            std::memcpy(const_cast<int32_t*>(hg.obs_pt), gr->obs_point, (size_t)No * 4);
+            std::memcpy(const_cast<double*>(hg.obs_uvr), gr->obs_uvr, (size_t)No * 24);
+        }
+        if (Ne) {
+            std::memcpy(const_cast<int32_t*>(hg.odo_i), gr->odo_from, (size_t)Ne * 4);
+            std::memcpy(const_cast<int32_t*>(hg.odo_j), gr->odo_to, (size_t)Ne * 4);
+            std::memcpy(const_cast<double*>(hg.odo_tq), gr->odo_tq, (size_t)Ne * 56);
+        }
+    }
+    if (Nz) {
+        std::memcpy(const_cast<double*>(hg.laser_xyz), gr->laser_xyz, (size_t)Nz * 24);
+        std::memcpy(const_cast<float*>(hg.grid.cost), gr->grid->correspondence_cost, grid_cells * 4);
+    }
     // buildIndexMapping: free poses in index (= id) order
     std::vector<int32_t> pose_free(Np), free_pose;
     for (int i = 0; i < Np; ++i) { if (gr->pose_fixed[i]) pose_free[i] = -1; else { pose_free[i] = (int32_t)free_pose.size(); free_pose.push_back(i); } }
     const int Npf = (int)free_pose.size();
-    std::vector<int32_t> lm_ptr(Nl + 1, 0);
-    for (int k = 0; k < No; ++k) lm_ptr[gr->obs_point[k] + 1]++;
-    for (int l = 0; l < Nl; ++l) lm_ptr[l + 1] += lm_ptr[l];
-    std::vector<uint8_t> obs_ok(std::max(No, 1));
-    int n_edges_ok = 0;
-    for (int k = 0; k < No; ++k) { obs_ok[k] = !(gr->pose_fixed[gr->obs_pose[k]] && gr->point_fixed[gr->obs_point[k]]); n_edges_ok += obs_ok[k]; }
+    std::memcpy(const_cast<int32_t*>(hg.pose_free), pose_free.data(), (size_t)Np * 4);
+    if (Npf) std::memcpy(const_cast<int32_t*>(hg.free_pose), free_pose.data(), (size_t)Npf * 4);
+    HIP_TRY(h, hipMemcpyAsync(w.d_prim, w.h_prim, pbytes, hipMemcpyHostToDevice, w.stream));
+    lap("primary");
 
-    // pose-major permutation of the observations of free poses, cut into chunks
-    std::vector<int32_t> cnt(Npf + 1, 0);
-    for (int k = 0; k < No; ++k) { const int a = pose_free[gr->obs_pose[k]]; if (a >= 0) cnt[a + 1]++; }
-    for (int a = 0; a < Npf; ++a) cnt[a + 1] += cnt[a];
-    std::vector<int32_t> pose_obs(std::max(cnt[Npf], 1)), fill(cnt.begin(), cnt.end() - 1);
-    for (int k = 0; k < No; ++k) { const int a = pose_free[gr->obs_pose[k]]; if (a >= 0) pose_obs[fill[a]++] = k; }
+    // ---- what the host needs of the O(N_obs) part: observations per free pose, co-observation pairs per block
+    GraphSummary sum;
+    summarize_graph(gr, pose_free.data(), Npf, opt.pool, !opt.trusted, sum, w.sum_part, w.sum_run);
+    if (sum.bad) return bad(h, sum.bad);
+    const std::vector<int32_t>& cnt = sum.cnt;
+    std::vector<int32_t>& pcount = sum.pcount;
+    const int64_t pairs_seen = sum.pairs_seen;
+    const int n_edges_ok = sum.n_edges_ok;
+    const int n_pose_obs = cnt[Npf];
+    lap("summary");
+
+    // pose-major chunks
     std::vector<int32_t> chunk_pose, chunk_ptr, pose_chunk_ptr(Npf + 1, 0);
     for (int a = 0; a < Npf; ++a) {
         pose_chunk_ptr[a] = (int32_t)chunk_pose.size();
@@ -236,11 +448,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     pose_chunk_ptr[Npf] = (int32_t)chunk_pose.size();
     const int n_chunks = (int)chunk_pose.size();
     chunk_ptr.push_back(cnt[Npf]);
-    // chunk c of pose a ends where the next chunk starts, or at the end of the pose's range
-    std::vector<int32_t> chunk_end(n_chunks);
-    for (int c = 0; c < n_chunks; ++c) chunk_end[c] = std::min(chunk_ptr[c] + LIN_CHUNK, cnt[chunk_pose[c] + 1]);
-    // k_linearize reads [chunk_ptr[c], chunk_ptr[c+1]) — consecutive chunks are contiguous, so chunk_ptr[c+1] == chunk_end[c]
-    for (int c = 0; c + 1 < n_chunks; ++c) if (chunk_ptr[c + 1] != chunk_end[c]) return bad(h, "internal: chunk layout");
+    // k_linearize reads [chunk_ptr[c], chunk_ptr[c+1]) — consecutive chunks are contiguous: chunk c of pose a ends where the next starts
+    for (int c = 0; c + 1 < n_chunks; ++c) if (chunk_ptr[c + 1] != std::min(chunk_ptr[c] + LIN_CHUNK, cnt[chunk_pose[c] + 1])) return bad(h, "internal: chunk layout");
 
     // odometry incidence
     std::vector<int32_t> pose_odo_ptr(Npf + 1, 0), pose_odo;
@@ -257,50 +466,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         pose_odo_ptr[Npf] = (int32_t)pose_odo.size();
     }
 
-    lap("index");
     // S block structure (g2o buildStructure analogue): per block (i<=j) the co-observation pairs
-    // free index of every observation's pose once (the two O(sum k_l^2) loops below read it k_l times per observation)
-    std::vector<int32_t> obs_free(std::max(No, 1));
-    for (int k = 0; k < No; ++k) obs_free[k] = pose_free[gr->obs_pose[k]];
-    std::vector<int32_t> pcount((size_t)Npf * Npf, 0);
     std::vector<uint8_t> has_odo((size_t)Npf * Npf, 0);
-    int64_t pairs_seen = 0;
-    {
-        // A landmark seen by the free poses {a_1 < ... < a_k} adds one pair to every block (a_i, a_j), i <= j.  Tracks are runs of
-        // consecutive key-frames almost always (a feature is tracked frame to frame and never re-acquired), so a landmark whose free
-        // poses form the contiguous range [s, e] only bumps run[s][e]; the blocks are then counted by one 2-D inclusion sum,
-        // pcount[a][b] = sum over s <= a, e >= b of run[s][e] — O(Nl + Npf^2) instead of O(sum k^2) (0.11 ms of a C2 upload, 0.64 ms
-        // at C4).  Landmarks with gaps in their track take the pairwise loop.
-        std::vector<int32_t> run((size_t)Npf * Npf, 0);
-        bool any_run = false;
-        for (int l = 0; l < Nl; ++l) {
-            if (gr->point_fixed[l]) continue;
-            const int k_end = lm_ptr[l + 1];
-            int first = -1, last = -1, cnt = 0;
-            for (int k = lm_ptr[l]; k < k_end; ++k) { const int a = obs_free[k]; if (a >= 0) { if (first < 0) first = a; last = a; ++cnt; } }
-            if (cnt == 0) continue;
-            pairs_seen += (int64_t)cnt * (cnt + 1) / 2;
-            if (last - first + 1 == cnt) { run[(size_t)first * Npf + last]++; any_run = true; continue; }     // (observations ascend by pose)
-            for (int k1 = lm_ptr[l]; k1 < k_end; ++k1) {
-                const int a = obs_free[k1];
-                if (a < 0) continue;
-                int32_t* row = pcount.data() + (size_t)a * Npf;
-                for (int k2 = k1; k2 < k_end; ++k2) { const int b = obs_free[k2]; if (b >= 0) row[b]++; }
-            }
-        }
-        if (any_run) {
-            // in place: run[a][b] <- sum_{s <= a, e >= b} run[s][e]
-            for (int a = 0; a < Npf; ++a)
-                for (int b = Npf - 1; b >= 0; --b) {
-                    int64_t v = run[(size_t)a * Npf + b];
-                    if (a > 0) v += run[(size_t)(a - 1) * Npf + b];
-                    if (b + 1 < Npf) v += run[(size_t)a * Npf + b + 1];
-                    if (a > 0 && b + 1 < Npf) v -= run[(size_t)(a - 1) * Npf + b + 1];
-                    run[(size_t)a * Npf + b] = (int32_t)v;
-                }
-            for (int a = 0; a < Npf; ++a) for (int b = a; b < Npf; ++b) pcount[(size_t)a * Npf + b] += run[(size_t)a * Npf + b];
-        }
-    }
     if (pairs_seen > 0x7fffffff) { h->err = "window too large (pair list)"; return VISFS_BA_ERR_UNSUPPORTED; }
     for (int e = 0; e < Ne; ++e) {
         int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
@@ -406,14 +573,15 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     // k_pcg_cu: the whole PCG in one workgroup when every block row is short enough to sit in registers (3 threads per scalar row)
     // One window: slower than k_pcg1 (34.7 vs 21.6 us per solve at C2, profiles/r02_pcg_cu_vs_handoff.log).  Many windows sharing every
     // launch: nothing spins and no hand-off is paid — 16 C2 windows 68.0 -> 70.6 k it/s, 32 windows 66.6 -> 74.3 k, but 8 windows
-    // 58.8 -> 55.6 k (profiles/r02_v3_pcg_cu_batches.log): the default for members of a batch of >= 16 windows; VISFS_BA_PCG_CU=0|1
-    // overrides.  Its mat-vec sums associate differently from k_pcg1's: such a batch agrees with single-window solves to rounding
-    // (same iteration counts: test_the_three_pcg_kernels_agree), not bit for bit like the smaller ones.
+    // 58.8 -> 55.6 k (profiles/r02_v3_pcg_cu_batches.log).  Its mat-vec sums associate differently from k_pcg1's, so a window's result
+    // would depend on how many OTHER windows were submitted with it if the kernel followed the batch size: it is opt-in
+    // (VISFS_BA_PCG_CU=1), never chosen from the batch — every window is bit-identical to
+    // its single-window solve however a batch is cut or sharded.
     const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
-                                const bool want = e ? (e[0] == '1') : (w.batch_member && w.batch_hint >= 16);
+                                const bool want = e && e[0] == '1';
                                 return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && want; }();
     // direct solver (Optimizer/Solver 0, 1, 3 and every solve of the Ceres branch): S of a sliding window is block-banded — the banded
-    // Cholesky in one workgroup (k_band_chol) when the band is narrow enough, the dense blocked Cholesky otherwise (VISFS_BA_BAND=0 forces it)
+    // factorisation in one workgroup (k_band_chol) when the band is narrow enough, the dense blocked Cholesky otherwise (VISFS_BA_BAND=0 forces it)
     int band_B = -1, band_rows = 0, band_lds = 0;
     std::vector<int32_t> band_code;
     if (prm.solver != 2 && Npf >= 1) {
@@ -428,7 +596,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
             for (int b = 0; b < n_blk; ++b) band_code[(size_t)blk_j[b] * (Bw + 1) + (blk_j[b] - blk_i[b])] = b;
         }
     }
-    lap("pair count");
+    lap("structure");
     // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
     int group = 4;
     const double mean_track = Nl > 0 ? (double)No / Nl : 1.0;
@@ -439,28 +607,15 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     const int n_parts = std::max(n_lin_a + 1, n_eval);
     const size_t n6 = (size_t)6 * Npf;
     const size_t chol_np = std::max<size_t>(32, (n6 + 31) / 32 * 32);
+    const size_t n_hist = (size_t)std::max(index_blocks(No), 1) * std::max(Npf, 1);
 
-    // ---- lay out the static section (host staging == device layout), then the mutable section
-    auto layout = [&](Arena& A, DeviceGraph& g, bool is_static_pass) {
-        (void)is_static_pass;
-        g.pose0 = A.take<double>((size_t)Np * POSE_STRIDE);
-        g.pt0 = A.take<double>((size_t)std::max(Nl, 1) * 3);
-        g.pose_free = A.take<int32_t>(Np);
-        g.free_pose = A.take<int32_t>(std::max(Npf, 1));
-        g.pt_fixed = A.take<uint8_t>(std::max(Nl, 1));
-        g.obs_pose = A.take<int32_t>(std::max(No, 1));
-        g.obs_pt = A.take<int32_t>(std::max(No, 1));
-        g.obs_ppos = A.take<int32_t>(std::max(No, 1));
-        g.obs_uvr = A.take<double>((size_t)std::max(No, 1) * 3);
-        g.obs_ok = A.take<uint8_t>(std::max(No, 1));
-        g.lm_ptr = A.take<int32_t>(Nl + 1);
+    // ---- the INDEX section (block-level structure of S, small) and the mutable section: one device arena, the index part staged in
+    // pinned memory with the same layout; everything of size N_obs that is derived (lm_ptr, obs_ok, pose_obs, obs_ppos, the pair
+    // lists) is built on the device from the primary section
+    auto layout = [&](Arena& A, DeviceGraph& g) {
         g.chunk_pose = A.take<int32_t>(std::max(n_chunks, 1));
         g.chunk_ptr = A.take<int32_t>(n_chunks + 1);
-        g.pose_obs = A.take<int32_t>(pose_obs.size());
         g.pose_chunk_ptr = A.take<int32_t>(Npf + 1);
-        g.odo_i = A.take<int32_t>(std::max(Ne, 1));
-        g.odo_j = A.take<int32_t>(std::max(Ne, 1));
-        g.odo_tq = A.take<double>((size_t)std::max(Ne, 1) * 7);
         g.pose_odo_ptr = A.take<int32_t>(Npf + 1);
         g.pose_odo = A.take<int32_t>(std::max<size_t>(pose_odo.size(), 1));
         g.blk_i = A.take<int32_t>(std::max(n_blk, 1));
@@ -476,22 +631,26 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
         g.pcg1_code = pcg1 ? A.take<int32_t>((size_t)Npf * Npf) : nullptr;
         g.band_code = band_B >= 0 ? A.take<int32_t>(band_code.size()) : nullptr;
-        g.laser_xyz = A.take<double>((size_t)std::max(Nz, 1) * 3);
-        g.grid.cost = A.take<float>(std::max<size_t>(grid_cells, 1));
     };
-    DeviceGraph hg{};                 // pointers into the pinned staging arena
     Arena sizing{ nullptr, 0, 0 };
-    layout(sizing, hg, true);
+    layout(sizing, hg);
     const size_t static_bytes = (sizing.used + 255) & ~size_t(255);
 
     Arena dyn{ nullptr, 0, static_bytes };
     DeviceGraph dg{};
+    int32_t* d_hist = nullptr;
     auto layout_dyn = [&](Arena& A, DeviceGraph& g) {
+        // device-built index arrays
+        g.lm_ptr = A.take<int32_t>(Nl + 1);
+        g.obs_ok = A.take<uint8_t>(std::max(No, 1));
+        g.obs_ppos = A.take<int32_t>(std::max(No, 1));
+        g.pose_obs = A.take<int32_t>(std::max(n_pose_obs, 1));
+        d_hist = A.take<int32_t>(n_hist);
         for (int k = 0; k < 2; ++k) {                       // the two linearisation sets: same layout, constant distance
             LinBuf& L = g.lin[k];
             L.obs_w = A.take<double>(std::max(No, 1));
             L.obs_pcw = A.take<double>((size_t)std::max(No, 1) * 4);
-            L.pose_pcw = A.take<double>(pose_obs.size() * 4);
+            L.pose_pcw = A.take<double>((size_t)std::max(n_pose_obs, 1) * 4);
             L.Hll = A.take<double>((size_t)std::max(Nl, 1) * 6);
             L.bl = A.take<double>((size_t)std::max(Nl, 1) * 3);
             L.hpp_part = A.take<double>((size_t)std::max(n_chunks, 1) * 27);
@@ -528,56 +687,40 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
         g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
-        g.pose_lm = A.take<int32_t>(pose_obs.size());                           // likewise
+        g.pose_lm = A.take<int32_t>(std::max(n_pose_obs, 1));                   // likewise
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
     };
     layout_dyn(dyn, dg);
     const size_t total_bytes = (dyn.used + 255) & ~size_t(255);
 
-    HIP_TRY(h, hipSetDevice(h->device));
     if (w.d_cap < total_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(w.stream));
         if (w.d_base) (void)hipFree(w.d_base);
         w.d_base = nullptr; w.d_cap = 0;
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&w.d_base), total_bytes));
-        w.d_cap = total_bytes;
+        const size_t want = total_bytes + total_bytes / 8;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&w.d_base), want));
+        w.d_cap = want;
     }
-    if (w.h_cap < static_bytes) {
+    // the pinned arena also receives the outputs of a solve (ws_read_state): both estimate buffers and the outlier flags
+    size_t host_need = static_bytes;
+    { DeviceGraph sz{}; sz.Np = Np; sz.Nl = Nl; sz.No = No; host_need = std::max(host_need, output_stage_bytes(sz)); }
+    if (w.h_cap < host_need) {
+        HIP_TRY(h, hipStreamSynchronize(w.stream));
         if (w.h_base) (void)hipHostFree(w.h_base);
         w.h_base = nullptr; w.h_cap = 0;
-        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&w.h_base), static_bytes, hipHostMallocDefault));
-        w.h_cap = static_bytes;
+        const size_t want = host_need + host_need / 8;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&w.h_base), want, hipHostMallocDefault));
+        w.h_cap = want;
     }
     lap("alloc");
-    // fill the staging arena
+    // fill the index staging
     Arena hs{ w.h_base, w.h_cap, 0 };
-    layout(hs, hg, true);
+    layout(hs, hg);
     {
-        double* p0 = const_cast<double*>(hg.pose0);
-        for (int i = 0; i < Np; ++i) { for (int q = 0; q < 7; ++q) p0[POSE_STRIDE * i + q] = gr->pose_tq[7 * i + q]; p0[POSE_STRIDE * i + 7] = 0.0; }
-        if (Nl) std::memcpy(const_cast<double*>(hg.pt0), gr->point_xyz, (size_t)Nl * 24);
-        std::memcpy(const_cast<int32_t*>(hg.pose_free), pose_free.data(), (size_t)Np * 4);
-        if (Npf) std::memcpy(const_cast<int32_t*>(hg.free_pose), free_pose.data(), (size_t)Npf * 4);
-        if (Nl) std::memcpy(const_cast<uint8_t*>(hg.pt_fixed), gr->point_fixed, Nl);
-        if (No) {
-            std::memcpy(const_cast<int32_t*>(hg.obs_pose), gr->obs_pose, (size_t)No * 4);
-            std::memcpy(const_cast<int32_t*>(hg.obs_pt), gr->obs_point, (size_t)No * 4);
-            { int32_t* pp = const_cast<int32_t*>(hg.obs_ppos);
-              for (int k = 0; k < No; ++k) pp[k] = -1;
-              for (int t = 0; t < cnt[Npf]; ++t) pp[pose_obs[t]] = t; }
-            std::memcpy(const_cast<double*>(hg.obs_uvr), gr->obs_uvr, (size_t)No * 24);
-            std::memcpy(const_cast<uint8_t*>(hg.obs_ok), obs_ok.data(), No);
-        }
-        std::memcpy(const_cast<int32_t*>(hg.lm_ptr), lm_ptr.data(), (size_t)(Nl + 1) * 4);
         if (n_chunks) std::memcpy(const_cast<int32_t*>(hg.chunk_pose), chunk_pose.data(), (size_t)n_chunks * 4);
         std::memcpy(const_cast<int32_t*>(hg.chunk_ptr), chunk_ptr.data(), (size_t)(n_chunks + 1) * 4);
-        std::memcpy(const_cast<int32_t*>(hg.pose_obs), pose_obs.data(), pose_obs.size() * 4);
         std::memcpy(const_cast<int32_t*>(hg.pose_chunk_ptr), pose_chunk_ptr.data(), (size_t)(Npf + 1) * 4);
-        if (Ne) {
-            std::memcpy(const_cast<int32_t*>(hg.odo_i), gr->odo_from, (size_t)Ne * 4);
-            std::memcpy(const_cast<int32_t*>(hg.odo_j), gr->odo_to, (size_t)Ne * 4);
-            std::memcpy(const_cast<double*>(hg.odo_tq), gr->odo_tq, (size_t)Ne * 56);
-        }
         std::memcpy(const_cast<int32_t*>(hg.pose_odo_ptr), pose_odo_ptr.data(), (size_t)(Npf + 1) * 4);
         if (!pose_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.pose_odo), pose_odo.data(), pose_odo.size() * 4);
         if (n_blk) { std::memcpy(const_cast<int32_t*>(hg.blk_i), blk_i.data(), (size_t)n_blk * 4); std::memcpy(const_cast<int32_t*>(hg.blk_j), blk_j.data(), (size_t)n_blk * 4); }
@@ -591,19 +734,16 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
         if (pcg1) std::memcpy(const_cast<int32_t*>(hg.pcg1_code), pcg1_code.data(), pcg1_code.size() * 4);
         if (band_B >= 0) std::memcpy(const_cast<int32_t*>(hg.band_code), band_code.data(), band_code.size() * 4);
-        if (Nz) {
-            std::memcpy(const_cast<double*>(hg.laser_xyz), gr->laser_xyz, (size_t)Nz * 24);
-            std::memcpy(const_cast<float*>(hg.grid.cost), gr->grid->correspondence_cost, grid_cells * 4);
-        }
     }
     lap("stage fill");
     // device pointers: same offsets
+    { Arena dp{ w.d_prim, w.d_prim_cap, 0 }; layout_prim(dp, dg, pz); }
     Arena ds{ w.d_base, w.d_cap, 0 };
-    layout(ds, dg, true);
+    layout(ds, dg);
     Arena dd{ w.d_base, w.d_cap, static_bytes };
     layout_dyn(dd, dg);
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
-    dg.n_pose_obs = cnt[Npf];
+    dg.n_pose_obs = n_pose_obs;
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
@@ -636,18 +776,19 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr) {
     if (ceres) { w.fused = false; w.spec = false; }
     // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
     { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
-    w.n_pairs = npairs; w.device_bytes = total_bytes;
+    w.n_pairs = npairs; w.device_bytes = total_bytes + pbytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
-    HIP_TRY(h, hipMemcpyAsync(w.d_base, w.h_base, static_bytes, hipMemcpyHostToDevice, w.stream));
+    if (static_bytes) HIP_TRY(h, hipMemcpyAsync(w.d_base, w.h_base, static_bytes, hipMemcpyHostToDevice, w.stream));
     HIP_TRY(h, hipMemsetAsync(w.d_base + static_bytes, 0, total_bytes - static_bytes, w.stream));
     if (configure_kernels(w.g) != 0) { h->err = "hipFuncSetAttribute failed"; return VISFS_BA_ERR_DEVICE; }
+    launch_build_index(w.g, d_hist, w.stream);             // lm_ptr, obs_ok, pose_obs / obs_ppos: never exist on the host
     launch_build_pairs(w.g, w.stream);                     // the co-observation pair lists never exist on the host
     launch_reset(w.g, ceres ? prm.iterations : prm.iterations / 2, prm.trust_region == 1, 1, w.stream);
     HIP_TRY(h, hipGetLastError());
     lap("enqueue");
-    // no synchronisation here: the launches that follow queue up behind the copy; the pinned staging arena is only reused by the
-    // NEXT upload, which drains the stream first (see the top of this function)
+    // no synchronisation here: the launches that follow queue up behind the copies; the pinned staging arenas are only reused by the
+    // NEXT upload, which drains the stream first
     if (timing) { HIP_TRY(h, hipStreamSynchronize(w.stream)); lap("h2d+sync"); }
     w.upload_in_flight = true;
     w.loaded = true;
@@ -931,13 +1072,136 @@ int find_id(const uint64_t* ids, int n, uint64_t id) {
     return -1;
 }
 
-struct PackedWindow {
-    std::vector<double> pose_tq, obs_uvr, odo_tq;
-    std::vector<uint8_t> pose_fixed, point_used;
-    std::vector<int32_t> obs_point, obs_pose, obs_ref, odo_from, odo_to;
-    visfs_ba_graph g{};
-    int32_t mono = 0;
+// Graph build of localOptimize (Optimizer.cpp:100-223) into caller-chosen arrays; `pose` rows are pose_stride doubles apart (7 for the
+// public visfs_ba_pack_window, POSE_STRIDE when the window layer packs straight into the device layout).  With a pool the
+// references — the only O(N_obs) part — are shared out at feature boundaries (the loop streams 28 B in and 36 B out per reference and
+// is bound by memory bandwidth: measured 208 -> 145-170 us at C2 with four threads, no gain at C4 — profiles/r03_host_threads.log); every thread writes its observations where they
+// would land if no reference were skipped, and the (rare) gaps are closed afterwards, so the result is the serial one byte for byte.
+struct PackOut {
+    double* pose = nullptr; int pose_stride = 7; uint8_t* pose_fixed = nullptr; uint8_t* point_used = nullptr;
+    int32_t* obs_point = nullptr; int32_t* obs_pose = nullptr; double* obs_uvr = nullptr; int32_t* obs_ref = nullptr;
+    int32_t* odo_from = nullptr; int32_t* odo_to = nullptr; double* odo_tq = nullptr;
 };
+int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph* g, int32_t* n_mono_skipped, WorkerPool* pool) {
+    std::memset(g, 0, sizeof(*g));
+    const auto te0 = std::chrono::steady_clock::now();
+    // poses: Twc = Twr * Trc ; Tcw = Twc^-1 as CameraPose(R,t) ; fixed iff id == rootId   (Optimizer.cpp:100-114)
+    for (int i = 0; i < w->n_poses; ++i) {
+        double Twc[12], Tcw[12];
+        iso_mul(w->pose_Twr + 12 * i, w->Trc, Twc);
+        iso_inv(Twc, Tcw);
+        iso_to_tq(Tcw, o.pose + (size_t)o.pose_stride * i);
+        for (int q = 7; q < o.pose_stride; ++q) o.pose[(size_t)o.pose_stride * i + q] = 0.0;
+        o.pose_fixed[i] = (w->pose_ids[i] == w->root_id);
+    }
+    // links: T_c1c2 = Trc^-1 * T_r1r2 * Trc as SE3Quat   (Optimizer.cpp:123-150)
+    int ne = 0;
+    double Tcr[12];
+    iso_inv(w->Trc, Tcr);
+    for (int k = 0; k < w->n_links; ++k) {
+        const uint64_t from = w->link_from[k], to = w->link_to[k];
+        if (from == 0 || to == 0) continue;
+        const int a = find_id(w->pose_ids, w->n_poses, from), b = find_id(w->pose_ids, w->n_poses, to);
+        if (a < 0 || b < 0 || from == to) continue;
+        double T1[12], T2[12];
+        iso_mul(Tcr, w->link_T + 12 * k, T1);
+        iso_mul(T1, w->Trc, T2);
+        iso_to_tq(T2, o.odo_tq + 7 * ne);
+        o.odo_from[ne] = a; o.odo_to[ne] = b;
+        ++ne;
+    }
+    // landmarks + stereo edges   (Optimizer.cpp:153-223)
+    std::memset(o.point_used, 0, (size_t)w->n_points);
+    const int Nr = w->n_refs;
+    double baseLine = 0.0;
+    if (w->n_cameras > 1) baseLine = (double)w->baseline;                       // :181-183
+    const int T = (pool && Nr >= 16384) ? 4 * pool->size() : 1;       // several tasks per thread: a worker that wakes late still finds work
+    std::vector<int> cut(T + 1, Nr);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        int k = (int)((int64_t)Nr * t / T);
+        k = std::max(k, cut[t - 1]);
+        while (k > 0 && k < Nr && w->ref_feature[k] == w->ref_feature[k - 1]) ++k;   // a feature's references (and its point_used flag) stay with one thread
+        cut[t] = k;
+    }
+    struct Part { int no = 0, mono = 0, first_p = -1, first_c = -1, last_p = -1, last_c = -1; bool bad = false; };
+    std::vector<Part> part(T);
+    static const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    if (timing) std::fprintf(stderr, "   pack: before the reference loop %.1f us\n", std::chrono::duration<double, std::micro>(tr0 - te0).count());
+    std::atomic<int> by_caller{ 0 };
+    auto body = [&](int t, int slot) {
+        if (timing && slot == 0) by_caller.fetch_add(1, std::memory_order_relaxed);
+        Part& P = part[t];
+        int no = cut[t], mono = 0, last_p = -1, last_c = -1;
+        // references arrive in nested-map order, so the id looked up is almost always at (or right after) the previous hit
+        int hint_p = 0, hint_c = 0;
+        auto find_hinted = [](const uint64_t* ids, int n, uint64_t id, int& hint) {
+            if (hint < n && ids[hint] == id) return hint;
+            if (hint + 1 < n && ids[hint + 1] == id) return ++hint;
+            const int f = find_id(ids, n, id);
+            if (f >= 0) hint = f;
+            return f;
+        };
+        for (int k = cut[t]; k < cut[t + 1]; ++k) {
+            const int p = find_hinted(w->point_ids, w->n_points, w->ref_feature[k], hint_p);
+            if (p < 0) continue;                                                    // :158
+            o.point_used[p] = 1;
+            const int c = find_hinted(w->pose_ids, w->n_poses, w->ref_pose[k], hint_c);
+            if (c < 0 || w->ref_pose[k] == 0) continue;                             // :172
+            const double depth = (double)w->ref_depth[k];                           // :174
+            if (std::isfinite(depth) && depth > 0.0 && baseLine > 0.0) {
+                if (p < last_p || (p == last_p && c <= last_c)) { P.bad = true; return; }   // nested std::map order
+                if (P.first_p < 0) { P.first_p = p; P.first_c = c; }
+                last_p = p; last_c = c;
+                const float disparity = static_cast<float>(baseLine * w->fx / depth);               // :187
+                o.obs_uvr[3 * (size_t)no + 0] = (double)w->ref_u[k];
+                o.obs_uvr[3 * (size_t)no + 1] = (double)w->ref_v[k];
+                o.obs_uvr[3 * (size_t)no + 2] = (double)(w->ref_u[k] - disparity);                  // float - float, :188
+                o.obs_point[no] = p; o.obs_pose[no] = c;
+                if (o.obs_ref) o.obs_ref[no] = k;
+                ++no;
+            } else {
+                ++mono;   // the reference dereferences an uninitialised edge pointer here (:179, :197-210); we skip the observation
+            }
+        }
+        P.no = no - cut[t]; P.mono = mono; P.last_p = last_p; P.last_c = last_c;
+    };
+    if (T > 1) pool->run(T, body); else body(0, 0);
+    if (timing) std::fprintf(stderr, "   pack: poses + links + cuts, then %d tasks (%d by the caller): %.1f us since entry\n", T, by_caller.load(),
+                             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
+    int no = 0, mono = 0, last_p = -1, last_c = -1;
+    for (int t = 0; t < T; ++t) {
+        const Part& P = part[t];
+        if (P.bad) return VISFS_BA_ERR_BAD_ARGUMENT;
+        if (P.no > 0) {
+            if (P.first_p < last_p || (P.first_p == last_p && P.first_c <= last_c)) return VISFS_BA_ERR_BAD_ARGUMENT;
+            last_p = P.last_p; last_c = P.last_c;
+            if (no != cut[t]) {                                                     // close the gap skipped references left
+                std::memmove(o.obs_point + no, o.obs_point + cut[t], (size_t)P.no * 4);
+                std::memmove(o.obs_pose + no, o.obs_pose + cut[t], (size_t)P.no * 4);
+                std::memmove(o.obs_uvr + 3 * (size_t)no, o.obs_uvr + 3 * (size_t)cut[t], (size_t)P.no * 24);
+                if (o.obs_ref) std::memmove(o.obs_ref + no, o.obs_ref + cut[t], (size_t)P.no * 4);
+            }
+        }
+        no += P.no; mono += P.mono;
+    }
+    if (n_mono_skipped) *n_mono_skipped = mono;
+    g->n_poses = w->n_poses; g->n_points = w->n_points; g->n_obs = no; g->n_odo = ne;
+    g->pose_tq = o.pose; g->pose_fixed = o.pose_fixed;
+    g->point_xyz = w->point_xyz; g->point_fixed = w->point_fixed;
+    g->obs_point = o.obs_point; g->obs_pose = o.obs_pose; g->obs_uvr = o.obs_uvr;
+    g->odo_from = o.odo_from; g->odo_to = o.odo_to; g->odo_tq = o.odo_tq;
+    g->fx = w->fx; g->fy = w->fy; g->cx = w->cx; g->cy = w->cy;
+    g->bf = ((w->n_cameras > 1) ? (double)w->baseline : 0.0) * w->fx;          // :195
+    // range points (Optimizer.cpp:225-258): `!_pointClouds.empty() && _submap != nullptr`; every point hangs off the newest pose
+    if (w->n_laser_points > 0 && w->grid != nullptr && w->laser_xyz != nullptr) {
+        g->n_laser = w->n_laser_points; g->laser_pose = w->n_poses - 1;
+        g->laser_xyz = w->laser_xyz; g->grid = w->grid;
+    }
+    std::memcpy(g->Tcr, Tcr, 96);                                             // transformRobotToImage_ (TypeOccupiedSpace2D.h:81-82)
+    return VISFS_BA_OK;
+}
 
 // Optimizer/Framework (Parameters.h:184): 0 = the g2o branch, 1 = the Ceres branch with its LEVENBERG_MARQUARDT strategy; the DOGLEG
 // strategy (Optimizer/TrustRegion=1 under Framework=1, Optimizer.cpp:515-519) is not implemented.
@@ -949,9 +1213,10 @@ static const char* framework_refusal(const visfs_ba_params& prm) {
 }
 
 // localOptimize in three steps so that a batch can run the middle one for many windows at once.
-// prepare_window: guards of Optimizer.cpp:74 / :360-364, graph build (:100-223), upload.  Returns 1 when the window is resident and
-// has to be optimised, 0 when `r` is already final (pass-through or refused input).
-int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, PackedWindow& pk) {
+// prepare_window: guards of Optimizer.cpp:74 / :360-364, graph build (:100-223) straight into the pinned staging arena of the device
+// layout, upload.  Returns 1 when the window is resident and has to be optimised, 0 when `r` is already final (pass-through or refused
+// input).  pool: host threads for the O(N_obs) passes (nullptr: the calling thread alone).
+int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, PackedWindow& pk, WorkerPool* pool = nullptr) {
     const visfs_ba_params& prm = h->prm;
     r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
     r->iterations_run[0] = r->iterations_run[1] = 0;
@@ -973,56 +1238,133 @@ int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win,
     for (int i = 1; i < win->n_poses; ++i) if (win->pose_ids[i] <= win->pose_ids[i - 1]) { r->status = bad(h, "pose ids must ascend (std::map order)"); return 0; }
     for (int i = 1; i < win->n_points; ++i) if (win->point_ids[i] <= win->point_ids[i - 1]) { r->status = bad(h, "point ids must ascend (std::map order)"); return 0; }
     const int Np = win->n_poses, Nl = win->n_points, Nr = win->n_refs, Nk = win->n_links;
-    pk.pose_tq.resize((size_t)Np * 7); pk.pose_fixed.resize(Np); pk.point_used.resize(std::max(Nl, 1));
-    pk.obs_point.resize(std::max(Nr, 1)); pk.obs_pose.resize(std::max(Nr, 1)); pk.obs_ref.resize(std::max(Nr, 1)); pk.obs_uvr.resize((size_t)std::max(Nr, 1) * 3);
-    pk.odo_from.resize(std::max(Nk, 1)); pk.odo_to.resize(std::max(Nk, 1)); pk.odo_tq.resize((size_t)std::max(Nk, 1) * 7);
-    int rc = visfs_ba_pack_window(&prm, win, pk.pose_tq.data(), pk.pose_fixed.data(), pk.point_used.data(), pk.obs_point.data(), pk.obs_pose.data(),
-                                  pk.obs_uvr.data(), pk.obs_ref.data(), pk.odo_from.data(), pk.odo_to.data(), pk.odo_tq.data(), &pk.g, &pk.mono);
+    int rc = ws_init(h, w);
+    if (rc != VISFS_BA_OK) { r->status = rc; return 0; }
+    // the primary staging arena is the source of the previous upload's host-to-device copy: that copy must have left it
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(w.stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; r->status = VISFS_BA_ERR_DEVICE; return 0; }
+    UploadOpts opt;
+    opt.in_staging = true; opt.trusted = true; opt.pool = pool;
+    opt.cap.Np = Np; opt.cap.Nl = Nl; opt.cap.cap_obs = Nr; opt.cap.cap_odo = Nk;
+    if (win->n_laser_points > 0 && win->grid != nullptr && win->laser_xyz != nullptr) {
+        const visfs_ba_grid& G = *win->grid;
+        opt.cap.Nz = win->n_laser_points;
+        if (G.num_x_cells > 0 && G.num_y_cells > 0 && (int64_t)G.num_x_cells * G.num_y_cells <= (int64_t)1 << 28) opt.cap.grid_cells = (size_t)G.num_x_cells * G.num_y_cells;
+    }
+    rc = ensure_prim(h, w, prim_bytes(opt.cap));
+    if (rc != VISFS_BA_OK) { r->status = rc; return 0; }
+    DeviceGraph hg{};
+    { Arena hp{ w.h_prim, w.h_prim_cap, 0 }; layout_prim(hp, hg, opt.cap); }
+    pk.pose_fixed.resize(Np); pk.point_used.resize(std::max(Nl, 1)); pk.obs_ref.resize(std::max(Nr, 1));
+    PackOut o;
+    o.pose = const_cast<double*>(hg.pose0); o.pose_stride = POSE_STRIDE; o.pose_fixed = pk.pose_fixed.data(); o.point_used = pk.point_used.data();
+    o.obs_point = const_cast<int32_t*>(hg.obs_pt); o.obs_pose = const_cast<int32_t*>(hg.obs_pose); o.obs_uvr = const_cast<double*>(hg.obs_uvr); o.obs_ref = pk.obs_ref.data();
+    o.odo_from = const_cast<int32_t*>(hg.odo_i); o.odo_to = const_cast<int32_t*>(hg.odo_j); o.odo_tq = const_cast<double*>(hg.odo_tq);
+    const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    rc = pack_window_impl(win, o, &pk.g, &pk.mono, pool);
+    if (timing) std::fprintf(stderr, "  pack (%d thread%s)     %8.1f us\n", pool ? pool->size() : 1, pool ? "s" : "", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count());
     if (rc != VISFS_BA_OK) { r->status = bad(h, "window references must be sorted by (feature, pose)"); return 0; }
+    if (Nl) { std::memcpy(const_cast<double*>(hg.pt0), win->point_xyz, (size_t)Nl * 24); std::memcpy(const_cast<uint8_t*>(hg.pt_fixed), win->point_fixed, Nl); }
     r->warn_mono_skipped = pk.mono;
-    rc = ws_upload(h, w, &pk.g);
+    rc = ws_upload(h, w, &pk.g, opt);
     if (rc != VISFS_BA_OK) { r->status = rc; return 0; }
     return 1;
 }
 
 // finish_window: write-back (Optimizer.cpp:284-302 outliers, :320-358 poses and landmarks) from the optimised resident window.
-int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, const PackedWindow& pk, int rc, const visfs_ba_stats& st) {
+int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, const PackedWindow& pk, int rc, const visfs_ba_stats& st, WorkerPool* pool = nullptr) {
     if (rc == VISFS_BA_ERR_DEVICE || rc == VISFS_BA_ERR_NOT_LOADED) return r->status = rc;
     const int Np = win->n_poses, Nl = win->n_points;
     r->status = rc;
     r->iterations_run[0] = st.iterations_run[0]; r->iterations_run[1] = st.iterations_run[1];
     r->chi2_initial = st.chi2_initial; r->chi2_phase1 = st.chi2_phase1; r->chi2_final = st.chi2_final;
     if (rc != VISFS_BA_OK && rc != VISFS_BA_ERR_HUGE_CHI2_2) return rc;
-    std::vector<double> pose((size_t)Np * 7), pts((size_t)std::max(Nl, 1) * 3);
-    std::vector<uint8_t> outl(std::max(pk.g.n_obs, 1));
-    int rc2 = ws_download(h, w, pose.data(), pts.data(), outl.data(), nullptr, /*state_fresh=*/true);
-    if (rc2 != VISFS_BA_OK) return r->status = rc2;
-    // outliers are appended at Optimizer.cpp:296, before the phase-2 abort check
+    // the outputs came back with the state (ws_read_state): read them where they are; otherwise fetch them now
+    std::vector<double> pose_v, pts_v;
+    std::vector<uint8_t> outl_v;
+    const double* pose = nullptr; const double* pts = nullptr; const uint8_t* outl = nullptr;
+    int pose_stride = 7;
+    if (w.outputs_staged) {
+        const OutputStage os = output_stage_of(w.g);
+        const int sel = w.h_state->sel;
+        pose = reinterpret_cast<const double*>(w.h_base + os.pose[sel]); pose_stride = POSE_STRIDE;
+        pts = reinterpret_cast<const double*>(w.h_base + os.pt[sel]);
+        outl = reinterpret_cast<const uint8_t*>(w.h_base + os.out);
+        w.outputs_staged = false;
+    } else {
+        pose_v.resize((size_t)Np * 7); pts_v.resize((size_t)std::max(Nl, 1) * 3); outl_v.resize(std::max(pk.g.n_obs, 1));
+        int rc2 = ws_download(h, w, pose_v.data(), pts_v.data(), outl_v.data(), nullptr, /*state_fresh=*/true);
+        if (rc2 != VISFS_BA_OK) return r->status = rc2;
+        pose = pose_v.data(); pts = pts_v.data(); outl = outl_v.data();
+    }
+    // outliers are appended at Optimizer.cpp:296, before the phase-2 abort check.  Large windows: counted and written by ranges of
+    // observations on the pool (a range's outliers land where the serial loop would put them).
     int n = 0;
-    for (int k = 0; k < pk.g.n_obs; ++k)
-        if (outl[k] && n < r->outlier_capacity) { r->outlier_feature[n] = win->ref_feature[pk.obs_ref[k]]; r->outlier_pose[n] = win->ref_pose[pk.obs_ref[k]]; ++n; }
+    {
+        const int No = pk.g.n_obs;
+        const int T = (pool && No >= 65536) ? 4 * pool->size() : 1;
+        std::vector<int> cnt(T + 1, 0);
+        auto count = [&](int t, int) {
+            const int lo = (int)((int64_t)No * t / T), hi = (int)((int64_t)No * (t + 1) / T);
+            int c = 0, k = lo;
+            while (k < hi) {
+                if (k + 8 <= hi) { uint64_t eight; std::memcpy(&eight, outl + k, 8); if (eight == 0) { k += 8; continue; } }   // outliers are a few per cent as a rule
+                c += outl[k] != 0; ++k;
+            }
+            cnt[t + 1] = c;
+        };
+        if (T > 1) pool->run(T, count); else count(0, 0);
+        for (int t = 0; t < T; ++t) cnt[t + 1] += cnt[t];
+        auto write = [&](int t, int) {
+            const int lo = (int)((int64_t)No * t / T), hi = (int)((int64_t)No * (t + 1) / T);
+            int at = cnt[t], k = lo;
+            if (cnt[t + 1] == at) return;
+            while (k < hi) {
+                if (k + 8 <= hi) { uint64_t eight; std::memcpy(&eight, outl + k, 8); if (eight == 0) { k += 8; continue; } }
+                if (outl[k]) { if (at < r->outlier_capacity) { r->outlier_feature[at] = win->ref_feature[pk.obs_ref[k]]; r->outlier_pose[at] = win->ref_pose[pk.obs_ref[k]]; } ++at; }
+                ++k;
+            }
+        };
+        if (T > 1) pool->run(T, write); else write(0, 0);
+        n = std::min(cnt[T], (int)r->outlier_capacity);
+    }
     r->n_outliers = n;
     if (rc != VISFS_BA_OK) return rc;
-    for (int i = 0; i < Np; ++i) { r->pose_ids_out[i] = win->pose_ids[i]; visfs_ba_unpack_pose(pose.data() + 7 * i, win->Trc, r->pose_Twr_out + 12 * i); }   // :320-340
+    for (int i = 0; i < Np; ++i) { r->pose_ids_out[i] = win->pose_ids[i]; visfs_ba_unpack_pose(pose + (size_t)pose_stride * i, win->Trc, r->pose_Twr_out + 12 * i); }   // :320-340
     r->n_poses_out = Np;
-    for (int l = 0; l < Nl; ++l) {                                  // :343-358
-        double* p = win->point_xyz + 3 * l;
-        if (pk.point_used[l]) {
-            const double dx = p[0] - pts[3 * l], dy = p[1] - pts[3 * l + 1], dz = p[2] - pts[3 * l + 2];
-            if (std::sqrt(dx * dx + dy * dy + dz * dz) < 5.0) { p[0] = pts[3 * l]; p[1] = pts[3 * l + 1]; p[2] = pts[3 * l + 2]; }
-        } else { p[0] = p[1] = p[2] = std::nan(""); }
+    {
+        const int T = (pool && Nl >= 16384) ? 2 * pool->size() : 1;
+        auto body = [&](int t, int) {
+            const int lo = (int)((int64_t)Nl * t / T), hi = (int)((int64_t)Nl * (t + 1) / T);
+            for (int l = lo; l < hi; ++l) {                             // :343-358
+                double* p = win->point_xyz + 3 * l;
+                if (pk.point_used[l]) {
+                    const double dx = p[0] - pts[3 * l], dy = p[1] - pts[3 * l + 1], dz = p[2] - pts[3 * l + 2];
+                    if (std::sqrt(dx * dx + dy * dy + dz * dz) < 5.0) { p[0] = pts[3 * l]; p[1] = pts[3 * l + 1]; p[2] = pts[3 * l + 2]; }
+                } else { p[0] = p[1] = p[2] = std::nan(""); }
+            }
+        };
+        if (T > 1) pool->run(T, body); else body(0, 0);
     }
     return VISFS_BA_OK;
 }
 
 int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r) {
-    PackedWindow pk;
-    if (!prepare_window(h, w, win, r, pk)) return r->status;
+    static const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (timing) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, " window %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
+    PackedWindow& pk = w.pk;
+    if (WorkerPool* pool = host_pool(h)) { if (win->n_refs >= 16384) pool->prewake(); }
+    if (!prepare_window(h, w, win, r, pk, host_pool(h))) return r->status;
+    lap("prepare");
     visfs_ba_stats st;
     w.want_outputs = true;                          // the outputs travel with the solve's state read
     const int rc = ws_optimize(h, w, &st);
     w.want_outputs = false;
-    return finish_window(h, w, win, r, pk, rc, st);
+    lap("optimize");
+    const int rcf = finish_window(h, w, win, r, pk, rc, st, host_pool(h));
+    lap("finish");
+    return rcf;
 }
 
 
@@ -1238,81 +1580,11 @@ int visfs_ba_pack_window(const visfs_ba_params* params, const visfs_ba_window* w
                          int32_t* odo_from, int32_t* odo_to, double* odo_tq,
                          visfs_ba_graph* g, int32_t* n_mono_skipped) {
     (void)params;
-    std::memset(g, 0, sizeof(*g));
-    // poses: Twc = Twr * Trc ; Tcw = Twc^-1 as CameraPose(R,t) ; fixed iff id == rootId   (Optimizer.cpp:100-114)
-    for (int i = 0; i < w->n_poses; ++i) {
-        double Twc[12], Tcw[12];
-        iso_mul(w->pose_Twr + 12 * i, w->Trc, Twc);
-        iso_inv(Twc, Tcw);
-        iso_to_tq(Tcw, pose_tq + 7 * i);
-        pose_fixed[i] = (w->pose_ids[i] == w->root_id);
-    }
-    // links: T_c1c2 = Trc^-1 * T_r1r2 * Trc as SE3Quat   (Optimizer.cpp:123-150)
-    int ne = 0;
-    double Tcr[12];
-    iso_inv(w->Trc, Tcr);
-    for (int k = 0; k < w->n_links; ++k) {
-        const uint64_t from = w->link_from[k], to = w->link_to[k];
-        if (from == 0 || to == 0) continue;
-        const int a = find_id(w->pose_ids, w->n_poses, from), b = find_id(w->pose_ids, w->n_poses, to);
-        if (a < 0 || b < 0 || from == to) continue;
-        double T1[12], T2[12];
-        iso_mul(Tcr, w->link_T + 12 * k, T1);
-        iso_mul(T1, w->Trc, T2);
-        iso_to_tq(T2, odo_tq + 7 * ne);
-        odo_from[ne] = a; odo_to[ne] = b;
-        ++ne;
-    }
-    // landmarks + stereo edges   (Optimizer.cpp:153-223)
-    std::memset(point_used, 0, (size_t)w->n_points);
-    int no = 0, mono = 0, last_p = -1, last_c = -1;
-    // references arrive in nested-map order, so the id looked up is almost always at (or right after) the previous hit
-    int hint_p = 0, hint_c = 0;
-    auto find_hinted = [](const uint64_t* ids, int n, uint64_t id, int& hint) {
-        if (hint < n && ids[hint] == id) return hint;
-        if (hint + 1 < n && ids[hint + 1] == id) return ++hint;
-        const int f = find_id(ids, n, id);
-        if (f >= 0) hint = f;
-        return f;
-    };
-    for (int k = 0; k < w->n_refs; ++k) {
-        const int p = find_hinted(w->point_ids, w->n_points, w->ref_feature[k], hint_p);
-        if (p < 0) continue;                                                    // :158
-        point_used[p] = 1;
-        const int c = find_hinted(w->pose_ids, w->n_poses, w->ref_pose[k], hint_c);
-        if (c < 0 || w->ref_pose[k] == 0) continue;                             // :172
-        const double depth = (double)w->ref_depth[k];                           // :174
-        double baseLine = 0.0;
-        if (w->n_cameras > 1) baseLine = (double)w->baseline;                   // :181-183
-        if (std::isfinite(depth) && depth > 0.0 && baseLine > 0.0) {
-            if (p < last_p || (p == last_p && c <= last_c)) return VISFS_BA_ERR_BAD_ARGUMENT;   // nested std::map order
-            last_p = p; last_c = c;
-            const float disparity = static_cast<float>(baseLine * w->fx / depth);               // :187
-            obs_uvr[3 * no + 0] = (double)w->ref_u[k];
-            obs_uvr[3 * no + 1] = (double)w->ref_v[k];
-            obs_uvr[3 * no + 2] = (double)(w->ref_u[k] - disparity);                            // float - float, :188
-            obs_point[no] = p; obs_pose[no] = c;
-            if (obs_ref) obs_ref[no] = k;
-            ++no;
-        } else {
-            ++mono;   // the reference dereferences an uninitialised edge pointer here (:179, :197-210); we skip the observation
-        }
-    }
-    if (n_mono_skipped) *n_mono_skipped = mono;
-    g->n_poses = w->n_poses; g->n_points = w->n_points; g->n_obs = no; g->n_odo = ne;
-    g->pose_tq = pose_tq; g->pose_fixed = pose_fixed;
-    g->point_xyz = w->point_xyz; g->point_fixed = w->point_fixed;
-    g->obs_point = obs_point; g->obs_pose = obs_pose; g->obs_uvr = obs_uvr;
-    g->odo_from = odo_from; g->odo_to = odo_to; g->odo_tq = odo_tq;
-    g->fx = w->fx; g->fy = w->fy; g->cx = w->cx; g->cy = w->cy;
-    g->bf = ((w->n_cameras > 1) ? (double)w->baseline : 0.0) * w->fx;          // :195
-    // range points (Optimizer.cpp:225-258): `!_pointClouds.empty() && _submap != nullptr`; every point hangs off the newest pose
-    if (w->n_laser_points > 0 && w->grid != nullptr && w->laser_xyz != nullptr) {
-        g->n_laser = w->n_laser_points; g->laser_pose = w->n_poses - 1;
-        g->laser_xyz = w->laser_xyz; g->grid = w->grid;
-    }
-    std::memcpy(g->Tcr, Tcr, 96);                                             // transformRobotToImage_ (TypeOccupiedSpace2D.h:81-82)
-    return VISFS_BA_OK;
+    PackOut o;
+    o.pose = pose_tq; o.pose_stride = 7; o.pose_fixed = pose_fixed; o.point_used = point_used;
+    o.obs_point = obs_point; o.obs_pose = obs_pose; o.obs_uvr = obs_uvr; o.obs_ref = obs_ref;
+    o.odo_from = odo_from; o.odo_to = odo_to; o.odo_tq = odo_tq;
+    return pack_window_impl(w, o, g, n_mono_skipped, nullptr);
 }
 
 void visfs_ba_unpack_pose(const double* tq, const double* Trc, double* Twr_out) {
@@ -1367,7 +1639,6 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         for (int i = 0; i < n; ++i) h->batch[i]->batch_hint = n;
         const int lanes = std::max(1, std::min<int>(n, 8));
-        std::vector<PackedWindow> pk(n);
         std::vector<int> need(n, 0), rcs(n, VISFS_BA_OK);
         std::vector<std::string> errs(lanes);
         auto parallel = [&](auto&& fn) {
@@ -1389,7 +1660,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
                 });
             }
         };
-        parallel([&](visfs_ba_handle& local, int i) { need[i] = prepare_window(&local, *h->batch[i], w[i], r[i], pk[i]); if (!need[i]) rcs[i] = r[i]->status; });
+        parallel([&](visfs_ba_handle& local, int i) { need[i] = prepare_window(&local, *h->batch[i], w[i], r[i], h->batch[i]->pk); if (!need[i]) rcs[i] = r[i]->status; });
         // groups: lanes per landmark, PCG variant class, small-solve / fused flags must agree inside one batched launch
         const char* env = std::getenv("VISFS_BA_BATCH");
         const bool batching = !(env && env[0] == '0');
@@ -1420,7 +1691,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             }
         }
         for (int i : singles) rcs[i] = ws_optimize(h, *h->batch[i], &stats[i]);
-        parallel([&](visfs_ba_handle& local, int i) { if (need[i]) rcs[i] = finish_window(&local, *h->batch[i], w[i], r[i], pk[i], rcs[i], stats[i]); });
+        parallel([&](visfs_ba_handle& local, int i) { if (need[i]) rcs[i] = finish_window(&local, *h->batch[i], w[i], r[i], h->batch[i]->pk, rcs[i], stats[i]); });
         for (int i = 0; i < n; ++i) if (rcs[i] == VISFS_BA_ERR_DEVICE) worst = VISFS_BA_ERR_DEVICE;
         for (int t = 0; t < lanes; ++t) if (!errs[t].empty()) h->err = errs[t];
         return worst;

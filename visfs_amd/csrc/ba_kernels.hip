@@ -966,6 +966,59 @@ __global__ __launch_bounds__(1024) void k_ceres_lin_finalize(const Src src) {
 // lane per observation of pose i, a binary search in pose j's list (pose_lm: the landmark of every pose-major entry), a ballot
 // prefix for the slot — no atomics, so the order
 // (and with it every later summation order) is fixed.  The host has sized blk_ptr from the same rule (counts only).
+// ---- the O(N_obs) index arrays, built on the device from the primary arrays (obs_pt, obs_pose, pose_free, pt_fixed): the host only
+// sends what localOptimize's inputs carry and the block-level structure of S; nothing of size N_obs is computed or copied twice.
+//   lm_ptr    CSR over the landmark-major observations (observations arrive sorted by (point, pose): boundaries of obs_pt);
+//   obs_ok    !(pose fixed && point fixed);
+//   pose_obs  the pose-major permutation (free poses only, ascending observation id inside a pose), obs_ppos its inverse.
+// The permutation is a stable multi-split: blocks of IDX_T observations, thread a of a block counts / ranks the observations of free
+// pose a by scanning the block's poses in LDS (every thread reads the same word: a broadcast) — no atomics, order fixed.
+constexpr int IDX_T = 256;
+__global__ __launch_bounds__(256) void k_index_count(const DeviceGraph g, int32_t* __restrict__ hist) {
+    __shared__ int sfree[IDX_T];
+    const int k0 = blockIdx.x * IDX_T, tid = threadIdx.x, k = k0 + tid;
+    const int n = min(IDX_T, g.No - k0);
+    int32_t* lm_ptr = const_cast<int32_t*>(g.lm_ptr);
+    if (tid < n) {
+        const int c = g.obs_pose[k], l = g.obs_pt[k];
+        const int a = g.pose_free[c];
+        sfree[tid] = a;
+        const_cast<uint8_t*>(g.obs_ok)[k] = !(a < 0 && g.pt_fixed[l]);
+        if (a < 0) const_cast<int32_t*>(g.obs_ppos)[k] = -1;
+        const int lprev = k > 0 ? g.obs_pt[k - 1] : -1;
+        for (int q = lprev + 1; q <= l; ++q) lm_ptr[q] = k;                   // landmarks without observations get empty ranges
+        if (k == g.No - 1) for (int q = l + 1; q <= g.Nl; ++q) lm_ptr[q] = g.No;
+    }
+    __syncthreads();
+    for (int a = tid; a < g.Npf; a += 256) {
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) cnt += (sfree[i] == a);
+        hist[(size_t)blockIdx.x * g.Npf + a] = cnt;
+    }
+}
+// exclusive scan of the per-block counts over the blocks, per pose, offset by where the pose's range starts in pose_obs
+__global__ __launch_bounds__(256) void k_index_scan(const DeviceGraph g, int32_t* __restrict__ hist, const int nblocks) {
+    if (g.No == 0 && threadIdx.x == 0 && blockIdx.x == 0) { int32_t* lm_ptr = const_cast<int32_t*>(g.lm_ptr); for (int q = 0; q <= g.Nl; ++q) lm_ptr[q] = 0; }
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= g.Npf) return;
+    int run = g.chunk_ptr[g.pose_chunk_ptr[a]];
+    for (int b = 0; b < nblocks; ++b) { const int c = hist[(size_t)b * g.Npf + a]; hist[(size_t)b * g.Npf + a] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void k_index_scatter(const DeviceGraph g, const int32_t* __restrict__ base) {
+    __shared__ int sfree[IDX_T];
+    const int k0 = blockIdx.x * IDX_T, tid = threadIdx.x;
+    const int n = min(IDX_T, g.No - k0);
+    if (tid < n) sfree[tid] = g.pose_free[g.obs_pose[k0 + tid]];
+    __syncthreads();
+    int32_t* pose_obs = const_cast<int32_t*>(g.pose_obs);
+    int32_t* obs_ppos = const_cast<int32_t*>(g.obs_ppos);
+    for (int a = tid; a < g.Npf; a += 256) {
+        int pos = base[(size_t)blockIdx.x * g.Npf + a];
+        for (int i = 0; i < n; ++i)
+            if (sfree[i] == a) { pose_obs[pos] = k0 + i; obs_ppos[k0 + i] = pos; ++pos; }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pose_landmarks(const DeviceGraph g) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < g.n_pose_obs) g.pose_lm[t] = g.obs_pt[g.pose_obs[t]];
@@ -3628,6 +3681,13 @@ static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int
 }
 
 // ---- single window
+void launch_build_index(const DeviceGraph& g, int32_t* hist, hipStream_t s) {
+    const int nblocks = (g.No + IDX_T - 1) / IDX_T;
+    if (nblocks > 0) hipLaunchKernelGGL(k_index_count, dim3(nblocks), dim3(256), 0, s, g, hist);
+    hipLaunchKernelGGL(k_index_scan, dim3(std::max(1, (g.Npf + 255) / 256)), dim3(256), 0, s, g, hist, nblocks);
+    if (nblocks > 0) hipLaunchKernelGGL(k_index_scatter, dim3(nblocks), dim3(256), 0, s, g, hist);
+}
+int index_blocks(int No) { return (No + IDX_T - 1) / IDX_T; }
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
     if (g.n_blk <= 0) return;
     if (g.n_pose_obs > 0) hipLaunchKernelGGL(k_pose_landmarks, dim3((g.n_pose_obs + 255) / 256), dim3(256), 0, s, g);

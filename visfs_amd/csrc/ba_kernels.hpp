@@ -17,6 +17,8 @@ int configure_kernels(const DeviceGraph& g);
 int pcg_resident_capacity(const LaunchDims& d, bool many, int device);   // workgroups of the persistent PCG that fit on the device at once (0: query failed)
 void arm_launch_events(hipEvent_t start, hipEvent_t stop);             // measurement: attach an event pair to the next timed launch (this thread)
 bool launch_events_pending();                                        // ... still armed: no timed launch has consumed it
+void launch_build_index(const DeviceGraph& g, int32_t* hist, hipStream_t s);   // upload: lm_ptr, obs_ok, pose_obs / obs_ppos from the primary arrays (hist: [index_blocks(No)][Npf] scratch)
+int index_blocks(int No);
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s);        // upload: co-observation pair lists of the S blocks
 void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int restore, hipStream_t s);
 void launch_linearize(const DeviceGraph& g, hipStream_t s);          // k_linearize (+ k_odo_linearize when the window has odometry edges)
