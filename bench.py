@@ -41,6 +41,8 @@ def algorithmic_bytes(kernel, d):
         return avg(tr, lambda No: 264 * No + 168 * Nl + 112 * Np)
     if kernel == "k_pcg":            # stage C, k iterations in one launch: k * (288 B/block + 4*48 B/pose)
         return d["pcg_iters_per_launch"] * (288 * nblk + 192 * Np)
+    if kernel == "k_direct":         # direct solve of the reduced system: every stored block of S once, b_s in, x out
+        return 288 * nblk + 2 * 48 * Np
     raise KeyError(kernel)
 
 
@@ -72,6 +74,9 @@ def main():
     ap.add_argument("--handles", type=int, default=1, help="with --windows-per-gpu B > 1 in launch mode: split the B resident windows over this many handles "
                     "(each its own stream and host thread, B / handles windows sharing every launch of a handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config5", choices=("auto", "on", "off"), default="auto",
+                    help="also measure BASELINE config 5's per-GPU share in the same run (8 resident C2-size windows per GPU sharing every launch, "
+                         "results all_gather'ed and checked): 'auto' = whenever --gpus > 1, so a scaling run covers config 5 without extra flags")
     args = ap.parse_args()
 
     from visfs_amd import abi, synth, backend, dist as vdist
@@ -156,7 +161,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # untimed calibration pass: a HIP-event pair on every kernel launch → per-kernel breakdown + the dominant kernel
-    data_kernels = ("k_linearize", "k_schur_partial", "k_backsub", "k_pcg")
+    data_kernels = ("k_linearize", "k_schur_partial", "k_backsub", "k_pcg", "k_direct")
     solvers[0].profile_enable(True)
     for _ in range(3):
         step()
@@ -179,6 +184,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = vdist.reduce_max(t1 - t0, world, red_dev)
     total_iters = vdist.reduce_sum(iters, world, red_dev)
+    graph_replay = bool(solvers[0].describe().get("graph_replayed", 0)) if B == 1 else False    # how the LAST timed solve was launched
     # the dominant kernel's launch durations: the SAME steps once more, right behind the timed region, with a HIP-event pair
     # attached to every launch of that kernel on the library's own stream (max(3, steps / 8) steps)
     if dom:
@@ -189,6 +195,9 @@ def main():
     # config 5 as north_star words it: after the timed region every rank's window results travel to every rank in ONE
     # all_gather (RCCL over xGMI when the backend is nccl); rank 0 checks them against its own single-rank solves of the same windows
     gathered = gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_dev, vdist, abi, synth, backend, torch)
+    c5 = None
+    if args.config5 == "on" or (args.config5 == "auto" and world > 1):
+        c5 = config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, synth, backend, torch)
     vdist.shutdown(world)                  # last collective done
 
     if rank != 0:
@@ -207,7 +216,7 @@ def main():
         avg_us = 1e3 * p["active_ms"] / p["active_launches"]
         byts = algorithmic_bytes(kernel, d)
         achieved = byts / (avg_us * 1e-6) / 1e9
-        symbol = {1: "k_pcg1", 2: "k_pcg", 3: "k_pcg", 4: "k_pcg_cu", 5: "k_small_solve", 6: "k_chol_update + k_chol_solve + ..."}.get(d.get("solver_kernel"), kernel) \
+        symbol = {1: "k_pcg1", 2: "k_pcg", 3: "k_pcg", 4: "k_pcg_cu", 5: "k_small_solve", 6: "k_chol_update + k_chol_solve + ...", 7: "k_band_chol"}.get(d.get("solver_kernel"), kernel) \
             if kernel in ("k_pcg", "k_direct") else kernel
         return {"bound": "hbm", "kernel": kernel, "kernel_symbol": symbol, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(args.config, kernel), "bytes_per_launch": byts,
@@ -235,7 +244,11 @@ def main():
                                   + (f"; {H} handles (streams / host threads) of {(B + H - 1) // H} windows each" if batched and H > 1 else "")},
         "roofline": roofline,
         "roofline_other_kernels": roofline_kernels,
+        # the headline re-optimises ONE resident graph: from its second solve on the library replays the launch sequence as a hipGraph
+        # (C2 +2 %, PROD +9 %); a per-frame visfs_ba_solve_window never gets that — its rate is in profiles/*e2e_breakdown.log
+        "graph_replay": graph_replay,
         "result_gather": gathered,
+        "config5": c5,
         "kernel_us_per_step_calibration": {k: round(1e3 * v["total_ms"] / 3, 2) for k, v in calib.items()},
     }
     if last is not None and args.solver == 2:
@@ -263,6 +276,58 @@ def main():
         # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
         out["max_pose_err_vs_oracle"] = parity_vs_oracle(args, prm, solvers[0])
     print(json.dumps(out))
+
+
+def config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, synth, backend, torch, per_gpu=8):
+    """BASELINE config 5 (64 independent 50-KF windows, 8 per GPU): this rank keeps windows rank * 8 .. rank * 8 + 7 of the C5 set
+    resident and solves them as one batch (blockIdx.y = window); timed like the headline (barrier + synchronize on both sides, max
+    over ranks); afterwards one all_gather of every window's poses, rank 0 re-solves the first window of every rank alone and
+    compares bit for bit."""
+    import time as _t
+    prm = abi.default_params(iterations=20, solver=2)
+    gbs = []
+    for b in range(per_gpu):
+        w = synth.make_window("C5", window_index=rank * per_gpu + b)
+        gbs.append(abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))[0])
+    s = backend.Solver(prm, device=dev)
+    s.batch_upload(gbs)
+
+    def step():
+        s.batch_reset()
+        rc, stats = s.batch_optimize()
+        assert rc == abi.OK, rc
+        return sum(st.iterations_run[0] + st.iterations_run[1] for st in stats)
+    for _ in range(3):
+        step()
+    steps = max(5, args.steps // 4)
+    vdist.barrier(world, bar_dev); torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    iters = 0
+    for _ in range(steps):
+        iters += step()
+    torch.cuda.synchronize(); vdist.barrier(world, bar_dev)
+    elapsed = vdist.reduce_max(_t.perf_counter() - t0, world, red_dev)
+    total = vdist.reduce_sum(iters, world, red_dev)
+    local = torch.from_numpy(np.stack([s.batch_download(b)[0] for b in range(per_gpu)], 0))
+    rec = {"workload": f"{per_gpu} resident C2-size windows per GPU x {world} GPU(s) = {per_gpu * world} windows, Schur + PCG, Iterations=20, batched launches",
+           "value": round(total / elapsed, 2), "unit": "BA iterations/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 4), "scaling": "weak"}
+    if world > 1:
+        ids = vdist.gather_results(torch.tensor([[float(rank)]], dtype=torch.float64), world, red_dev).cpu().numpy().ravel()
+        allp = vdist.gather_results(local, world, red_dev).cpu().numpy()
+    else:
+        ids, allp = np.array([0.0]), local.numpy()
+    if rank == 0:
+        same = True
+        for r in range(world):
+            w = synth.make_window("C5", window_index=r * per_gpu)
+            gb = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))[0]
+            s1 = backend.Solver(prm, device=dev)
+            s1.batch_upload([gb]); s1.batch_reset(); s1.batch_optimize(); ref = s1.batch_download(0)[0]
+            s1.close()
+            same = same and bool(np.array_equal(ref, allp[r * per_gpu]))
+        rec.update({"ranks_seen": [int(x) for x in ids], "windows": int(allp.shape[0]), "bit_identical": same})
+    s.close()
+    return rec if rank == 0 else None
 
 
 def gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_dev, vdist, abi, synth, backend, torch):

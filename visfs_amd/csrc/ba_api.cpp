@@ -77,6 +77,8 @@ struct Workspace {
     hipGraphExec_t graph_exec = nullptr;
     int graph_units[2] = { -1, -1 };
     int solves_since_upload = 0;
+    bool graph_failed = false;                     // a capture or instantiation failed once: eager launches from then on
+    bool last_replayed = false;                    // the last solve ran as a hipGraph replay (measurement: visfs_ba_graph_info)
     bool upload_in_flight = false;                 // ws_upload no longer drains its stream: whoever uses the graph from ANOTHER stream must (batch_optimize)
     // host mirrors for fetch / unpack
     std::vector<int32_t> free_pose, blk_i, blk_j, odo_i, odo_j, pose_free;
@@ -879,10 +881,17 @@ void fill_stats(const LmState& st, visfs_ba_stats* out) {
 // block rows sum to <= 1024 (two 4-window batches of C2 size overlap: the hand-off waits of one hide behind the gathers of the
 // other).  Grids of the four-wave kernel (k_pcg: LDS, one workgroup per CU) stay exclusive: a placement of one-wave grids that
 // fills one SIMD of many CUs could otherwise keep a four-wave workgroup from ever fitting.
-struct PcgBudget { std::mutex m; std::condition_variable cv; int used = 0; static constexpr int CAP = 1024; };
+struct PcgBudget { std::mutex m; std::condition_variable cv; int used = 0; int cap = 0; };   // cap: wavefront slots of the device, 0 until first use
 PcgBudget& pcg_device_budget(int device) {
     static PcgBudget b[64];
     return b[(unsigned)device % 64u];
+}
+// One-wave slots of the device, counted conservatively (one per SIMD): compute units x 4.  A partitioned device (CPX / NPS modes: e.g.
+// 32 CUs) gets the budget of what it really has; if the query fails the budget is 1, i.e. every persistent PCG solve is exclusive.
+static int pcg_device_slots(int device) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 1;
+    return cus * 4;
 }
 class PcgLease {
 public:
@@ -890,11 +899,12 @@ public:
     PcgLease(const PcgLease&) = delete;
     PcgLease& operator=(const PcgLease&) = delete;
     ~PcgLease() { release(); }
-    void acquire(int device, int cost) {                       // cost <= 0 or > CAP: exclusive
+    void acquire(int device, int cost) {                       // cost <= 0 or > capacity: exclusive
         b_ = &pcg_device_budget(device);
-        cost_ = (cost <= 0 || cost > PcgBudget::CAP) ? PcgBudget::CAP : cost;
         std::unique_lock<std::mutex> lk(b_->m);
-        b_->cv.wait(lk, [&]() { return b_->used + cost_ <= PcgBudget::CAP; });
+        if (b_->cap == 0) b_->cap = pcg_device_slots(device);
+        cost_ = (cost <= 0 || cost > b_->cap) ? b_->cap : cost;
+        b_->cv.wait(lk, [&]() { return b_->used + cost_ <= b_->cap; });
         b_->used += cost_;
     }
     void release() {
@@ -907,6 +917,13 @@ private:
     PcgBudget* b_ = nullptr;
     int cost_ = 0;
 };
+// the budget of a device (for decisions that depend on whether two leases fit side by side)
+static int pcg_budget_capacity(int device) {
+    PcgBudget& b = pcg_device_budget(device);
+    std::lock_guard<std::mutex> lk(b.m);
+    if (b.cap == 0) b.cap = pcg_device_slots(device);
+    return b.cap;
+}
 // Wavefront slots a solve's persistent PCG grid needs (0: exclusive use of the budget).
 static int pcg_wave_cost(const LaunchDims& d, int members) {
     static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 1; }();
@@ -969,19 +986,32 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     static const int graph_mode = []() { const char* e = std::getenv("VISFS_BA_GRAPH"); return e ? std::atoi(e) : 2; }();
     const int n0 = half + w.extra_units[0], n1 = half2 > 0 ? half2 + w.extra_units[1] : 0;
     w.solves_since_upload += 1;
-    if (graph_mode != 0 && !w.prof_mask && (graph_mode == 1 || w.solves_since_upload >= 2)) {
+    bool replayed = false;
+    if (graph_mode != 0 && !w.prof_mask && !w.graph_failed && (graph_mode == 1 || w.solves_since_upload >= 2)) {
         if (!w.graph_exec || w.graph_units[0] != n0 || w.graph_units[1] != n1) {
             if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
+            // Any failure between begin and end must still END the capture (the stream is unusable otherwise), drop the partial graph and
+            // fall back to the eager sequence for this solve; capture is then not retried for this handle's workspace.
             hipGraph_t gr = nullptr;
-            HIP_TRY(h, hipStreamBeginCapture(w.stream, hipStreamCaptureModeThreadLocal));
-            enqueue_units(n0, true); phase_end(0); enqueue_units(n1, true); phase_end(1);
-            HIP_TRY(h, hipStreamEndCapture(w.stream, &gr));
-            HIP_TRY(h, hipGraphInstantiate(&w.graph_exec, gr, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(gr);
-            w.graph_units[0] = n0; w.graph_units[1] = n1;
+            bool ok = hipStreamBeginCapture(w.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                enqueue_units(n0, true); phase_end(0); enqueue_units(n1, true); phase_end(1);
+                const hipError_t launch_err = hipGetLastError();
+                const hipError_t end_err = hipStreamEndCapture(w.stream, &gr);
+                ok = launch_err == hipSuccess && end_err == hipSuccess && gr != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&w.graph_exec, gr, nullptr, nullptr, 0) == hipSuccess;
+            if (gr) (void)hipGraphDestroy(gr);
+            if (!ok) { if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; } w.graph_failed = true; (void)hipGetLastError(); }
+            else { w.graph_units[0] = n0; w.graph_units[1] = n1; }
         }
-        HIP_TRY(h, hipGraphLaunch(w.graph_exec, w.stream));
-    } else {
+        if (w.graph_exec) {
+            if (hipGraphLaunch(w.graph_exec, w.stream) == hipSuccess) replayed = true;
+            else { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; w.graph_failed = true; (void)hipGetLastError(); }
+        }
+    }
+    w.last_replayed = replayed;
+    if (!replayed) {
         enqueue_units(n0, true);                                                                    // :265
         phase_end(0);
         enqueue_units(n1, true);
@@ -1462,6 +1492,14 @@ int batch_optimize_group(visfs_ba_handle* h, const std::vector<int>& members) {
     }
     int K = parts_env >= 0 ? parts_env : 2;
     K = std::min(K, B / 4);                                     // at least four windows per part
+    if (K >= 2 && one_wave) {
+        // the parts hold their leases at the same time: when they do not fit the device's budget together the second would only wait
+        // for the first — a thread, a stream and two smaller launch sequences for nothing
+        LaunchDims d = dims_of(h->batch[members[0]]->g);
+        for (int i : members) d = dims_max(d, dims_of(h->batch[i]->g));
+        const int per0 = (B + K - 1) / K;
+        if ((int64_t)K * pcg_wave_cost(d, per0) > pcg_budget_capacity(h->device)) K = 1;
+    }
     if (K < 2 || !(one_wave || one_cu) || B < 8) return batch_optimize(h, h->scratch, h->batch, members, h->ws.stream);
     HIP_TRY(h, hipSetDevice(h->device));
     while ((int)h->part_stream.size() < K - 1) {
@@ -1802,6 +1840,8 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->n_schur_chunks = w.g.n_sch;
     out->device_bytes = (int64_t)w.device_bytes;
     out->fused_path = w.fused ? 1 : 0;
+    out->band_blocks = (h->prm.solver != 2 && !w.small_solve) ? w.g.band_B : -1;
+    out->graph_replayed = w.last_replayed ? 1 : 0;
     out->solver_kernel = w.small_solve ? 5 : h->prm.solver != 2 ? (w.g.band_B >= 0 ? 7 : 6) : w.g.pcg_cu ? 4 : w.g.pcg1_code ? 1 : w.g.Npf > MAX_PCG_ONE_ROW_POSES ? 3 : 2;
     return VISFS_BA_OK;
 }
@@ -1987,6 +2027,9 @@ static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size
 // (LinearSolverPCG::init()), run the outlier pass on the committed estimate.
 int visfs_ba_stage_commit(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (h->prm.framework != 0) { h->err = "the stage hooks step the g2o branch only (Optimizer/Framework=0)"; return VISFS_BA_ERR_UNSUPPORTED; }
+    return guarded(h, [&]() -> int {
+    HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     int rc = ws_read_state(h, w);
@@ -1994,10 +2037,14 @@ int visfs_ba_stage_commit(visfs_ba_handle* h) {
     w.h_state->sel ^= 1;
     HIP_TRY(h, hipMemcpyAsync(w.g.st, w.h_state, sizeof(LmState), hipMemcpyHostToDevice, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));
-    return VISFS_BA_OK;
+    return (int)VISFS_BA_OK;
+    });
 }
 int visfs_ba_stage_begin_phase(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (h->prm.framework != 0) { h->err = "the stage hooks step the g2o branch only (Optimizer/Framework=0)"; return VISFS_BA_ERR_UNSUPPORTED; }
+    return guarded(h, [&]() -> int {
+    HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     int rc = ws_read_state(h, w);
@@ -2005,16 +2052,21 @@ int visfs_ba_stage_begin_phase(visfs_ba_handle* h) {
     w.h_state->pcg_residual = -1.0; w.h_state->pcg_res_in = -1.0; w.h_state->status = 0;
     HIP_TRY(h, hipMemcpyAsync(w.g.st, w.h_state, sizeof(LmState), hipMemcpyHostToDevice, w.stream));
     HIP_TRY(h, hipStreamSynchronize(w.stream));
-    return VISFS_BA_OK;
+    return (int)VISFS_BA_OK;
+    });
 }
 int visfs_ba_stage_mark_outliers(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (h->prm.framework != 0) { h->err = "the stage hooks step the g2o branch only (Optimizer/Framework=0)"; return VISFS_BA_ERR_UNSUPPORTED; }
+    return guarded(h, [&]() -> int {
+    HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     Workspace& w = h->ws;
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     launch_eval_mark(w.g, w.stream);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(w.stream));
-    return VISFS_BA_OK;
+    return (int)VISFS_BA_OK;
+    });
 }
 
 int visfs_ba_hook_lm_script(int32_t gauss_newton, int32_t n_iter, double chi0, double max_diag0, int32_t n_trials,

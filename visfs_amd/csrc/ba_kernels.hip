@@ -1253,7 +1253,16 @@ __device__ __forceinline__ double gauss_jordan_6x6(const double val, const int l
 // (bd, be = blk_desc[2 b], blk_desc[2 b + 1] come from the caller: they do not depend on the LM state, so a kernel can have them in
 // flight while its gate is still being read)
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be) {
-    {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass
+    {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass.
+        // CONTRACT with the persistent PCG (k_pcg / k_pcg1) that follows: (1) EVERY block's wave runs this loop — the words are dealt
+        // over all n_blk waves (stride n_blk * 64), so a kernel that calls schur_block for a subset of the blocks clears only a
+        // subset of the words; (2) the PCG relies on it: a hand-off tag is just the iteration number, so a word that keeps the
+        // previous damped solve's value for iteration e is ACCEPTED by a consumer that polls before the producer's store lands.  The
+        // waves' redundant recurrences then differ in the last bits, they leave the loop in different iterations, and the others
+        // spin for a granule that is never published (LmState::pcg_timeout -> VISFS_BA_ERR_DEVICE).  That is what the dropped DIP
+        // variant of round 2 ran into (profiles/r02_dip_variant.log: C3 and the batched runs, whose waves start further apart;
+        // DESIGN.md §7).  Whoever moves the finalisation elsewhere must clear ALL 4 * 6 Npf + Npf words before the PCG launch — and
+        // b_s, Minv of ALL rows must be complete at that kernel boundary too: every PCG wave reads all of them in its set-up.
         const int nwords = 4 * 6 * g.Npf + g.Npf;           // q granules of both parities + one placement word per block row
         for (int w = b * 64 + lane; w < nwords; w += g.n_blk * 64) g.granules[w] = 0ull;
     }
@@ -1328,7 +1337,8 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
 // its six entries and publishes them as twelve 8-byte granules {epoch:32 | half of the double:32} with one
 // write-through store each; every workgroup then sweeps all granules of the iteration until their tags match
 // (cdna_hip_programming.md §6 Guideline 16, form R2: the data is the flag — no fence, no separate flag word).
-// Granules are double-buffered on the iteration parity and zeroed by k_schur_finalize before every solve.
+// Granules are double-buffered on the iteration parity and zeroed by k_schur_finalize before every solve (schur_block: every block's
+// wave clears its share — see the contract there; a tag is only the iteration number, stale words of the previous solve would match).
 // Residency: grid = Npf <= 256 workgroups of 4 waves: one per CU always fits, so the grid is co-resident on an otherwise
 // idle device; concurrent windows (visfs_ba_solve_batch) are limited so that the sum of their grids stays <= 256.
 // The XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID (hardware register 20), bits 3:0.
