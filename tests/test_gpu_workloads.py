@@ -376,3 +376,34 @@ def test_c4r_parity_with_the_converged_class_spelled_out(olib):
     assert np.array_equal(outo, outg)
     assert rel_err(pg, po) < 1e-6 and rel_err(ptg, pto) < 1e-6
     s.close(); o.close()
+
+
+def test_reference_default_solver_in_batched_launches(olib):
+    """Optimizer/Solver=0 (the reference default, Parameters.h:185) through visfs_ba_solve_batch: windows whose reduced system is banded
+    share every launch (k_band_chol<Many>: one workgroup per window) instead of being solved one after another — each result equal
+    to the single-window solve bit for bit; a window with a wide band (every pose sees every landmark: dense S) is solved on its own."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=0)
+    ws = [synth.make_window("custom", n_kf=24, n_lm=500, n_obs=4000, seed=300 + i) for i in range(6)]
+    ws.append(synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11))
+    ws += [synth.make_window("PROD", window_index=i) for i in range(2)]                   # k_small_solve group
+    s = backend.Solver(prm)
+    singles = []
+    for w in ws:
+        wb = abi.WindowBuffers(w)
+        rc, rb = s.solve_window(wb)
+        singles.append((rc, rb, wb))
+        if len(w["pose_ids"]) > 11:
+            assert s.describe()["solver_kernel"] == 7
+    wbs = [abi.WindowBuffers(w) for w in ws]
+    rbs = s.solve_batch(wbs)
+    for (rc, a, wa), b, wb in zip(singles, rbs, wbs):
+        assert rc == abi.OK and b.struct.status == rc
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert np.array_equal(wa.point_xyz, wb.point_xyz, equal_nan=True)
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run)
+    s.close()
+    # and against the oracle for one of them
+    o, g, gb = make_pair(olib, ws[0], iterations=10, solver=0)
+    check_optimize(o, g)
+    g.close(); o.close()

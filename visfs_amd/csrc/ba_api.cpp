@@ -935,7 +935,7 @@ static int pcg_wave_cost(const LaunchDims& d, int members) {
 int batch_members_per_launch(visfs_ba_handle* h, const std::vector<Workspace*>& ws, const std::vector<int>& all) {
     LaunchDims d = dims_of(ws[all[0]]->g);
     bool no_pcg = true;
-    for (int i : all) { d = dims_max(d, dims_of(ws[i]->g)); no_pcg = no_pcg && (ws[i]->small_solve || ws[i]->fused || ws[i]->g.pcg_cu); }
+    for (int i : all) { d = dims_max(d, dims_of(ws[i]->g)); no_pcg = no_pcg && (ws[i]->small_solve || ws[i]->fused || ws[i]->g.pcg_cu || (h->prm.solver != 2 && ws[i]->g.band_B >= 0)); }
     if (no_pcg) return 4096;                               // single-workgroup solvers: no co-residency requirement
     int cap = pcg_resident_capacity(d, true, h->device);
     if (cap <= 0) cap = 256;                               // query failed: one 256-thread workgroup per CU is always admitted
@@ -1707,9 +1707,11 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
         for (int i = 0; i < n; ++i) {
             if (!need[i]) continue;
             const Workspace& ws = *h->batch[i];
-            const bool batchable = batching && h->prm.framework == 0 && (h->prm.solver == 2 || ws.small_solve || ws.fused) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
+            // (the direct solver shares launches when the window's S is banded: k_band_chol, one workgroup per window)
+            const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
+            const bool batchable = batching && h->prm.framework == 0 && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
-            const int cls = ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
+            const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
         }
         std::vector<visfs_ba_stats> stats(n);
@@ -1804,9 +1806,10 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
         std::map<std::array<int, 4>, std::vector<int>> groups;
         for (int i = 0; i < n; ++i) {
             const Workspace& ws = *h->batch[i];
-            if (!(h->prm.solver == 2 || ws.small_solve || ws.fused)) { h->err = "batched launches need Optimizer/Solver=2 or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
+            const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
+            if (!(h->prm.solver == 2 || ws.small_solve || ws.fused || band)) { h->err = "batched launches need Optimizer/Solver=2, a banded reduced system (direct solver) or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
             if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
-            const int cls = ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
+            const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
         }
         int worst = VISFS_BA_OK;

@@ -244,8 +244,22 @@ BA_HD void hpl_tile(const Rt& T, const Vec3& pc, double wo, const Intrinsics& K,
 // core N has to be formed, the lower half is three cross products.  A^T A = [[2a^2, 0, a(c+e)], [0, b^2, bd],
 // [a(c+e), bd, c^2+d^2+e^2]] with a = fx/z, b = fy/z, c = -fx x/z^2, d = -fy y/z^2, e = c + bf/z^2.
 // Same values as hpl_tile up to rounding (different association); used where the arithmetic is the bound (Schur gather).
+// 1 / x where the arithmetic is the bound (the Schur gather and the back-substitution rebuild two tiles and invert one landmark block
+// per co-observation pair): v_rcp_f64 + two Newton steps — 5 dependent operations instead of the ~14 of an IEEE division, correctly
+// rounded but for rare last-bit cases.  Only the LINEAR SYSTEM passes through it (tiles, landmark inverses); residuals and chi2, which
+// drive the LM decisions, keep IEEE divisions.  The host build (tests of the device functions) divides.
+BA_HD double fast_recip(const double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
 BA_HD void tile_core(const Mat3& R, const Vec3& pc, double wo, const Intrinsics& K, double N[9]) {
-    const double iz = 1.0 / pc.z, iz2 = iz * iz;
+    const double iz = fast_recip(pc.z), iz2 = iz * iz;
     const double a = K.fx * iz, b = K.fy * iz;
     const double c = -K.fx * pc.x * iz2, d = -K.fy * pc.y * iz2, e = c + K.bf * iz2;
     const double m00 = wo * (2.0 * a * a), m02 = wo * (a * (c + e)), m11 = wo * (b * b), m12 = wo * (b * d);
@@ -275,7 +289,7 @@ BA_HD void huber_ceres(double s, double a, double& rho0, double& rho1) {
 BA_HD void sym3_inverse(const double h[6], double o[6]) {
     const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    const double id = 1.0 / (a * c00 + b * c01 + c * c02);
+    const double id = fast_recip(a * c00 + b * c01 + c * c02);     // (a singular block gives inf or NaN: the callers test for both)
     o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
     o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
 }
