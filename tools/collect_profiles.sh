@@ -13,7 +13,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 step() { echo "[collect] $*" >&2; }
 step "headline"
 timeout -k 10 400 python3 bench.py --config5 on > "$OUT/${TAG}_c2_bench.json" 2> "$OUT/${TAG}_c2_bench.err"
-for CFG in C3 C4 C4R; do
+for CFG in C1 PROD C3 C4 C4R; do
   step "bench $CFG"
   timeout -k 10 400 python3 bench.py --config $CFG --steps 10 --warmup 2 > "$OUT/${TAG}_bench_$CFG.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
@@ -23,6 +23,7 @@ timeout -k 10 300 python3 bench.py --config C4 --solver 0 --iterations 10 --step
 for CFG in C2 PROD; do
   timeout -k 10 300 python3 bench.py --config $CFG --framework 1 --steps 20 --warmup 3 > "$OUT/${TAG}_bench_ceres_$CFG.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
+timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu 8 --solver 0 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x8_solver0.json" 2>> "$OUT/${TAG}_c2_bench.err"
 step "batches on one GPU"
 for B in 8 16; do
   timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu $B --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x$B.json" 2>> "$OUT/${TAG}_c2_bench.err"
