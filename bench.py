@@ -197,7 +197,12 @@ def main():
     gathered = gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_dev, vdist, abi, synth, backend, torch)
     c5 = None
     if args.config5 == "on" or (args.config5 == "auto" and world > 1):
-        c5 = config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, synth, backend, torch)
+        # (the headline line must survive whatever happens in this extra leg: every rank takes the same path through its collectives
+        # unless its own solve fails, and a failure is reported instead of raised)
+        try:
+            c5 = config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, synth, backend, torch)
+        except Exception as e:          # noqa: BLE001
+            c5 = {"error": f"{type(e).__name__}: {e}"[:200]}
     vdist.shutdown(world)                  # last collective done
 
     if rank != 0:

@@ -111,3 +111,28 @@ def test_random_window_matches_oracle_ceres_branch(olib, i):
         et, er = synth.pose_errors(rb_g.pose_Twr_out[:n], rb_o.pose_Twr_out[:n])
         assert et < 1e-7 and er < 1e-7, (et, er, kw)
         assert rel_err(wb_g.point_xyz, wb_o.point_xyz) < 1e-6
+
+
+def test_ceres_branch_in_batched_launches(olib):
+    """Optimizer/Framework=1 through visfs_ba_solve_batch: windows whose reduced system is small (k_small_solve) or banded (k_band_chol)
+    share every launch — k_ceres_lin_finalize after every linearisation, the per-variable damping in the Schur gather, one pass of
+    <= Iterations trust-region iterations, no second phase — and come out as the bytes of their single-window solves."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=12, framework=1)
+    ws = [synth.make_window("PROD", window_index=i) for i in range(5)]
+    ws += [synth.make_window("custom", n_kf=24, n_lm=500, n_obs=4000, seed=400 + i) for i in range(4)]
+    ws.append(hard_window())
+    s = backend.Solver(prm)
+    singles = []
+    for w in ws:
+        wb = abi.WindowBuffers(w)
+        rc, rb = s.solve_window(wb)
+        singles.append((rc, rb, wb))
+    wbs = [abi.WindowBuffers(w) for w in ws]
+    rbs = s.solve_batch(wbs)
+    for (rc, a, wa), b, wb in zip(singles, rbs, wbs):
+        assert rc == abi.OK and b.struct.status == rc
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run)
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert np.array_equal(wa.point_xyz, wb.point_xyz, equal_nan=True)
+    s.close()

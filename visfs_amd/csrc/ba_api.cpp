@@ -46,7 +46,38 @@ struct Arena {
 
 // Host scratch of the window layer that survives from call to call (a fresh std::vector of this size is an mmap, a page fault per
 // 4 KiB on first touch and an munmap, every frame — and page faults from several threads at once serialise in the kernel).
-struct SummaryPart { std::vector<int32_t> cnt, run, pc; int64_t pairs = 0; int ok = 0; bool any_run = false, used = false; const char* bad = nullptr; };
+struct alignas(128) SummaryPart {          // (one per thread, updated per observation: no two may share a cache line)
+    std::vector<int32_t> cnt, run, pc, track;
+    int64_t pairs = 0; int ok = 0; bool any_run = false, used = false; const char* bad = nullptr;
+    int npf = 0; int cur = -1; bool cur_fixed = false;
+    int first = -1, last = -1, c = 0; bool gap = false;         // the current landmark's free poses: a contiguous run unless `gap`
+    void begin(int Npf) {
+        used = true; npf = Npf; cnt.assign(Npf + 1, 0); run.assign((size_t)Npf * Npf, 0); pc.clear(); track.clear();
+        pairs = 0; ok = 0; any_run = false; bad = nullptr; cur = -1; first = last = -1; c = 0; gap = false;
+    }
+    // observations arrive landmark by landmark (a landmark never straddles two accumulators), poses ascending inside a landmark
+    inline void add(int landmark, bool landmark_fixed, int a /* free index of the pose, -1: fixed */) {
+        if (landmark != cur) { flush(); cur = landmark; cur_fixed = landmark_fixed; }
+        ok += !(a < 0 && landmark_fixed);
+        if (a < 0) return;
+        cnt[a + 1]++;
+        if (c == 0) { first = last = a; c = 1; return; }
+        if (!gap && a != last + 1) { gap = true; track.clear(); for (int q = first; q <= last; ++q) track.push_back(q); }   // (rare) the members so far were a run
+        if (gap) track.push_back(a);
+        last = a; ++c;
+    }
+    void flush() {
+        if (cur >= 0 && !cur_fixed && c > 0) {
+            pairs += (int64_t)c * (c + 1) / 2;
+            if (!gap) { run[(size_t)first * npf + last]++; any_run = true; }
+            else {
+                if (pc.empty()) pc.assign((size_t)npf * npf, 0);      // tracks with gaps are rare: their pairwise table only exists when one shows up
+                for (int i = 0; i < c; ++i) { int32_t* row = pc.data() + (size_t)track[i] * npf; for (int j = i; j < c; ++j) row[track[j]]++; }
+            }
+        }
+        c = 0; gap = false; first = last = -1;
+    }
+};
 struct PackedWindow {
     std::vector<uint8_t> pose_fixed, point_used;
     std::vector<int32_t> obs_ref;
@@ -222,7 +253,7 @@ size_t output_stage_bytes(const DeviceGraph& g) {
 // device allocation and pinned staging arena.  Its layout depends only on the sizes below, so (a) the window layer packs straight
 // into the staging arena (no second copy of anything of size N_obs) and (b) its host-to-device copy starts before the structure of
 // S has been worked out.
-struct PrimSizes { int Np = 0, Nl = 0, cap_obs = 0, cap_odo = 0, Nz = 0; size_t grid_cells = 0; };
+struct PrimSizes { int Np = 0, Nl = 0, cap_obs = 0, cap_odo = 0, Nz = 0; size_t grid_cells = 0; bool raw_refs = false; };   // raw_refs: (u, v, depth) floats instead of (u_l, v_l, u_r) doubles
 void layout_prim(Arena& A, DeviceGraph& g, const PrimSizes& z) {
     g.pose0 = A.take<double>((size_t)z.Np * POSE_STRIDE);
     g.pt0 = A.take<double>((size_t)std::max(z.Nl, 1) * 3);
@@ -231,7 +262,8 @@ void layout_prim(Arena& A, DeviceGraph& g, const PrimSizes& z) {
     g.pt_fixed = A.take<uint8_t>(std::max(z.Nl, 1));
     g.obs_pose = A.take<int32_t>(std::max(z.cap_obs, 1));
     g.obs_pt = A.take<int32_t>(std::max(z.cap_obs, 1));
-    g.obs_uvr = A.take<double>((size_t)std::max(z.cap_obs, 1) * 3);
+    if (z.raw_refs) { g.obs_uvd = A.take<float>((size_t)std::max(z.cap_obs, 1) * 3); g.obs_uvr = nullptr; }
+    else { g.obs_uvr = A.take<double>((size_t)std::max(z.cap_obs, 1) * 3); g.obs_uvd = nullptr; }
     g.odo_i = A.take<int32_t>(std::max(z.cap_odo, 1));
     g.odo_j = A.take<int32_t>(std::max(z.cap_odo, 1));
     g.odo_tq = A.take<double>((size_t)std::max(z.cap_odo, 1) * 7);
@@ -274,62 +306,13 @@ struct GraphSummary {
 // key-frames almost always (a feature is tracked frame to frame and never re-acquired), so a landmark whose free poses form the
 // contiguous range [s, e] only bumps run[s][e]; the blocks are then counted by one 2-D inclusion sum, pcount[a][b] = sum over s <= a,
 // e >= b of run[s][e] — O(Nl + Npf^2) instead of O(sum k^2).  Landmarks with gaps in their track take the pairwise loop.
-void summarize_graph(const visfs_ba_graph* gr, const int32_t* pose_free, const int Npf, WorkerPool* pool, const bool check, GraphSummary& S,
-                     std::vector<SummaryPart>& part, std::vector<int32_t>& run) {
-    const int No = gr->n_obs, Nl = gr->n_points, Np = gr->n_poses;
+void merge_summary(std::vector<SummaryPart>& part, const int NT, const int Npf, GraphSummary& S, std::vector<int32_t>& run) {
     const size_t nn = (size_t)Npf * Npf;
-    // several tasks per thread (a worker that wakes late still finds work); accumulators per THREAD, not per task
-    const int NT = (pool && No >= 16384 && nn <= ((size_t)1 << 17)) ? pool->size() : 1;
-    const int T = NT > 1 ? 4 * NT : 1;
-    std::vector<int> cut(T + 1, No);
-    cut[0] = 0;
-    for (int t = 1; t < T; ++t) {
-        int k = (int)((int64_t)No * t / T);
-        k = std::max(k, cut[t - 1]);
-        while (k > 0 && k < No && gr->obs_point[k] == gr->obs_point[k - 1]) ++k;     // a landmark's observations stay with one task
-        cut[t] = k;
-    }
-    typedef SummaryPart Part;
-    if ((int)part.size() < NT) part.resize(NT);
-    for (int t = 0; t < NT; ++t) { Part& P = part[t]; P.used = false; P.pairs = 0; P.ok = 0; P.any_run = false; P.bad = nullptr; P.pc.clear(); }
-    auto body = [&](int t, int slot) {
-        Part& P = part[slot];
-        if (!P.used) { P.used = true; P.cnt.assign(Npf + 1, 0); P.run.assign(nn, 0); }
-        if (P.bad) return;
-        const int k_lo = cut[t], k_hi = cut[t + 1];
-        int k = k_lo;
-        while (k < k_hi) {
-            const int l = gr->obs_point[k];
-            if (check && (l < 0 || l >= Nl)) { P.bad = "observation index out of range"; return; }
-            if (check && k > 0 && l < gr->obs_point[k - 1]) { P.bad = "observations must be sorted by (point, pose) and unique"; return; }
-            const bool lfix = gr->point_fixed[l] != 0;
-            int first = -1, last = -1, c = 0, ks = k;
-            for (; k < k_hi && gr->obs_point[k] == l; ++k) {
-                const int cp = gr->obs_pose[k];
-                if (check && (cp < 0 || cp >= Np)) { P.bad = "observation index out of range"; return; }
-                if (check && k > ks && cp <= gr->obs_pose[k - 1]) { P.bad = "observations must be sorted by (point, pose) and unique"; return; }
-                const int a = pose_free[cp];
-                P.ok += !(a < 0 && lfix);
-                if (a >= 0) { P.cnt[a + 1]++; if (first < 0) first = a; last = a; ++c; }
-            }
-            if (lfix || c == 0) continue;
-            P.pairs += (int64_t)c * (c + 1) / 2;
-            if (last - first + 1 == c) { P.run[(size_t)first * Npf + last]++; P.any_run = true; continue; }   // (observations ascend by pose)
-            if (P.pc.empty()) P.pc.assign(nn, 0);                    // tracks with gaps are rare: their pairwise table only exists when one shows up
-            for (int k1 = ks; k1 < k; ++k1) {
-                const int a = pose_free[gr->obs_pose[k1]];
-                if (a < 0) continue;
-                int32_t* row = P.pc.data() + (size_t)a * Npf;
-                for (int k2 = k1; k2 < k; ++k2) { const int b2 = pose_free[gr->obs_pose[k2]]; if (b2 >= 0) row[b2]++; }
-            }
-        }
-    };
-    if (T > 1) pool->run(T, body); else body(0, 0);
     S.cnt.assign(Npf + 1, 0); S.pcount.assign(nn, 0); S.pairs_seen = 0; S.n_edges_ok = 0; S.bad = nullptr;
     run.assign(nn, 0);
     bool any_run = false;
     for (int t = 0; t < NT; ++t) {
-        const Part& P = part[t];
+        const SummaryPart& P = part[t];
         if (!P.used) continue;
         if (P.bad) { S.bad = P.bad; return; }
         for (int a = 0; a <= Npf; ++a) S.cnt[a] += P.cnt[a];
@@ -351,12 +334,48 @@ void summarize_graph(const visfs_ba_graph* gr, const int32_t* pose_free, const i
         for (int a = 0; a < Npf; ++a) for (int b2 = a; b2 < Npf; ++b2) S.pcount[(size_t)a * Npf + b2] += run[(size_t)a * Npf + b2];
     }
 }
+void summarize_graph(const visfs_ba_graph* gr, const int32_t* pose_free, const int Npf, WorkerPool* pool, const bool check, GraphSummary& S,
+                     std::vector<SummaryPart>& part, std::vector<int32_t>& run) {
+    const int No = gr->n_obs, Nl = gr->n_points, Np = gr->n_poses;
+    const size_t nn = (size_t)Npf * Npf;
+    // several tasks per thread (a worker that wakes late still finds work); accumulators per THREAD, not per task
+    const int NT = (pool && No >= 16384 && nn <= ((size_t)1 << 17)) ? pool->size() : 1;
+    const int T = NT > 1 ? 4 * NT : 1;
+    std::vector<int> cut(T + 1, No);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        int k = (int)((int64_t)No * t / T);
+        k = std::max(k, cut[t - 1]);
+        while (k > 0 && k < No && gr->obs_point[k] == gr->obs_point[k - 1]) ++k;     // a landmark's observations stay with one task
+        cut[t] = k;
+    }
+    if ((int)part.size() < NT) part.resize(NT);
+    for (int t = 0; t < NT; ++t) part[t].used = false;
+    auto body = [&](int t, int slot) {
+        SummaryPart& P = part[slot];
+        if (!P.used) P.begin(Npf);
+        if (P.bad) return;
+        for (int k = cut[t]; k < cut[t + 1]; ++k) {
+            const int l = gr->obs_point[k], cp = gr->obs_pose[k];
+            if (check) {
+                if (l < 0 || l >= Nl || cp < 0 || cp >= Np) { P.bad = "observation index out of range"; return; }
+                if (k > 0 && (l < gr->obs_point[k - 1] || (l == gr->obs_point[k - 1] && cp <= gr->obs_pose[k - 1]))) { P.bad = "observations must be sorted by (point, pose) and unique"; return; }
+            }
+            P.add(l, gr->point_fixed[l] != 0, pose_free[cp]);
+        }
+        P.flush();
+    };
+    if (T > 1) pool->run(T, body); else body(0, 0);
+    merge_summary(part, NT, Npf, S, run);
+}
 
 struct UploadOpts {
     bool in_staging = false;   // the graph's arrays already live in the workspace's primary staging arena, laid out for `cap` (window layer)
     PrimSizes cap;             // ... the sizes that layout was made for
     bool trusted = false;      // ... and were produced by the library's own graph build: no validation pass
     WorkerPool* pool = nullptr;
+    double baseline = 0.0;     // raw references (cap.raw_refs): the stereo baseline the device forms the disparity with
+    int summary_slots = 0;     // > 0: the graph build has already fed w.sum_part[0 .. summary_slots) (no second pass over the observations)
 };
 
 int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const UploadOpts& opt = UploadOpts()) {
@@ -432,7 +451,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
 
     // ---- what the host needs of the O(N_obs) part: observations per free pose, co-observation pairs per block
     GraphSummary sum;
-    summarize_graph(gr, pose_free.data(), Npf, opt.pool, !opt.trusted, sum, w.sum_part, w.sum_run);
+    if (opt.summary_slots > 0) merge_summary(w.sum_part, opt.summary_slots, Npf, sum, w.sum_run);
+    else summarize_graph(gr, pose_free.data(), Npf, opt.pool, !opt.trusted, sum, w.sum_part, w.sum_run);
     if (sum.bad) return bad(h, sum.bad);
     const std::vector<int32_t>& cnt = sum.cnt;
     std::vector<int32_t>& pcount = sum.pcount;
@@ -647,6 +667,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.obs_ok = A.take<uint8_t>(std::max(No, 1));
         g.obs_ppos = A.take<int32_t>(std::max(No, 1));
         g.pose_obs = A.take<int32_t>(std::max(n_pose_obs, 1));
+        if (pz.raw_refs) g.obs_uvr = A.take<double>((size_t)std::max(No, 1) * 3);      // written by k_index_count from obs_uvd
         d_hist = A.take<int32_t>(n_hist);
         for (int k = 0; k < 2; ++k) {                       // the two linearisation sets: same layout, constant distance
             LinBuf& L = g.lin[k];
@@ -750,6 +771,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
+    dg.stereo_baseline = opt.baseline;
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_pixel_var_out = dg.inv_pixel_var;
     dg.ceres = ceres ? 1 : 0;
@@ -1110,9 +1132,11 @@ int find_id(const uint64_t* ids, int n, uint64_t id) {
 struct PackOut {
     double* pose = nullptr; int pose_stride = 7; uint8_t* pose_fixed = nullptr; uint8_t* point_used = nullptr;
     int32_t* obs_point = nullptr; int32_t* obs_pose = nullptr; double* obs_uvr = nullptr; int32_t* obs_ref = nullptr;
+    float* obs_uvd = nullptr;          // when set: the raw (u, v, depth) floats are stored instead of obs_uvr (the device forms the measurement)
     int32_t* odo_from = nullptr; int32_t* odo_to = nullptr; double* odo_tq = nullptr;
 };
-int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph* g, int32_t* n_mono_skipped, WorkerPool* pool) {
+struct PackSummary { std::vector<SummaryPart>* part = nullptr; std::vector<int32_t> pose_free; int Npf = 0; int slots = 0; };
+int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph* g, int32_t* n_mono_skipped, WorkerPool* pool, PackSummary* ps = nullptr) {
     std::memset(g, 0, sizeof(*g));
     const auto te0 = std::chrono::steady_clock::now();
     // poses: Twc = Twr * Trc ; Tcw = Twc^-1 as CameraPose(R,t) ; fixed iff id == rootId   (Optimizer.cpp:100-114)
@@ -1143,6 +1167,15 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
     // landmarks + stereo edges   (Optimizer.cpp:153-223)
     std::memset(o.point_used, 0, (size_t)w->n_points);
     const int Nr = w->n_refs;
+    if (ps) {
+        // the structure summary of the upload (observations per free pose, co-observation pairs per block of S) is accumulated here,
+        // while an observation's indices are in registers: re-reading them from the pinned arena afterwards is a pass over uncached memory
+        ps->pose_free.resize(w->n_poses); ps->Npf = 0;
+        for (int i = 0; i < w->n_poses; ++i) ps->pose_free[i] = o.pose_fixed[i] ? -1 : ps->Npf++;
+        ps->slots = pool ? pool->size() : 1;
+        if ((size_t)ps->Npf * ps->Npf > ((size_t)1 << 17) && ps->slots > 1) { ps->slots = 0; ps = nullptr; }     // very wide systems: per-thread tables would not pay
+        else { if ((int)ps->part->size() < ps->slots) ps->part->resize(ps->slots); for (int t = 0; t < ps->slots; ++t) (*ps->part)[t].used = false; }
+    }
     double baseLine = 0.0;
     if (w->n_cameras > 1) baseLine = (double)w->baseline;                       // :181-183
     const int T = (pool && Nr >= 16384) ? 4 * pool->size() : 1;       // several tasks per thread: a worker that wakes late still finds work
@@ -1162,6 +1195,8 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
     std::atomic<int> by_caller{ 0 };
     auto body = [&](int t, int slot) {
         if (timing && slot == 0) by_caller.fetch_add(1, std::memory_order_relaxed);
+        SummaryPart* SP = ps ? &(*ps->part)[slot] : nullptr;
+        if (SP && !SP->used) SP->begin(ps->Npf);
         Part& P = part[t];
         int no = cut[t], mono = 0, last_p = -1, last_c = -1;
         // references arrive in nested-map order, so the id looked up is almost always at (or right after) the previous hit
@@ -1184,17 +1219,23 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
                 if (p < last_p || (p == last_p && c <= last_c)) { P.bad = true; return; }   // nested std::map order
                 if (P.first_p < 0) { P.first_p = p; P.first_c = c; }
                 last_p = p; last_c = c;
-                const float disparity = static_cast<float>(baseLine * w->fx / depth);               // :187
-                o.obs_uvr[3 * (size_t)no + 0] = (double)w->ref_u[k];
-                o.obs_uvr[3 * (size_t)no + 1] = (double)w->ref_v[k];
-                o.obs_uvr[3 * (size_t)no + 2] = (double)(w->ref_u[k] - disparity);                  // float - float, :188
+                if (o.obs_uvd) {
+                    o.obs_uvd[3 * (size_t)no + 0] = w->ref_u[k]; o.obs_uvd[3 * (size_t)no + 1] = w->ref_v[k]; o.obs_uvd[3 * (size_t)no + 2] = w->ref_depth[k];
+                } else {
+                    const float disparity = static_cast<float>(baseLine * w->fx / depth);           // :187
+                    o.obs_uvr[3 * (size_t)no + 0] = (double)w->ref_u[k];
+                    o.obs_uvr[3 * (size_t)no + 1] = (double)w->ref_v[k];
+                    o.obs_uvr[3 * (size_t)no + 2] = (double)(w->ref_u[k] - disparity);              // float - float, :188
+                }
                 o.obs_point[no] = p; o.obs_pose[no] = c;
                 if (o.obs_ref) o.obs_ref[no] = k;
+                if (SP) SP->add(p, w->point_fixed[p] != 0, ps->pose_free[c]);
                 ++no;
             } else {
                 ++mono;   // the reference dereferences an uninitialised edge pointer here (:179, :197-210); we skip the observation
             }
         }
+        if (SP) SP->flush();
         P.no = no - cut[t]; P.mono = mono; P.last_p = last_p; P.last_c = last_c;
     };
     if (T > 1) pool->run(T, body); else body(0, 0);
@@ -1210,7 +1251,8 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
             if (no != cut[t]) {                                                     // close the gap skipped references left
                 std::memmove(o.obs_point + no, o.obs_point + cut[t], (size_t)P.no * 4);
                 std::memmove(o.obs_pose + no, o.obs_pose + cut[t], (size_t)P.no * 4);
-                std::memmove(o.obs_uvr + 3 * (size_t)no, o.obs_uvr + 3 * (size_t)cut[t], (size_t)P.no * 24);
+                if (o.obs_uvd) std::memmove(o.obs_uvd + 3 * (size_t)no, o.obs_uvd + 3 * (size_t)cut[t], (size_t)P.no * 12);
+                else std::memmove(o.obs_uvr + 3 * (size_t)no, o.obs_uvr + 3 * (size_t)cut[t], (size_t)P.no * 24);
                 if (o.obs_ref) std::memmove(o.obs_ref + no, o.obs_ref + cut[t], (size_t)P.no * 4);
             }
         }
@@ -1275,6 +1317,9 @@ int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win,
     UploadOpts opt;
     opt.in_staging = true; opt.trusted = true; opt.pool = pool;
     opt.cap.Np = Np; opt.cap.Nl = Nl; opt.cap.cap_obs = Nr; opt.cap.cap_odo = Nk;
+    // the references cross the memory bus and PCIe as localOptimize receives them (float u, v, depth: 12 bytes); the device forms (u_l, v_l, u_r)
+    { static const bool raw = []() { const char* e = std::getenv("VISFS_BA_RAW_REFS"); return !(e && e[0] == '0'); }(); opt.cap.raw_refs = raw; }
+    opt.baseline = (win->n_cameras > 1) ? (double)win->baseline : 0.0;
     if (win->n_laser_points > 0 && win->grid != nullptr && win->laser_xyz != nullptr) {
         const visfs_ba_grid& G = *win->grid;
         opt.cap.Nz = win->n_laser_points;
@@ -1287,11 +1332,13 @@ int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win,
     pk.pose_fixed.resize(Np); pk.point_used.resize(std::max(Nl, 1)); pk.obs_ref.resize(std::max(Nr, 1));
     PackOut o;
     o.pose = const_cast<double*>(hg.pose0); o.pose_stride = POSE_STRIDE; o.pose_fixed = pk.pose_fixed.data(); o.point_used = pk.point_used.data();
-    o.obs_point = const_cast<int32_t*>(hg.obs_pt); o.obs_pose = const_cast<int32_t*>(hg.obs_pose); o.obs_uvr = const_cast<double*>(hg.obs_uvr); o.obs_ref = pk.obs_ref.data();
+    o.obs_point = const_cast<int32_t*>(hg.obs_pt); o.obs_pose = const_cast<int32_t*>(hg.obs_pose); o.obs_uvr = const_cast<double*>(hg.obs_uvr); o.obs_uvd = const_cast<float*>(hg.obs_uvd); o.obs_ref = pk.obs_ref.data();
     o.odo_from = const_cast<int32_t*>(hg.odo_i); o.odo_to = const_cast<int32_t*>(hg.odo_j); o.odo_tq = const_cast<double*>(hg.odo_tq);
     const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    rc = pack_window_impl(win, o, &pk.g, &pk.mono, pool);
+    PackSummary psum; psum.part = &w.sum_part;
+    rc = pack_window_impl(win, o, &pk.g, &pk.mono, pool, &psum);
+    opt.summary_slots = psum.slots;     // (0 when the build declined to accumulate: ws_upload then runs its own pass)
     if (timing) std::fprintf(stderr, "  pack (%d thread%s)     %8.1f us\n", pool ? pool->size() : 1, pool ? "s" : "", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count());
     if (rc != VISFS_BA_OK) { r->status = bad(h, "window references must be sorted by (feature, pose)"); return 0; }
     if (Nl) { std::memcpy(const_cast<double*>(hg.pt0), win->point_xyz, (size_t)Nl * 24); std::memcpy(const_cast<uint8_t*>(hg.pt_fixed), win->point_fixed, Nl); }
@@ -1436,7 +1483,9 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     PcgLease pcg_lease;                                                                // persistent PCG: co-residency budget of the device
     if (!fused && !small_solve && !d.pcg_cu && h->prm.solver == 2) pcg_lease.acquire(h->device, pcg_wave_cost(d, B));
     HIP_TRY(h, hipMemcpyAsync(bs.d_graphs, hg.data(), (size_t)B * sizeof(DeviceGraph), hipMemcpyHostToDevice, stream));
-    const int half = h->prm.iterations / 2;
+    // g2o branch: optimize(iterations / 2) twice; Ceres branch: one Solve of <= iterations trust-region iterations, no second pass
+    const bool ceres = h->prm.framework == 1;
+    const int half = ceres ? h->prm.iterations : h->prm.iterations / 2;
     launch_reset_batch(bs.d_graphs, B, d, half, h->prm.trust_region == 1, 0, stream);
     if (fused) {
         launch_small_optimize_batch(bs.d_graphs, B, h->prm.solver, half, stream);
@@ -1444,7 +1493,7 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     // As for a single window (ws_optimize): both phases and their device-gated ends are enqueued up front and the whole LM states
     // come back in ONE copy; windows that rejected trials are topped up from what comes back.  Every launch is gated per window,
     // so the same sequence is safe for windows at different points of the schedule.
-    const int half2 = (h->prm.robust_kernel_delta > 0.0) ? half : 0;                                // :310-311
+    const int half2 = (h->prm.robust_kernel_delta > 0.0 && !ceres) ? half : 0;                      // :310-311
     auto units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, fused_decide, stream); first = false; } };
     auto phase_end = [&](int which) {
         if (which == 0) launch_phase_end_batch(bs.d_graphs, B, d, 0, 1, half2, stream);             // :270-303
@@ -1709,7 +1758,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             const Workspace& ws = *h->batch[i];
             // (the direct solver shares launches when the window's S is banded: k_band_chol, one workgroup per window)
             const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
-            const bool batchable = batching && h->prm.framework == 0 && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
+            const bool batchable = batching && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
@@ -1766,7 +1815,6 @@ int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* c
     if (!h || n < 0 || (n > 0 && !graphs)) return VISFS_BA_ERR_BAD_ARGUMENT;
     for (int i = 0; i < n; ++i) if (!graphs[i]) return VISFS_BA_ERR_BAD_ARGUMENT;
     if (const char* why = framework_refusal(h->prm)) { h->err = why; return VISFS_BA_ERR_UNSUPPORTED; }
-    if (h->prm.framework == 1) { h->err = "batched launches are implemented for Optimizer/Framework=0 only: solve Ceres-flavour windows one by one (visfs_ba_solve_batch does)"; return VISFS_BA_ERR_UNSUPPORTED; }
     return guarded(h, [&]() -> int {
         while ((int)h->batch.size() < n) { h->batch.push_back(new Workspace()); h->batch.back()->batch_member = true; }
         for (int i = 0; i < n; ++i) h->batch[i]->batch_hint = n;
@@ -1793,7 +1841,7 @@ int visfs_ba_batch_upload(visfs_ba_handle* h, int32_t n, const visfs_ba_graph* c
 int visfs_ba_batch_reset(visfs_ba_handle* h) {
     if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->n_batch > 0) launch_reset_batch(h->scratch.d_all, h->n_batch, h->scratch.all_dims, h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
+    if (h->n_batch > 0) launch_reset_batch(h->scratch.d_all, h->n_batch, h->scratch.all_dims, h->prm.framework == 1 ? h->prm.iterations : h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
     HIP_TRY(h, hipGetLastError());
     return VISFS_BA_OK;
 }

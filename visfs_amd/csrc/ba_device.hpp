@@ -143,7 +143,10 @@ struct DeviceGraph {
     const int32_t* obs_pose;    // [No]
     const int32_t* obs_pt;      // [No]
     const int32_t* obs_ppos;    // [No] position of the observation in pose_obs (pose-major order), -1 for observations of fixed poses
-    const double* obs_uvr;      // [No][3]
+    const double* obs_uvr;      // [No][3] (u_l, v_l, u_r) as Optimizer.cpp:187-188 forms them; window layer: written by k_index_count from obs_uvd
+    const float* obs_uvd;       // [No][3] window layer only: the key-point (u, v) and the depth as localOptimize receives them (FeatureBA: floats) — 12
+                                //   instead of 24 bytes per observation across the host's memory bus and PCIe; nullptr: obs_uvr came from the host
+    double stereo_baseline;     // ... the baseline (getBaseLine(), a float) the disparity is formed with
     const uint8_t* obs_ok;      // [No] !(pose fixed && point fixed)
     const int32_t* lm_ptr;      // [Nl+1]
     const int32_t* chunk_pose;  // [n_chunks] free pose index

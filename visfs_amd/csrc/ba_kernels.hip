@@ -983,6 +983,14 @@ __global__ __launch_bounds__(256) void k_index_count(const DeviceGraph g, int32_
         const int c = g.obs_pose[k], l = g.obs_pt[k];
         const int a = g.pose_free[c];
         sfree[tid] = a;
+        if (g.obs_uvd) {
+            // the stereo measurement exactly as Optimizer.cpp:187-188 forms it: disparity = float(baseLine * fx / depth) in double, then
+            // float; u_r = u - disparity in FLOAT arithmetic, promoted (IEEE double division and round-to-nearest conversions on both sides)
+            const float u = g.obs_uvd[3 * (size_t)k], v = g.obs_uvd[3 * (size_t)k + 1], dpt = g.obs_uvd[3 * (size_t)k + 2];
+            const float disparity = static_cast<float>(g.stereo_baseline * g.fx / (double)dpt);
+            double* uvr = const_cast<double*>(g.obs_uvr) + 3 * (size_t)k;
+            uvr[0] = (double)u; uvr[1] = (double)v; uvr[2] = (double)(u - disparity);
+        }
         const_cast<uint8_t*>(g.obs_ok)[k] = !(a < 0 && g.pt_fixed[l]);
         if (a < 0) const_cast<int32_t*>(g.obs_ppos)[k] = -1;
         const int lprev = k > 0 ? g.obs_pt[k - 1] : -1;
@@ -2454,6 +2462,8 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     unsigned char* pij = reinterpret_cast<unsigned char*>(scode) + ((size_t)Npf * W * 4 + 15) / 16 * 16;   // [(B - 1) B / 2][2] (i, j), 2 <= j <= i <= B
     // ---- the first RR block rows of S: the lower block (I, I - d) is the transpose of the stored upper block (I - d, I).  The block
     // ids go to LDS first, so that the element loads below are independent of each other and many are in flight per thread.
+    // (measured and dropped: letting the rows of a RESIDENT band enter progressively through the streaming path — the 7 us up-front
+    // load shrinks to 3.6, but waves 1..3 then wait for global loads in 40 of the 49 steps: 87.7 -> 94.7 us per C2 solve)
     const int nrows0 = min(RR, Npf), nslots0 = nrows0 * W;
     for (int t = tid; t < Npf * W; t += BAND_T) scode[t] = g.band_code[t];
     for (int t = tid; t < 6 * Npf; t += BAND_T) cvec[t] = g.bs[t];
@@ -2543,6 +2553,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     constexpr int NPEND = (BAND_MAX_W * 36 + (BAND_T - 64) - 1) / (BAND_T - 64);
     double pend[NPEND];                                        // streaming form: the block row of S on its way into the ring (waves 1..3)
     int pend_row = -1;
+    int enter_row = nrows0 % RR;                               // ring row of the next block row of S to enter (streaming: the row of block row k - 1)
     for (int k = 0; k < Npf; ++k) {
         const int nb = min(B, Npf - 1 - k);
         double* Dk = dinv + 36 * (k & 1);
@@ -2565,16 +2576,16 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
             if (lane == 0 && k < 16) sstamp[2 + 6 * k] = wall_clock64();
 #endif
         } else if (k > 0) {
-            // the block row of S that entered the registers one step ago goes to the ring row it replaces (its loads have had a whole
-            // step to arrive), then the loads of the next one are issued: block row k - 1 + RR, into the ring row of block row k - 1
+            // the block row of S that entered the registers one step ago goes to its ring row (its loads have had a whole step to arrive),
+            // then the loads of the next one are issued: block row k - 1 + nrows0 (streaming form: into the ring row of block row k - 1)
             if (pend_row >= 0) {
                 double* dst = ring + (size_t)pend_row * rowsz;
 #pragma unroll
                 for (int u = 0; u < NPEND; ++u) { const int t = tid - 64 + (BAND_T - 64) * u; if (t < rowsz) dst[t] = pend[u]; }
                 pend_row = -1;
             }
-            const int Inew = k - 1 + RR;
-            if (!resident && Inew < Npf) {
+            const int Inew = k - 1 + nrows0;
+            if (Inew < Npf) {
                 const int* code = scode + Inew * W;             // (from LDS: a block id fetched from HBM first would be a second dependent global round trip)
 #pragma unroll
                 for (int u = 0; u < NPEND; ++u) {
@@ -2582,7 +2593,8 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
                     pend[u] = 0.0;
                     if (t < rowsz) { const int d = t / 36, q = t - 36 * d, b = code[d]; if (b >= 0) pend[u] = g.S[36 * (size_t)b + 6 * (q % 6) + q / 6]; }
                 }
-                pend_row = kp;
+                pend_row = enter_row;
+                if (++enter_row == RR) enter_row = 0;
             }
             syrk_rest(k - 1, kp);
 #ifdef VISFS_BA_STAMPS
@@ -3573,6 +3585,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.pcg_cu = g.pcg_cu;
     d.band = g.band_B >= 0 ? 1 : 0;                    // direct solver: every window of a launch on the banded factorisation (k_band_chol)
     d.band_lds = g.band_B >= 0 ? g.band_lds_bytes : 0;
+    d.ceres = g.ceres;
     return d;
 }
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
@@ -3584,6 +3597,7 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.pcg_one_wave = a.pcg_one_wave & b.pcg_one_wave;
     d.pcg_cu = a.pcg_cu & b.pcg_cu;
     d.band = a.band & b.band; d.band_lds = std::max(a.band_lds, b.band_lds);
+    d.ceres = a.ceres & b.ceres;                       // (a handle has one framework: all windows of a launch agree)
     return d;
 }
 // dynamic LDS of the kernels that stage every pose of the window as R|t (12 doubles each); windows beyond MAX_STAGED_POSES use the
@@ -3650,9 +3664,9 @@ static void launch_ceres_lin_finalize_src(const Src& src, int B, hipStream_t s) 
 template <class Src>
 static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     if (d.sch_wgs <= 0) return;
-    if (LinSel<Src>::two_sets && graph_of_host(src).ceres) {               // Optimizer/Framework=1: single windows only
-        if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, One, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, One{ graph_of_host(src) });
-        else TIMED_LAUNCH((k_schur_partial<false, One, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, One{ graph_of_host(src) });
+    if (d.ceres) {                                                         // Optimizer/Framework=1: the damping is per variable (damp_of)
+        if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
+        else TIMED_LAUNCH((k_schur_partial<false, Src, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
         return;
     }
     if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
@@ -3777,7 +3791,8 @@ void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int m
 void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, hipStream_t s) {
     const Many src{ gs };
     launch_linearize_src(src, d, B, 0, s);             // batched windows keep the gated unit (LinSel<Many>: set 0 only)
-    if (first) launch_lin_finalize_src(src, 0, B, s);
+    if (d.ceres) launch_ceres_lin_finalize_src(src, B, s);   // Optimizer/Framework=1: cost, gradient test, Jacobi scaling after EVERY linearisation
+    else if (first) launch_lin_finalize_src(src, 0, B, s);
     launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
     else if (solver != 2) {
