@@ -285,6 +285,16 @@ int visfs_ba_hook_lm_script(int32_t gauss_newton, int32_t n_iter, double chi0, d
 int visfs_ba_hook_ceres_script(int32_t max_iter, double cost0, double x_norm0, double grad_max0, int32_t n, const int32_t* ok,
                                const double* model_cost_change, const double* cand_cost, const double* step_norm,
                                const double* grad_max, const double* x_norm, visfs_ba_stats* stats);
+/* The same with the DOGLEG strategy (Optimizer/TrustRegion=1; [ceres-upstream] DoglegStrategy's radius and mu rules): iteration t's step
+ * had the scaled length dogleg_step_norm[t]; mu_trace[i] (VISFS_BA_MAX_TRACE doubles) = the regularisation mu after iteration i. */
+int visfs_ba_hook_dogleg_script(int32_t max_iter, double cost0, double x_norm0, double grad_max0, int32_t n, const int32_t* ok,
+                                const double* model_cost_change, const double* cand_cost, const double* step_norm,
+                                const double* dogleg_step_norm, const double* grad_max, const double* x_norm, visfs_ba_stats* stats,
+                                double* mu_trace);
+/* Host-only hook: the point on the dogleg path (the function k_dogleg_mid calls, compiled for the host) from the inner products of the
+ * scaled space: s1 = ||g_s||^2, s2 = ||gn_s||^2, s3 = g_s . gn_s, jv2 = ||J (g / m)||^2.  out = { A, B, step norm, model cost change }:
+ * the step is A (g / m) + B dn in the unscaled variables. */
+int visfs_ba_hook_dogleg_combine(double s1, double s2, double s3, double jv2, double radius, double mu, double out[4]);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------ */
 /* Sizes of the resident graph and of the index structures built at upload. */

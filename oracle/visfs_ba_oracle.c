@@ -11,6 +11,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -1253,9 +1254,14 @@ int oracle_sys_mark_outliers(oracle_sys* s) {
 typedef struct {
     double radius, decrease_factor, cost, x_norm;
     int iter, invalid, done, reason;    /* reason: 1 max iterations, 2 gradient, 3 parameter, 4 function tolerance, 5 min radius, 6 invalid steps */
+    /* DoglegStrategy (Optimizer/TrustRegion=1 under Framework=1): the multiplier of the Gauss-Newton regularisation and the norm of the
+     * last dogleg step in the scaled space */
+    int dogleg;
+    double mu, dogleg_step_norm;
 } ceres_tr;
 static void ceres_tr_init(ceres_tr* t, double cost, double x_norm) {
     t->radius = 1e4; t->decrease_factor = 2.0; t->cost = cost; t->x_norm = x_norm; t->iter = 0; t->invalid = 0; t->done = 0; t->reason = 0;
+    t->dogleg = 0; t->mu = 1e-8; t->dogleg_step_norm = 0.0;          /* kMinMu */
 }
 /* One pass of the minimizer loop after the linear solve: solve_ok = the strategy produced a finite step; model_cost_change =
  * -(J step)^T (f + J step / 2); cand_cost = cost at x (+) step (only read when the step is valid); step_norm = ||x - candidate||.
@@ -1263,6 +1269,7 @@ static void ceres_tr_init(ceres_tr* t, double cost, double x_norm) {
 static int ceres_tr_step(ceres_tr* t, int solve_ok, double model_cost_change, double cand_cost, double step_norm) {
     if (!solve_ok || !(model_cost_change > 0.0)) {                       /* step_is_valid = model_cost_change > 0 */
         if (++t->invalid >= 5) { t->done = 1; t->reason = 6; }            /* HandleInvalidStep */
+        else if (t->dogleg) t->mu *= 10.0;                                /* DoglegStrategy::StepIsInvalid: mu *= mu_increase_factor (reuse = false) */
         else t->radius *= 0.5;                                            /* LevenbergMarquardtStrategy::StepIsInvalid */
         return 0;
     }
@@ -1274,11 +1281,19 @@ static int ceres_tr_step(ceres_tr* t, int solve_ok, double model_cost_change, do
     const double rho = cost_change / model_cost_change;                  /* StepQuality, monotonic */
     if (rho > 1e-3) {
         t->cost = cand_cost;
+        if (t->dogleg) {
+            /* [ceres-upstream] DoglegStrategy::StepAccepted (dogleg_strategy.cc): decrease_threshold 0.25, increase_threshold 0.75 */
+            if (rho < 0.25) t->radius *= 0.5;
+            if (rho > 0.75) t->radius = fmax(t->radius, 3.0 * t->dogleg_step_norm);
+            t->mu = fmax(1e-8, 2.0 * t->mu / 10.0);                       /* back towards a pure Gauss-Newton solve */
+            return 1;
+        }
         t->radius = t->radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));               /* StepAccepted */
         t->radius = fmin(1e16, t->radius);
         t->decrease_factor = 2.0;
         return 1;
     }
+    if (t->dogleg) { t->radius *= 0.5; return 0; }                        /* DoglegStrategy::StepRejected (reuse = true: the same Gauss-Newton step, a new interpolant) */
     t->radius = t->radius / t->decrease_factor;                          /* StepRejected */
     t->decrease_factor *= 2.0;
     return 0;
@@ -1342,9 +1357,115 @@ static int step_is_finite(const oracle_sys* s) {
 /* ceres::Solve(options, &problem, &summary) of Optimizer.cpp:504-527 + the outlier loop :529-540.  Every linear_solver_type the
  * branch can select (DENSE_SCHUR / DENSE_NORMAL_CHOLESKY / DENSE_QR) solves the same damped normal equations exactly: restated as
  * Schur elimination + dense Cholesky.  options.max_solver_time_in_seconds = 0.06 is NOT restated (the result would depend on the
- * machine); DOGLEG (Optimizer/TrustRegion=1) is not restated: VISFS_BA_ERR_UNSUPPORTED. */
+ * machine).  DOGLEG (Optimizer/TrustRegion=1): ceres_dogleg_step above. */
+/* [ceres-upstream] DoglegStrategy::ComputeStep, TRADITIONAL_DOGLEG (dogleg_strategy.cc of Ceres 2.0 / 2.1), in the unscaled variables.
+ * Ceres works on the Jacobi-scaled Jacobian J' = J S and in the elliptical norm ||D y|| with D = sqrt(clamp(diag(J'^T J'), 1e-6, 1e32)):
+ * with m_i = D_i^2 / S_i^2 (ceres_multipliers) the scaled gradient is g_i / sqrt(m_i), the Gauss-Newton step solves (H + mu M) dn = b
+ * (b = -g; the regularised solve of ComputeGaussNewtonStep, lm_diagonal = D sqrt(mu)) and has scaled entries sqrt(m_i) dn_i, the Cauchy
+ * point is -alpha v with v_i = g_i / m_i and alpha = ||g_s||^2 / ||J v||^2, and a scaled step A g_s + B gn_s is the step A v + B dn.
+ * Returns 0 when the linear solver failed; fills s->dxp / s->dxl with the dogleg step, *mcc with the model cost change
+ * -(J step)^T (f + J step / 2) = -(g . step + step^T H step / 2) and t->dogleg_step_norm. */
+/* [ceres-upstream] DoglegStrategy::ComputeTraditionalDoglegStep (dogleg_strategy.cc) on the inner products of the scaled space:
+ * S1 = ||g_s||^2, S2 = ||gn_s||^2, S3 = g_s . gn_s, JV2 = ||J v||^2 with v = g / m (alpha = S1 / JV2: the Cauchy point is -alpha g_s).
+ * out = { A, B, dogleg_step_norm, model_cost_change }: the scaled step is A g_s + B gn_s, i.e. A v + B dn in the unscaled variables;
+ * model_cost_change = -(g . step + step^T H step / 2) (TrustRegionMinimizer::ComputeTrustRegionStep: the model of the unregularised
+ * problem), written with v^T H v = ||J v||^2 and H dn = -g - mu M dn. */
+void oracle_dogleg_combine(double S1, double S2, double S3, double JV2, double radius, double mu, double out[4]) {
+    const double gnorm = sqrt(S1), gn_norm = sqrt(S2), alpha = S1 / JV2;
+    double A, B, norm;
+    if (gn_norm <= radius) { A = 0.0; B = 1.0; norm = gn_norm; }                     /* case 1: the Gauss-Newton step lies inside */
+    else if (gnorm * alpha >= radius) { A = -radius / gnorm; B = 0.0; norm = radius; } /* case 2: the Cauchy point lies outside */
+    else {                                                                          /* case 3: the boundary point of the segment Cauchy -> Gauss-Newton */
+        const double b_dot_a = -alpha * S3;
+        const double a_sq = pow(alpha * gnorm, 2.0);
+        const double bma_sq = a_sq - 2.0 * b_dot_a + pow(gn_norm, 2.0);
+        const double c = b_dot_a - a_sq;
+        const double d = sqrt(c * c + bma_sq * (pow(radius, 2.0) - a_sq));
+        const double beta = (c <= 0.0) ? (d - c) / bma_sq : (radius * radius - a_sq) / (d + c);
+        A = -alpha * (1.0 - beta); B = beta;
+        norm = sqrt(A * A * S1 + 2.0 * A * B * S3 + B * B * S2);
+    }
+    const double sHs = A * A * JV2 + 2.0 * A * B * (-S1 - mu * S3) + B * B * (-S3 - mu * S2);
+    out[0] = A; out[1] = B; out[2] = norm; out[3] = -(A * S1 + B * S3 + 0.5 * sHs);
+}
+static int ceres_dogleg_step(oracle_sys* s, ceres_tr* t, double* mcc) {
+    int pit = 0;
+    if (!schur_solve(s, t->mu, &pit) || !step_is_finite(s)) return 0;     /* (H + mu M) dn = b: s->dxp, s->dxl = dn */
+    const int n6 = s->n6, Nl = s->Nl;
+    /* ||g_s||^2, ||gn_s||^2, g_s . gn_s */
+    double S1 = 0.0, S2 = 0.0, S3 = 0.0;
+    for (int i = 0; i < n6; ++i) { const double g = -s->bp[i]; S1 += g * g / s->mp[i]; S2 += s->mp[i] * s->dxp[i] * s->dxp[i]; S3 += g * s->dxp[i]; }
+    for (int l = 0; l < Nl; ++l) {
+        if (s->pt_fixed[l] || !landmark_has_active_edge(s, l)) continue;
+        for (int c = 0; c < 3; ++c) { const double g = -s->bl[3 * l + c], m = s->ml[3 * l + c], d = s->dxl[3 * l + c]; S1 += g * g / m; S2 += m * d * d; S3 += g * d; }
+    }
+    /* ||J v||^2 over the (robustified) residual blocks: v = g / m on the free variables */
+    double JV2 = 0.0;
+    const double delta = s->prm.robust_kernel_delta;
+    for (int k = 0; k < s->No; ++k) {
+        if (!edge_active(s, k)) continue;
+        const int ip = s->obs_pose[k], l = s->obs_pt[k];
+        double e[3], Ji[9], Jj[18];
+        oracle_stereo_edge(s->pose + 7 * ip, s->pt + 3 * l, s->obs_uvr + 3 * k, s->intr, e, Ji, Jj);
+        double rho[2]; ceres_huber(s->chi2[k], delta, rho);
+        double r[3] = { 0.0, 0.0, 0.0 };
+        if (!s->pt_fixed[l]) for (int q = 0; q < 3; ++q) for (int c = 0; c < 3; ++c) r[q] += Ji[3 * q + c] * (-s->bl[3 * l + c] / s->ml[3 * l + c]);
+        const int a = s->pose_idx[ip];
+        if (a >= 0) for (int q = 0; q < 3; ++q) for (int c = 0; c < 6; ++c) r[q] += Jj[6 * q + c] * (-s->bp[6 * a + c] / s->mp[6 * a + c]);
+        JV2 += rho[1] * s->w_px * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    }
+    if (s->Nz > 0 && s->pose_idx[s->laser_pose] >= 0) {
+        const int a = s->pose_idx[s->laser_pose];
+        for (int k = 0; k < s->Nz; ++k) {
+            double e, J[6], r = 0.0;
+            laser_edge_impl(s->pose + 7 * s->laser_pose, s->Tcr, s->laser_xyz + 3 * k, &s->grid, &e, J, s->ceres);
+            for (int c = 0; c < 6; ++c) r += J[c] * (-s->bp[6 * a + c] / s->mp[6 * a + c]);
+            JV2 += s->w_laser * r * r;
+        }
+    }
+    double out[4];
+    oracle_dogleg_combine(S1, S2, S3, JV2, t->radius, t->mu, out);
+    const double A = out[0], B = out[1];
+    t->dogleg_step_norm = out[2];
+    *mcc = out[3];
+    if (getenv("VISFS_ORACLE_TRACE")) fprintf(stderr, "[oracle dogleg] it %d radius %.6g mu %.3g |gn| %.6g |cauchy| %.6g -> A %.6g B %.6g mcc %.6g\n", t->iter, t->radius, t->mu, sqrt(S2), sqrt(S1) * S1 / JV2, A, B, *mcc);
+    for (int i = 0; i < n6; ++i) s->dxp[i] = A * (-s->bp[i] / s->mp[i]) + B * s->dxp[i];
+    for (int l = 0; l < Nl; ++l) {
+        if (s->pt_fixed[l] || !landmark_has_active_edge(s, l)) { s->dxl[3 * l] = s->dxl[3 * l + 1] = s->dxl[3 * l + 2] = 0.0; continue; }
+        for (int c = 0; c < 3; ++c) s->dxl[3 * l + c] = A * (-s->bl[3 * l + c] / s->ml[3 * l + c]) + B * s->dxl[3 * l + c];
+    }
+    return isfinite(*mcc) && step_is_finite(s);
+}
+
+/* [ceres-upstream] TrustRegionMinimizer::IterationZero with jacobi_scaling: column scale 1 / (1 + sqrt(diag(J^T J))), kept for the whole solve */
+static void ceres_estimate_scale(oracle_sys* s) {
+    for (int i = 0; i < s->n6; ++i) { const double q = 1.0 / (1.0 + sqrt(s->Hpp[(size_t)i * s->n6 + i])); s->s2p[i] = q * q; }
+    for (int l = 0; l < s->Nl; ++l) { static const int dq[3] = { 0, 3, 5 }; for (int c = 0; c < 3; ++c) { const double q = 1.0 / (1.0 + sqrt(s->Hll[6 * l + dq[c]])); s->s2l[3 * l + c] = q * q; } }
+}
+
+/* Stage entry for tests (Optimizer/Framework=1 systems, after oracle_sys_linearize at iteration zero): ONE dogleg step with the given
+ * radius and mu from the current linearisation — Jacobi scaling as at iteration zero, multipliers, ceres_dogleg_step, Plus.  The step is
+ * left in the DX buffers, the trial state in the TRIAL buffers; out = { model cost change, dogleg step norm, trial cost (sum rho / 2) }. */
+int oracle_sys_dogleg_trial(oracle_sys* s, double radius, double mu, double out[3]) {
+    if (!s->ceres) return 0;
+    const int saved_solver = s->prm.solver;
+    s->prm.solver = 0;
+    ceres_estimate_scale(s);
+    ceres_multipliers(s);
+    ceres_tr t;
+    ceres_tr_init(&t, 0.0, 0.0);
+    t.dogleg = 1; t.radius = radius; t.mu = mu; t.iter = 1;
+    double mcc = 0.0;
+    const int ok = ceres_dogleg_step(s, &t, &mcc);
+    s->prm.solver = saved_solver;
+    if (!ok) return 0;
+    apply_update(s);
+    out[0] = mcc; out[1] = t.dogleg_step_norm; out[2] = 0.5 * active_robust_chi2(s, s->pose_trial, s->pt_trial, 0);
+    return 1;
+}
+
 static int ceres_optimize(oracle_sys* s, visfs_ba_stats* st) {
-    if (s->prm.trust_region == 1) return VISFS_BA_ERR_UNSUPPORTED;
+    const int dogleg = s->prm.trust_region == 1;                /* Optimizer.cpp:515-519: options.trust_region_strategy_type = ceres::DOGLEG */
     const int max_it = s->prm.iterations;
     const int saved_solver = s->prm.solver;
     s->prm.solver = 0;                                         /* schur_solve: dense Cholesky on the reduced system */
@@ -1352,21 +1473,29 @@ static int ceres_optimize(oracle_sys* s, visfs_ba_stats* st) {
     oracle_sys_linearize(s, &chi, &md);                        /* IterationZero: cost = sum rho / 2, robustified Jacobian */
     st->chi2_initial = chi;
     { int n_ok = 0; for (int k = 0; k < s->No; ++k) n_ok += s->obs_edge_ok[k]; st->n_active_edges[0] = st->n_active_edges[1] = n_ok; }
-    for (int i = 0; i < s->n6; ++i) { const double q = 1.0 / (1.0 + sqrt(s->Hpp[(size_t)i * s->n6 + i])); s->s2p[i] = q * q; }   /* EstimateScale */
-    for (int l = 0; l < s->Nl; ++l) { static const int dq[3] = { 0, 3, 5 }; for (int c = 0; c < 3; ++c) { const double q = 1.0 / (1.0 + sqrt(s->Hll[6 * l + dq[c]])); s->s2l[3 * l + c] = q * q; } }
+    ceres_estimate_scale(s);
     ceres_tr t;
     ceres_tr_init(&t, 0.5 * chi, sqrt(ceres_x_norm2(s, s->pose, s->pt)));
+    t.dogleg = dogleg;
     if (max_it <= 0) { t.done = 1; t.reason = 1; }             /* the first FinalizeIteration... sees iteration 0 >= max_num_iterations */
     else if (ceres_grad_max(s) <= 1e-10) { t.done = 1; t.reason = 2; }
     while (!t.done) {
         t.iter++;
         ceres_multipliers(s);
         int pit = 0;
-        int ok = schur_solve(s, 1.0 / t.radius, &pit);
-        st->trials_run[0]++;
-        if (ok && !step_is_finite(s)) ok = 0;
         double mcc = 0.0, cand = 0.0, step_norm = 0.0;
-        if (ok) mcc = 0.5 * compute_scale(s, 1.0 / t.radius);  /* = step^T b - step^T H step / 2 with (H + D) step = b */
+        int ok;
+        st->trials_run[0]++;
+        if (dogleg) {
+            /* (a rejected step makes Ceres reuse the stored Gauss-Newton step and gradient with the halved radius — recomputing them with
+             * the same mu gives the same vectors; its inner retry loop on a failed factorisation, mu *= 10 up to 1, is folded into the
+             * invalid-step rule: one retry per iteration) */
+            ok = ceres_dogleg_step(s, &t, &mcc);
+        } else {
+            ok = schur_solve(s, 1.0 / t.radius, &pit);
+            if (ok && !step_is_finite(s)) ok = 0;
+            if (ok) mcc = 0.5 * compute_scale(s, 1.0 / t.radius);  /* = step^T b - step^T H step / 2 with (H + D) step = b */
+        }
         if (ok && mcc > 0.0) {
             apply_update(s);                                   /* Plus: t + dt, (deltaQ(dtheta) * q).normalized() (LocalParameterization.cpp:10-24) */
             cand = 0.5 * active_robust_chi2(s, s->pose_trial, s->pt_trial, 0);
@@ -1419,6 +1548,30 @@ int oracle_ceres_script(int max_iter, double cost0, double x_norm0, double grad_
         st->trials_run[0]++;
         const int accepted = ceres_tr_step(&t, ok[q], mcc[q], cand_cost[q], step_norm[q]);
         if (st->n_trace < VISFS_BA_MAX_TRACE) { st->trace_lambda[st->n_trace] = t.radius; st->trace_chi2[st->n_trace] = 2.0 * t.cost; st->n_trace++; }
+        ceres_tr_finalize(&t, max_iter, accepted, grad_max[q], x_norm[q]);
+    }
+    st->iterations_run[0] = t.iter;
+    st->chi2_final = 2.0 * t.cost;
+    return t.reason;
+}
+
+/* the same loop with DoglegStrategy's rules: iteration t's step had the scaled length dogleg_step_norm[t]; mu_trace[i] = mu after iteration i */
+int oracle_dogleg_script(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc,
+                         const double* cand_cost, const double* step_norm, const double* dogleg_step_norm, const double* grad_max, const double* x_norm,
+                         visfs_ba_stats* st, double* mu_trace) {
+    memset(st, 0, sizeof(*st));
+    ceres_tr t;
+    ceres_tr_init(&t, cost0, x_norm0);
+    t.dogleg = 1;
+    if (max_iter <= 0) { t.done = 1; t.reason = 1; }
+    else if (grad_max0 <= 1e-10) { t.done = 1; t.reason = 2; }
+    while (!t.done) {
+        const int q = t.iter < n ? t.iter : n - 1;
+        t.iter++;
+        st->trials_run[0]++;
+        t.dogleg_step_norm = dogleg_step_norm[q];
+        const int accepted = ceres_tr_step(&t, ok[q], mcc[q], cand_cost[q], step_norm[q]);
+        if (st->n_trace < VISFS_BA_MAX_TRACE) { mu_trace[st->n_trace] = t.mu; st->trace_lambda[st->n_trace] = t.radius; st->trace_chi2[st->n_trace] = 2.0 * t.cost; st->n_trace++; }
         ceres_tr_finalize(&t, max_iter, accepted, grad_max[q], x_norm[q]);
     }
     st->iterations_run[0] = t.iter;

@@ -68,6 +68,9 @@ void oracle_sys_linearize(oracle_sys* s, double* robust_chi2, double* max_diag);
 /* setLambda + Schur solve + update + computeActiveErrors at the trial state; trial is NOT committed. */
 void oracle_sys_trial(oracle_sys* s, double lambda, double* trial_chi2, double* scale,
                       int32_t* pcg_iterations, int32_t* solver_ok);
+/* Optimizer/Framework=1 systems: one DOGLEG step (radius, mu) from the current linearisation; step -> DX buffers, trial state -> TRIAL
+ * buffers, out = { model cost change, scaled step norm, trial cost }.  Returns 0 when the factorisation fails. */
+int oracle_sys_dogleg_trial(oracle_sys* s, double radius, double mu, double out[3]);
 /* Same buffer ids and layouts as visfs_ba_stage_fetch. */
 int oracle_sys_fetch(oracle_sys* s, int32_t which, double* dst, size_t n_doubles);
 /* Both phases + outlier marking (Optimizer.cpp:261-318). Returns status; seconds = wall time of that region. */
@@ -91,6 +94,12 @@ int oracle_lm_script(int gauss_newton, int n_iter, double chi0, double max_diag0
 /* Optimizer/Framework=1: [ceres-upstream] TrustRegionMinimizer + LevenbergMarquardtStrategy on scripted outcomes (see the .c file). */
 int oracle_ceres_script(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc,
                         const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, visfs_ba_stats* stats);
+/* ... with [ceres-upstream] DoglegStrategy (Optimizer/TrustRegion=1): the scaled step lengths come with the script, mu_trace goes out. */
+int oracle_dogleg_script(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc,
+                         const double* cand_cost, const double* step_norm, const double* dogleg_step_norm, const double* grad_max, const double* x_norm,
+                         visfs_ba_stats* stats, double* mu_trace);
+/* The point on the (traditional) dogleg path from the inner products of the scaled space: out = { A, B, step norm, model cost change }. */
+void oracle_dogleg_combine(double S1, double S2, double S3, double JV2, double radius, double mu, double out[4]);
 
 /* localOptimize-equivalent on host buffers (pack → optimise → write-back). */
 int oracle_solve_window(const visfs_ba_params* params, const visfs_ba_window* w, visfs_ba_result* r, int num_threads);

@@ -56,6 +56,12 @@ def load(omp=False):
     _pi = C.POINTER(C.c_int32)
     lib.oracle_ceres_script.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _pi, _pd, _pd, _pd, _pd, _pd, C.POINTER(abi.Stats)]
     lib.oracle_ceres_script.restype = C.c_int
+    lib.oracle_dogleg_script.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _pi, _pd, _pd, _pd, _pd, _pd, _pd, C.POINTER(abi.Stats), _pd]
+    lib.oracle_dogleg_script.restype = C.c_int
+    lib.oracle_dogleg_combine.argtypes = [C.c_double] * 6 + [_pd]
+    lib.oracle_dogleg_combine.restype = None
+    lib.oracle_sys_dogleg_trial.argtypes = [C.c_void_p, C.c_double, C.c_double, _pd]
+    lib.oracle_sys_dogleg_trial.restype = C.c_int
     lib.oracle_solve_window.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Window), C.POINTER(abi.Result), C.c_int]
     lib.oracle_solve_window.restype = C.c_int
     return lib
@@ -90,6 +96,11 @@ class OracleSystem:
         chi, sc, it, ok = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
         self.lib.oracle_sys_trial(self.h, lam, C.byref(chi), C.byref(sc), C.byref(it), C.byref(ok))
         return chi.value, sc.value, it.value, ok.value
+
+    def dogleg_trial(self, radius, mu):
+        out = np.zeros(3)
+        ok = self.lib.oracle_sys_dogleg_trial(self.h, radius, mu, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return ok, out[0], out[1], out[2]
 
     def commit(self):
         self.lib.oracle_sys_commit(self.h)

@@ -119,11 +119,8 @@ def test_one_pass_and_the_outlier_rule(olib):
     o.close()
 
 
-def test_dogleg_is_refused_and_the_solver_id_does_not_matter(olib):
+def test_the_solver_id_does_not_matter(olib):
     w = synth.make_window("C1")
-    o, gb, rc, st = _solve(olib, w, iterations=10, trust_region=1)
-    assert rc == abi.ERR_UNSUPPORTED
-    o.close()
     ref = None
     for solver in (0, 1, 2, 3):                                   # DENSE_SCHUR / DENSE_NORMAL_CHOLESKY / DENSE_QR / default: exact dense solves
         o, gb, rc, st = _solve(olib, w, iterations=10, solver=solver)
@@ -131,6 +128,123 @@ def test_dogleg_is_refused_and_the_solver_id_does_not_matter(olib):
         assert rc == abi.OK
         if ref is None: ref = d
         assert all(np.array_equal(x, y) for x, y in zip(d, ref))
+
+
+# ------------------------------------------------------------------ Optimizer/TrustRegion=1: the DOGLEG strategy (Optimizer.cpp:515-519)
+def _dense_system(o, gb):
+    """The full normal equations over [free poses | non-fixed landmarks] from the oracle's blocks (their assembly is checked densely,
+    edge by edge, in test_oracle_algebra.py): H, g = -b."""
+    npf = o.npf
+    n6 = 6 * npf
+    free_pt = [l for l in range(gb.n_points) if not gb.point_fixed[l]]
+    col = {l: n6 + 3 * a for a, l in enumerate(free_pt)}
+    n = n6 + 3 * len(free_pt)
+    H = np.zeros((n, n)); b = np.zeros(n)
+    H[:n6, :n6] = o.fetch(abi.BUF_HPP).reshape(n6, n6); b[:n6] = o.fetch(abi.BUF_BP)
+    Hll = o.fetch(abi.BUF_HLL).reshape(-1, 6); bl = o.fetch(abi.BUF_BL).reshape(-1, 3)
+    for l in free_pt:
+        c = col[l]
+        h = Hll[l]
+        H[c:c + 3, c:c + 3] = [[h[0], h[1], h[2]], [h[1], h[3], h[4]], [h[2], h[4], h[5]]]
+        b[c:c + 3] = bl[l]
+    W = o.fetch(abi.BUF_HPL).reshape(-1, 6, 3)
+    pose_free = np.cumsum(1 - np.asarray(gb.pose_fixed)) - 1
+    for k in range(gb.n_obs):
+        i, l = int(gb.obs_pose[k]), int(gb.obs_point[k])
+        if gb.pose_fixed[i] or gb.point_fixed[l] or not W[k].any():
+            continue
+        a = 6 * int(pose_free[i])
+        H[a:a + 6, col[l]:col[l] + 3] += W[k]; H[col[l]:col[l] + 3, a:a + 6] += W[k].T
+    return H, -b, free_pt, col
+
+
+@pytest.mark.parametrize("cfg", ["C1", "HARD", "LASER"])
+def test_one_dogleg_step_against_dense_numpy(olib, cfg):
+    """ceres_dogleg_step — the regularised Gauss-Newton solve through the Schur complement, the inner products, ||J v||^2 edge by edge, the
+    point on the path, the model cost change — against the textbook construction on the dense system: scaled variables y = sqrt(M) x,
+    Cauchy point -(|g_s|^2 / g_s^T H_s g_s) g_s, Gauss-Newton point, the first point of the path Cauchy -> Gauss-Newton on the boundary
+    (the root of a quadratic, numpy.roots), and -(g . step + step^T H step / 2)."""
+    w = {"C1": lambda: synth.make_window("C1"), "HARD": hard_window, "LASER": lambda: synth.make_laser_window(with_visual=True, n_points=300)}[cfg]()
+    prm = abi.default_params(framework=1, trust_region=1, iterations=10)
+    wb, gb, *_ = graph_of(olib.oracle_pack_window, prm, w)
+    o = oracle_lib.OracleSystem(olib, prm, gb)
+    chi0, _ = o.linearize()
+    H, g, free_pt, col = _dense_system(o, gb)
+    n6 = 6 * o.npf
+    d = np.diag(H)
+    s2 = 1.0 / (1.0 + np.sqrt(d)) ** 2                          # Jacobi scaling of iteration zero
+    M = np.clip(d * s2, 1e-6, 1e32) / s2                        # DoglegStrategy's diagonal in the unscaled variables
+    sq = np.sqrt(M)
+    Hs = H / np.outer(sq, sq); gs = g / sq                      # the problem in the scaled variables
+    seen = set()
+    pose0 = np.asarray(gb.pose_tq).reshape(-1, 7); pt0 = np.asarray(gb.point_xyz).reshape(-1, 3)
+    for mu in (1e-8, 1e-3):
+        gn = -np.linalg.solve(Hs + mu * np.eye(len(g)), gs)
+        cauchy = -(gs @ gs) / (gs @ Hs @ gs) * gs
+        for which, radius in ((1, 2.0 * np.linalg.norm(gn)), (2, 0.5 * np.linalg.norm(cauchy)), (3, 0.5 * (np.linalg.norm(cauchy) + np.linalg.norm(gn)))):
+            assert np.linalg.norm(cauchy) < np.linalg.norm(gn)
+            if which == 1:
+                ys = gn
+            elif which == 2:
+                ys = -radius * gs / np.linalg.norm(gs)
+            else:
+                dv = gn - cauchy                                # |cauchy + beta dv|^2 = radius^2, the root in [0, 1]
+                roots = np.roots([dv @ dv, 2.0 * cauchy @ dv, cauchy @ cauchy - radius * radius])
+                beta = [r.real for r in roots if abs(r.imag) < 1e-12 and 0.0 <= r.real <= 1.0]
+                assert len(beta) == 1
+                ys = cauchy + beta[0] * dv
+            step = ys / sq
+            ok, mcc, norm, cost_t = o.dogleg_trial(float(radius), mu)
+            assert ok
+            seen.add(which)
+            dxp = o.fetch(abi.BUF_DX_POSE); dxl = o.fetch(abi.BUF_DX_POINT).reshape(-1, 3)
+            ref = np.abs(step).max()
+            assert np.abs(dxp - step[:n6]).max() <= 1e-7 * ref, (cfg, mu, which)
+            for l in free_pt:
+                assert np.abs(dxl[l] - step[col[l]:col[l] + 3]).max() <= 1e-7 * ref, (cfg, mu, which, l)
+            assert np.isclose(norm, np.linalg.norm(ys), rtol=1e-8)
+            want = -(g @ step + 0.5 * step @ H @ step)
+            assert want > 0 and np.isclose(mcc, want, rtol=1e-7), (cfg, mu, which, mcc, want)
+            # the trial state and its cost (visual windows: the numpy cost of _cost)
+            pose_t = o.fetch(abi.BUF_POSE_TRIAL).reshape(-1, 7); pt_t = o.fetch(abi.BUF_POINT_TRIAL).reshape(-1, 3)
+            for l in free_pt:
+                assert np.allclose(pt_t[l], pt0[l] + dxl[l], rtol=0, atol=1e-12 * max(1.0, np.abs(pt0[l]).max()))
+            if cfg != "LASER":
+                assert abs(cost_t - _cost(olib, gb, pose_t, pt_t)) <= 1e-9 * max(cost_t, 1.0)
+            # inside the region the model is trusted: the step of case 1 at mu ~ 0 is the plain Gauss-Newton step
+            if which == 1 and mu == 1e-8:
+                assert cost_t < 0.5 * chi0
+    assert seen == {1, 2, 3}
+    o.close()
+
+
+@pytest.mark.parametrize("cfg", ["C1", "PROD"])
+def test_dogleg_descends_monotonically_to_the_stationary_point_levenberg_marquardt_finds(olib, cfg):
+    w = synth.make_window(cfg)
+    o, gb, rc, st = _solve(olib, w, iterations=50, trust_region=1)
+    assert rc == abi.OK
+    cost2 = np.array([st.trace_chi2[i] for i in range(st.n_trace)])
+    assert (np.diff(cost2) <= 0).all() and st.chi2_final < 0.2 * st.chi2_initial
+    po, pto, outo, chio = o.download()
+    assert abs(0.5 * st.chi2_final - _cost(olib, gb, po, pto)) <= 1e-9 * st.chi2_final
+    o2, gb2, rc2, st2 = _solve(olib, w, iterations=50, trust_region=0)
+    assert abs(st.chi2_final - st2.chi2_final) <= 1e-5 * st2.chi2_final
+    assert np.array_equal(outo, o2.download()[2])                                   # the same outlier set at the end
+    o.close(); o2.close()
+
+
+def test_dogleg_rejected_steps_on_the_hard_window(olib):
+    """No fixed landmarks, a bad start: steps get rejected (the radius halves, the cost stays), later steps lie on the segment between
+    the Cauchy and the Gauss-Newton point."""
+    o, gb, rc, st = _solve(olib, hard_window(), iterations=40, trust_region=1)
+    assert rc == abi.OK and st.iterations_run[0] >= 20
+    radius = np.array([st.trace_lambda[i] for i in range(st.n_trace)]); cost2 = np.array([st.trace_chi2[i] for i in range(st.n_trace)])
+    rejected = np.flatnonzero(np.diff(cost2) == 0) + 1
+    rejected = rejected[rejected < st.n_trace - 1]                   # (the last iteration ends on the function tolerance: its step is not taken, the radius stays)
+    assert len(rejected) >= 3 and (np.diff(cost2) <= 0).all()
+    assert all(radius[i] == 0.5 * radius[i - 1] for i in rejected)
+    assert radius[0] > 1e4                                            # the first step (rho > 0.75) grew it from the initial 1e4 to 3 x the step
+    o.close()
 
 
 def test_window_level_write_back(olib):

@@ -120,19 +120,20 @@ def test_shim_laser_factor_matches_the_c_abi(driver, tmp_path):
 @pytest.mark.gpu
 def test_shim_error_convention(driver, tmp_path):
     w = synth.make_window("PROD")
-    # the Ceres branch's DOGLEG strategy is not implemented: an empty map comes back
+    # an Optimizer/Framework the reference does not know: an empty map comes back
     dump_window(tmp_path / "in.bin", w)
-    subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Framework=1", "Optimizer/TrustRegion=1"], check=True, capture_output=True)
+    subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Framework=2"], check=True, capture_output=True)
     status, poses, pts, outl = read_result(tmp_path / "out.bin")
     assert status == abi.ERR_UNSUPPORTED and poses == {}
-    # ... its LEVENBERG_MARQUARDT strategy is: same poses as the C ABI's
-    subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Framework=1"], check=True, capture_output=True)
-    status, poses, pts, outl = read_result(tmp_path / "out.bin")
+    # the Ceres branch, both trust-region strategies: same poses as the C ABI's
     from visfs_amd import backend
-    s = backend.Solver(abi.default_params(framework=1))
-    rc, rb = s.solve_window(abi.WindowBuffers(w))
-    s.close()
-    assert status == rc == abi.OK and np.array_equal(np.array([poses[k] for k in sorted(poses)]), rb.pose_Twr_out[:len(poses)])
+    for tr in (0, 1):
+        subprocess.run([driver, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "Optimizer/Framework=1", "Optimizer/TrustRegion=%d" % tr], check=True, capture_output=True)
+        status, poses, pts, outl = read_result(tmp_path / "out.bin")
+        s = backend.Solver(abi.default_params(framework=1, trust_region=tr))
+        rc, rb = s.solve_window(abi.WindowBuffers(w))
+        s.close()
+        assert status == rc == abi.OK and np.array_equal(np.array([poses[k] for k in sorted(poses)]), rb.pose_Twr_out[:len(poses)])
     # single pose → input poses come back
     w1 = dict(w); w1["pose_ids"] = w["pose_ids"][:1]; w1["pose_Twr"] = w["pose_Twr"][:1]
     dump_window(tmp_path / "in.bin", w1)

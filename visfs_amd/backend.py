@@ -24,7 +24,7 @@ EXPORTS = [
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
     "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
-    "visfs_ba_create_error", "visfs_ba_hook_lm_script", "visfs_ba_hook_ceres_script", "visfs_ba_solve_batch_sharded", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
+    "visfs_ba_create_error", "visfs_ba_hook_lm_script", "visfs_ba_hook_ceres_script", "visfs_ba_hook_dogleg_script", "visfs_ba_hook_dogleg_combine", "visfs_ba_solve_batch_sharded", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
 ]
 
 _lib = None
@@ -93,6 +93,10 @@ def load_library():
     lib.visfs_ba_hook_lm_script.restype = C.c_int
     _pi = C.POINTER(C.c_int32)
     lib.visfs_ba_hook_ceres_script.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd, C.POINTER(abi.Stats)]
+    lib.visfs_ba_hook_dogleg_script.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd, _pd, C.POINTER(abi.Stats), _pd]
+    lib.visfs_ba_hook_dogleg_script.restype = C.c_int
+    lib.visfs_ba_hook_dogleg_combine.argtypes = [C.c_double] * 6 + [_pd]
+    lib.visfs_ba_hook_dogleg_combine.restype = C.c_int
     lib.visfs_ba_hook_ceres_script.restype = C.c_int
     if lib.visfs_ba_abi_version() != abi.ABI_VERSION:
         raise BackendError("ABI version mismatch between visfs_amd/abi.py and libvisfs_ba_hip.so")

@@ -701,6 +701,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.trial_gran = A.take<unsigned long long>((size_t)n_parts * 4);
         g.aux_part = A.take<double>((size_t)n_parts);
+        g.dl_part = A.take<double>(ceres && prm.trust_region == 1 ? (size_t)n_parts * 4 : 1);
         g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.s2p = A.take<double>(std::max<size_t>(n6, 1));
         const bool dense_chol = prm.solver != 2 && band_B < 0;
@@ -775,6 +776,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     dg.inv_pixel_var = 1.0 / prm.pixel_variance;          // Optimizer.cpp:153
     dg.inv_pixel_var_out = dg.inv_pixel_var;
     dg.ceres = ceres ? 1 : 0;
+    dg.dogleg = (ceres && prm.trust_region == 1) ? 1 : 0;   // Optimizer.cpp:515-519: options.trust_region_strategy_type = ceres::DOGLEG
     dg.inv_odo_cov = 1.0 / prm.odometry_covariance;       // Optimizer.cpp:117-121
     dg.huber_delta = prm.robust_kernel_delta;             // Optimizer.cpp:212-216
     dg.Nz = Nz; dg.laser_pose = Nz ? gr->laser_pose : 0;
@@ -866,6 +868,13 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
         { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
         if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
+    }
+    if (w.g.dogleg) {
+        // the solve above was the regularised Gauss-Newton step (H + mu M) dn = b.  Pass 1 keeps its landmark part and sums the inner
+        // products of the dogleg construction, the one-workgroup kernel picks the point on the dogleg path, pass 2 evaluates it.
+        { ProfScope p(w, VISFS_BA_K_BACKSUB, true); launch_backsub_dogleg(w.g, 1, w.stream); launch_dogleg_mid(w.g, w.stream); launch_backsub_dogleg(w.g, 2, w.stream); }
+        { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
+        return;
     }
     const bool fused_decide = w.fused_decide;     // the gated unit: the LM decision rides on k_backsub
     {   ProfScope p(w, VISFS_BA_K_BACKSUB, true);
@@ -1275,13 +1284,11 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
     return VISFS_BA_OK;
 }
 
-// Optimizer/Framework (Parameters.h:184): 0 = the g2o branch, 1 = the Ceres branch with its LEVENBERG_MARQUARDT strategy; the DOGLEG
-// strategy (Optimizer/TrustRegion=1 under Framework=1, Optimizer.cpp:515-519) is not implemented.
+// Optimizer/Framework (Parameters.h:184): 0 = the g2o branch, 1 = the Ceres branch — LEVENBERG_MARQUARDT, or with Optimizer/TrustRegion=1
+// the (traditional) DOGLEG strategy (Optimizer.cpp:515-519).
 static const char* framework_refusal(const visfs_ba_params& prm) {
-    if (prm.framework == 0) return nullptr;
-    if (prm.framework != 1) return "Optimizer/Framework must be 0 (g2o branch) or 1 (Ceres branch)";
-    if (prm.trust_region == 1) return "Optimizer/Framework=1 with Optimizer/TrustRegion=1 (Ceres DOGLEG) is not implemented";
-    return nullptr;
+    if (prm.framework == 0 || prm.framework == 1) return nullptr;
+    return "Optimizer/Framework must be 0 (g2o branch) or 1 (Ceres branch)";
 }
 
 // localOptimize in three steps so that a batch can run the middle one for many windows at once.
@@ -1758,7 +1765,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             const Workspace& ws = *h->batch[i];
             // (the direct solver shares launches when the window's S is banded: k_band_chol, one workgroup per window)
             const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
-            const bool batchable = batching && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
+            const bool batchable = batching && !ws.g.dogleg && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
@@ -1856,6 +1863,7 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
             const Workspace& ws = *h->batch[i];
             const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
             if (!(h->prm.solver == 2 || ws.small_solve || ws.fused || band)) { h->err = "batched launches need Optimizer/Solver=2, a banded reduced system (direct solver) or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
+            if (ws.g.dogleg) { h->err = "Optimizer/Framework=1 with Optimizer/TrustRegion=1 (DOGLEG) has no batched launches: solve the windows one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
@@ -2136,6 +2144,22 @@ int visfs_ba_hook_ceres_script(int32_t max_iter, double cost0, double x_norm0, d
     const int reason = ceres_script_host(max_iter, cost0, x_norm0, grad_max0, n, ok, model_cost_change, cand_cost, step_norm, grad_max, x_norm, &st);
     fill_stats(st, stats);
     return reason;
+}
+
+int visfs_ba_hook_dogleg_script(int32_t max_iter, double cost0, double x_norm0, double grad_max0, int32_t n, const int32_t* ok, const double* model_cost_change,
+                                const double* cand_cost, const double* step_norm, const double* dogleg_step_norm, const double* grad_max, const double* x_norm,
+                                visfs_ba_stats* stats, double* mu_trace) {
+    if (!ok || !model_cost_change || !cand_cost || !step_norm || !dogleg_step_norm || !grad_max || !x_norm || !stats || !mu_trace || n < 1) return VISFS_BA_ERR_BAD_ARGUMENT;
+    LmState st;
+    const int reason = ceres_script_host(max_iter, cost0, x_norm0, grad_max0, n, ok, model_cost_change, cand_cost, step_norm, grad_max, x_norm, &st, dogleg_step_norm, mu_trace);
+    fill_stats(st, stats);
+    return reason;
+}
+
+int visfs_ba_hook_dogleg_combine(double s1, double s2, double s3, double jv2, double radius, double mu, double out[4]) {
+    if (!out) return VISFS_BA_ERR_BAD_ARGUMENT;
+    dogleg_combine(s1, s2, s3, jv2, radius, mu, out[0], out[1], out[2], out[3]);
+    return VISFS_BA_OK;
 }
 
 int visfs_ba_stage_fetch(visfs_ba_handle* h, int32_t which, double* dst, size_t n_doubles) {

@@ -81,6 +81,10 @@ struct LmState {
     double tr_radius, tr_x_norm;
     int32_t tr_invalid;     // consecutive invalid steps
     int32_t tr_reason;      // why the minimizer stopped: 1 max iterations, 2 gradient, 3 parameter, 4 function tolerance, 5 min radius, 6 invalid steps
+    // Optimizer/Framework=1 with Optimizer/TrustRegion=1 ([ceres-upstream] DoglegStrategy, TRADITIONAL_DOGLEG): lambda = dl_mu, the multiplier of
+    // the Gauss-Newton regularisation; the step of this unit is dl_A * v + dl_B * dn (v = g / m, dn = the regularised Gauss-Newton step)
+    double dl_mu, dl_A, dl_B, dl_step_norm, dl_mcc;
+    int32_t dogleg;
     uint32_t decide_epoch;  // tag of the last k_backsub launch that carried the LM decision; never reset (k_reset leaves it): stale
                             // hand-off words of an earlier launch or solve can then never match the tag a launch waits for
 };
@@ -126,6 +130,7 @@ struct DeviceGraph {
     // Optimizer/Framework=1 (Ceres branch, Optimizer.cpp:366-593): the residual is info * e with info = I / var, so the objective carries
     // 1 / var^2 (inv_pixel_var, inv_laser_cov hold the squares then) while the outlier test of :529-540 keeps e . (info e)
     int32_t ceres;
+    int32_t dogleg;         // ... with its DOGLEG trust-region strategy (Optimizer/TrustRegion=1, Optimizer.cpp:515-519)
     double inv_pixel_var_out;
     // laser occupied-space edges (Optimizer.cpp:224-258): Nz unary edges on pose `laser_pose`; aggregated into slot Ne of odo_blk
     int32_t Nz, laser_pose;
@@ -209,6 +214,7 @@ struct DeviceGraph {
     double* aux_part;           // [n_lin_a + 1] per-workgroup partials of the Ceres flavour: ||x||^2 shares (k_linearize), ||step||^2 shares (k_backsub)
     double* s2l;                // [Nl][3]
     double* s2p;                // [Npf][6]
+    double* dl_part;            // [n_lin_a + 1][4] dogleg pass A per workgroup: ||J v||^2, ||g_s||^2, ||gn_s||^2, g_s . gn_s shares
     unsigned long long* trial_gran; // [n_lin_a + 1][4] the same two sums as {epoch:32 | half:32} hand-off words (k_backsub with the LM decision on board)
     double* chol_f;             // [chol_np][chol_np] the Cholesky factor L (direct solver), separate from the matrix being updated
     double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)

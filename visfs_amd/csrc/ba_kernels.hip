@@ -494,6 +494,7 @@ __host__ __device__ __forceinline__ void ceres_decide(LmState* st, const bool so
     if (!solve_ok || !(mcc > 0.0)) {                                       // step_is_valid = model_cost_change > 0
         st->tr_invalid += 1;
         if (st->tr_invalid >= 5) { stop = true; st->tr_reason = 6; }         // max_num_consecutive_invalid_steps
+        else if (st->dogleg) st->dl_mu *= 10.0;                             // DoglegStrategy::StepIsInvalid: mu *= mu_increase_factor
         else st->tr_radius *= 0.5;                                          // LevenbergMarquardtStrategy::StepIsInvalid
     } else {
         st->tr_invalid = 0;
@@ -509,16 +510,25 @@ __host__ __device__ __forceinline__ void ceres_decide(LmState* st, const bool so
                 accepted = true;
                 st->current_chi = 2.0 * cand;
                 st->sel ^= 1;                                               // the candidate becomes x
-                st->tr_radius = st->tr_radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
-                st->tr_radius = fmin(1e16, st->tr_radius);
-                st->ni = 2.0;
+                if (st->dogleg) {
+                    // [ceres-upstream] DoglegStrategy::StepAccepted: decrease_threshold 0.25, increase_threshold 0.75
+                    if (rho < 0.25) st->tr_radius *= 0.5;
+                    if (rho > 0.75) st->tr_radius = fmax(st->tr_radius, 3.0 * st->dl_step_norm);
+                    st->dl_mu = fmax(1e-8, 2.0 * st->dl_mu / 10.0);        // back towards a pure Gauss-Newton solve
+                } else {
+                    st->tr_radius = st->tr_radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
+                    st->tr_radius = fmin(1e16, st->tr_radius);
+                    st->ni = 2.0;
+                }
+            } else if (st->dogleg) {
+                st->tr_radius *= 0.5;                                       // DoglegStrategy::StepRejected (Ceres then reuses the Gauss-Newton step: same vectors)
             } else {
                 st->tr_radius = st->tr_radius / st->ni;
                 st->ni *= 2.0;
             }
         }
     }
-    st->lambda = 1.0 / st->tr_radius;
+    st->lambda = st->dogleg ? st->dl_mu : 1.0 / st->tr_radius;         // what the next unit's solve is damped with
     if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = st->tr_radius; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
     // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test of an accepted step follows its linearisation: k_ceres_lin_finalize)
     if (!stop && st->phase_iter >= st->max_iter) { stop = true; st->tr_reason = 1; }
@@ -534,7 +544,8 @@ __host__ __device__ __forceinline__ void ceres_lin_update(LmState* st, const dou
     if (st->phase_iter == 0) {
         st->chi2_initial = chi_total;
         st->tr_radius = 1e4; st->ni = 2.0; st->tr_invalid = 0; st->tr_reason = 0;     // initial_trust_region_radius
-        st->lambda = 1.0 / st->tr_radius;
+        st->dl_mu = 1e-8;                                                              // DoglegStrategy: kMinMu
+        st->lambda = st->dogleg ? st->dl_mu : 1.0 / st->tr_radius;
     }
     if (grad_max <= 1e-10) { st->done = 1; st->mode = 0; st->tr_reason = 2; }          // GradientToleranceReached
 }
@@ -578,7 +589,7 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
     }
     chi = block_sum_256(chi, red);
     sc = block_sum_256(sc, red);
-    if (g.ceres) { ceres_decide_role(g, st, ok, chi, sc, red); return; }
+    if (g.ceres) { ceres_decide_role(g, st, ok, chi, g.dogleg ? 2.0 * st->dl_mcc : sc, red); return; }   // (dogleg: the model cost change of k_dogleg_mid)
     if (tid != 0) return;
     lm_decide(st, ok, lambda, chi, sc, spec);
 }
@@ -870,8 +881,10 @@ int lm_script_host(const int gauss_newton, const int n_iter, const double chi0, 
 // (ceres_lin_update, ceres_decide), on scripted outcomes: iteration t's solve reports (ok, model_cost_change, candidate cost,
 // ||step||); an accepted step then reports (||g||_inf, ||x||) of its linearisation.
 int ceres_script_host(const int max_iter, const double cost0, const double x_norm0, const double grad_max0, const int n, const int32_t* ok,
-                      const double* mcc, const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, LmState* st) {
+                      const double* mcc, const double* cand_cost, const double* step_norm, const double* grad_max, const double* x_norm, LmState* st,
+                      const double* dogleg_step_norm, double* mu_trace) {
     *st = LmState{};
+    st->dogleg = dogleg_step_norm ? 1 : 0;                     // the DOGLEG strategy: iteration t's step had the scaled length dogleg_step_norm[t]
     st->ni = 2.0; st->max_iter = max_iter; st->current_chi = 2.0 * cost0;
     st->done = max_iter <= 0 ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL);
     if (st->done) st->tr_reason = 1;
@@ -880,7 +893,9 @@ int ceres_script_host(const int max_iter, const double cost0, const double x_nor
     for (int guard = 0; st->mode != 0 && guard < 100000; ++guard) {
         const int q = pos < n ? pos : n - 1;
         ++pos;
+        if (dogleg_step_norm) st->dl_step_norm = dogleg_step_norm[q];
         ceres_decide(st, ok[q] != 0, 2.0 * cand_cost[q], 2.0 * mcc[q], step_norm[q]);
+        if (mu_trace && st->n_trace >= 1 && st->n_trace <= MAX_TRACE) mu_trace[st->n_trace - 1] = st->dl_mu;
         if (st->mode & MODE_LIN) ceres_lin_update(st, st->current_chi, grad_max[q], x_norm[q]);
     }
     st->chi2_final = st->current_chi;
@@ -2718,10 +2733,15 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
 
 // K7 + trial chi2 for one landmark handled by G lanes: dl = (Hll + lambda I)^-1 (b_l - sum_i Hpl_il^T x_i), the trial point,
 // and the robust chi2 of its edges at the trial state.  sRt = trial poses, sRt0 = poses of the linearisation point.
-template <int G, bool STG = true>
+// DL (Optimizer/Framework=1 with the DOGLEG strategy): 1 = pass A — the regularised Gauss-Newton landmark step is back-substituted and kept
+// (dxl), and instead of the trial evaluation the lane accumulates the inner products of the dogleg construction: chi_acc <- ||J v||^2
+// (v = g / m, the direction of the Cauchy point; per robustified residual block), scale_acc <- ||g_s||^2, *step_acc <- ||gn_s||^2,
+// *dot_acc <- g_s . gn_s (landmark shares);  2 = pass B — the landmark step is dl_A v + dl_B dn, then the usual trial evaluation.
+template <int G, bool STG = true, int DL = 0>
 __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> Pt, const PoseSrc<STG> P0,
                                                  const double* __restrict__ pt, double* __restrict__ pt_t, const double lambda, const Intrinsics& K,
-                                                 const double iv, const double delta, double& chi_acc, double& scale_acc, double* step_acc = nullptr) {
+                                                 const double iv, const double delta, double& chi_acc, double& scale_acc, double* step_acc = nullptr,
+                                                 double* dot_acc = nullptr, const double dlA = 0.0, const double dlB = 1.0) {
     int k0 = 0, k1 = 0;
     Vec3 pw{ 0, 0, 0 };
     bool lfree = false;
@@ -2732,6 +2752,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
     }
     // c_l = b_l - sum_i Hpl_il^T x_i
     double t0 = 0, t1 = 0, t2 = 0, any = 0.0;
+    if (DL != 2)
     for (int k = k0 + sub; k < k1; k += G) {
         const double w = L.obs_w[k];
         if (w == 0.0) continue;
@@ -2756,7 +2777,19 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
     t0 = group_sum<G>(t0); t1 = group_sum<G>(t1); t2 = group_sum<G>(t2);
     any = group_max<G>(any);
     double d0 = 0, d1 = 0, d2 = 0;
-    if (lvalid && lfree && any != 0.0) {
+    double vl0 = 0.0, vl1 = 0.0, vl2 = 0.0;                    // dogleg: v = g / m = -b_l / m_l of this landmark
+    double m0 = 1.0, m1 = 1.0, m2 = 1.0;
+    if (DL != 0 && lvalid && lfree) {
+        const double* H = L.Hll + 6 * (size_t)l;
+        const double* Bq = L.bl + 3 * (size_t)l;
+        m0 = damp_of(g, 1.0, H[0], g.s2l, 3 * (size_t)l); m1 = damp_of(g, 1.0, H[3], g.s2l, 3 * (size_t)l + 1); m2 = damp_of(g, 1.0, H[5], g.s2l, 3 * (size_t)l + 2);
+        vl0 = -Bq[0] / m0; vl1 = -Bq[1] / m1; vl2 = -Bq[2] / m2;
+        if (DL == 2) {
+            d0 = dlA * vl0 + dlB * g.dxl[3 * (size_t)l]; d1 = dlA * vl1 + dlB * g.dxl[3 * (size_t)l + 1]; d2 = dlA * vl2 + dlB * g.dxl[3 * (size_t)l + 2];
+            if (sub == 0 && step_acc) *step_acc += d0 * d0 + d1 * d1 + d2 * d2;
+        }
+    }
+    if (DL != 2 && lvalid && lfree && any != 0.0) {
         const double* H = L.Hll + 6 * (size_t)l;
         const double* B = L.bl + 3 * (size_t)l;
         double a0 = lambda, a1 = lambda, a2 = lambda;
@@ -2768,13 +2801,47 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
         d0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
         d1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
         d2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
-        if (sub == 0) scale_acc += d0 * (a0 * d0 + B[0]) + d1 * (a1 * d1 + B[1]) + d2 * (a2 * d2 + B[2]);
-        if (sub == 0 && step_acc) *step_acc += d0 * d0 + d1 * d1 + d2 * d2;          // Optimizer/Framework=1: the landmark's share of ||x - candidate||^2
+        if (DL == 0) {
+            if (sub == 0) scale_acc += d0 * (a0 * d0 + B[0]) + d1 * (a1 * d1 + B[1]) + d2 * (a2 * d2 + B[2]);
+            if (sub == 0 && step_acc) *step_acc += d0 * d0 + d1 * d1 + d2 * d2;      // Optimizer/Framework=1: the landmark's share of ||x - candidate||^2
+        } else if (sub == 0) {
+            // pass A:  ||g_s||^2 += b_c^2 / m_c, ||gn_s||^2 += m_c dn_c^2, g_s . gn_s += g_c dn_c
+            scale_acc += B[0] * B[0] / m0 + B[1] * B[1] / m1 + B[2] * B[2] / m2;
+            *step_acc += m0 * d0 * d0 + m1 * d1 * d1 + m2 * d2 * d2;
+            *dot_acc -= B[0] * d0 + B[1] * d1 + B[2] * d2;
+        }
     }
     const Vec3 pn{ pw.x + d0, pw.y + d1, pw.z + d2 };         // VertexPointXYZ::oplus
     if (lvalid && sub == 0) {
         pt_t[3 * l] = pn.x; pt_t[3 * l + 1] = pn.y; pt_t[3 * l + 2] = pn.z;
-        g.dxl[3 * (size_t)l] = d0; g.dxl[3 * (size_t)l + 1] = d1; g.dxl[3 * (size_t)l + 2] = d2;
+        if (DL != 2) { g.dxl[3 * (size_t)l] = d0; g.dxl[3 * (size_t)l + 1] = d1; g.dxl[3 * (size_t)l + 2] = d2; }
+    }
+    if (DL == 1) {
+        // ||J v||^2 of this landmark's residual blocks at the linearisation point: J_e v = Jp v_l + Jx v_p, weighted rho' / sigma^2
+        for (int k = k0 + sub; k < k1; k += G) {
+            const double w = L.obs_w[k];
+            if (w == 0.0) continue;
+            const int ipk = g.obs_pose[k];
+            const int a = g.pose_free[ipk];
+            const double2* seed = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)k);
+            const double2 s0 = seed[0], s1 = seed[1];
+            const Vec3 pcs{ s0.x, s0.y, s1.x };
+            double Jp[9], Jx[18];
+            stereo_jacobians(P0.get(ipk), pcs, K, Jp, Jx);
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+            if (lfree) {
+                r0 = Jp[0] * vl0 + Jp[1] * vl1 + Jp[2] * vl2; r1 = Jp[3] * vl0 + Jp[4] * vl1 + Jp[5] * vl2; r2 = Jp[6] * vl0 + Jp[7] * vl1 + Jp[8] * vl2;
+            }
+            if (a >= 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double vp = -g.bp[6 * (size_t)a + c] / damp_of(g, 1.0, g.Hpp[36 * (size_t)a + 7 * c], g.s2p, 6 * (size_t)a + c);
+                    r0 += Jx[c] * vp; r1 += Jx[6 + c] * vp; r2 += Jx[12 + c] * vp;
+                }
+            }
+            chi_acc += w * iv * (r0 * r0 + r1 * r1 + r2 * r2);
+        }
+        return;
     }
     // computeActiveErrors + activeRobustChi2 at the trial state
     for (int k = k0 + sub; k < k1; k += G) {
@@ -2798,9 +2865,10 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // last ones of the launch, takes the LM decision on the trial (decide_gather_role) — k_decide (6.3 us + a launch gap per unit) leaves.
 // The batched instantiation drifts from 90 to 114 VGPRs with the role on board (one wave per SIMD less for a bandwidth-bound
 // launch): it is held at five waves per SIMD (96 VGPRs, a dozen spill slots outside the loops).
-template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false>
+template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false, int DL = 0>
 __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void k_backsub(const Src src) {
     static_assert(!(DEC && ODOSPEC), "the decision rides on the gated unit only");
+    static_assert(DL == 0 || (!DEC && !ODOSPEC), "the dogleg passes are plain launches");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (DEC) {
         const int dw = decider_window();
@@ -2828,6 +2896,27 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     const double iv = g.inv_pixel_var, delta = g.huber_delta;
     const int bid = blockIdx.x, tid = threadIdx.x;
     if (bid > g.n_lin_a) return;
+    if (DL == 1 && bid == g.n_lin_a) {
+        // dogleg pass A: the laser residual blocks' share of ||J v||^2 (J at the linearisation pose, v_p = -b_p / m_p of the newest pose)
+        double jv = 0.0;
+        if (g.Nz > 0 && g.pose_free[g.laser_pose] >= 0) {
+            const int a = g.pose_free[g.laser_pose];
+            double vp[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) vp[c] = -g.bp[6 * (size_t)a + c] / damp_of(g, 1.0, g.Hpp[36 * (size_t)a + 7 * c], g.s2p, 6 * (size_t)a + c);
+            for (int z = tid; z < g.Nz; z += 256) {
+                double J[6];
+                laser_jacobian(g.pose[sel] + POSE_STRIDE * g.laser_pose, g.Tcr, Vec3{ g.laser_xyz[3 * z], g.laser_xyz[3 * z + 1], g.laser_xyz[3 * z + 2] }, g.grid, J, true);
+                double r = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) r += J[c] * vp[c];
+                jv += g.inv_laser_cov * r * r;
+            }
+        }
+        const double jv_tot = block_sum_256(jv, red);
+        if (tid == 0) { g.dl_part[4 * (size_t)bid] = jv_tot; g.dl_part[4 * (size_t)bid + 1] = 0.0; g.dl_part[4 * (size_t)bid + 2] = 0.0; g.dl_part[4 * (size_t)bid + 3] = 0.0; }
+        return;
+    }
     if (bid == g.n_lin_a) {
         // odometry chi2 at the trial state (the pose part of computeScale is done in k_decide)
         const double ic = g.inv_odo_cov;
@@ -2864,12 +2953,51 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     constexpr int LPW = 256 / G;
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
-    double chi_acc = 0.0, scale_acc = 0.0, step_acc = 0.0;
-    backsub_landmark<G, STG>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc, &step_acc);
+    double chi_acc = 0.0, scale_acc = 0.0, step_acc = 0.0, dot_acc = 0.0;
+    backsub_landmark<G, STG, DL>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc, &step_acc, &dot_acc, st->dl_A, st->dl_B);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
+    if (DL == 1) {
+        const double s2_tot = block_sum_256(step_acc, red), s3_tot = block_sum_256(dot_acc, red);
+        if (tid == 0) { g.dl_part[4 * (size_t)bid] = chi_tot; g.dl_part[4 * (size_t)bid + 1] = sc_tot; g.dl_part[4 * (size_t)bid + 2] = s2_tot; g.dl_part[4 * (size_t)bid + 3] = s3_tot; }
+        return;
+    }
     if (g.ceres) { const double st_tot = block_sum_256(step_acc, red); if (tid == 0) g.aux_part[bid] = st_tot; }
     if (tid == 0) { if (DEC) publish_trial(g, bid, st->decide_epoch + 1u, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
+}
+
+// Between the two dogleg passes (one workgroup): the inner products summed in a fixed order, the step coefficients and the model cost
+// change (dogleg_combine), then the trial poses x (+) (dl_A v_p + dl_B dn_p) — the solver's epilogue left x (+) dn_p there.
+template <class Src>
+__global__ __launch_bounds__(256) void k_dogleg_mid(const Src src) {
+    const DeviceGraph& g = graph_of(src);
+    LmState* st = g.st;
+    __shared__ double red[4];
+    if (!(st->mode & MODE_TRIAL) || st->solver_failed || st->pcg_timeout) return;
+    const int tid = threadIdx.x;
+    double jv = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int w = tid; w < g.n_lin_a + 1; w += 256) { jv += g.dl_part[4 * (size_t)w]; s1 += g.dl_part[4 * (size_t)w + 1]; s2 += g.dl_part[4 * (size_t)w + 2]; s3 += g.dl_part[4 * (size_t)w + 3]; }
+    for (int t = tid; t < 6 * g.Npf; t += 256) {
+        const double m = damp_of(g, 1.0, g.Hpp[36 * (size_t)(t / 6) + 7 * (t % 6)], g.s2p, t), b = g.bp[t], x = g.x[t];
+        s1 += b * b / m; s2 += m * x * x; s3 -= b * x;
+    }
+    jv = block_sum_256(jv, red); s1 = block_sum_256(s1, red); s2 = block_sum_256(s2, red); s3 = block_sum_256(s3, red);
+    double A, B, norm, mcc;
+    dogleg_combine(s1, s2, s3, jv, st->tr_radius, st->dl_mu, A, B, norm, mcc);     // (every thread: the same inputs, the same result)
+    __syncthreads();
+    if (tid == 0) { st->dl_A = A; st->dl_B = B; st->dl_step_norm = norm; st->dl_mcc = mcc; }
+    const int sel = st->sel;
+    for (int a = tid; a < g.Npf; a += 256) {
+        const int ip = g.free_pose[a];
+        double dx[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int t = 6 * a + c;
+            const double m = damp_of(g, 1.0, g.Hpp[36 * (size_t)a + 7 * c], g.s2p, t);
+            dx[c] = A * (-g.bp[t] / m) + B * g.x[t];
+        }
+        pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+    }
 }
 
 // ================================================================= K9: Levenberg-Marquardt control (lm_decide / decide_role: above k_linearize)
@@ -3011,6 +3139,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         st->pcg_iter = 0; st->pcg_total = 0; st->gauss_newton = gauss_newton; st->status = 0;
         st->n_outliers = 0; st->n_trace = 0;
         st->tr_radius = 1e4; st->tr_x_norm = 0.0; st->tr_invalid = 0; st->tr_reason = 0;
+        st->dogleg = g.dogleg; st->dl_mu = 1e-8; st->dl_A = 0.0; st->dl_B = 1.0; st->dl_step_norm = 0.0; st->dl_mcc = 0.0;
         st->iterations_run[0] = st->iterations_run[1] = 0; st->trials_run[0] = st->trials_run[1] = 0;
     }
 }
@@ -3741,6 +3870,30 @@ void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(On
 void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 1, 0, s); }
 void launch_backsub_decide(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 0, 1, s); }
 void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
+// Optimizer/Framework=1 with the DOGLEG strategy: pass 1 (Gauss-Newton landmark step + the inner products), the combination, pass 2 (trial state)
+template <int G>
+static void launch_backsub_dogleg_t(const DeviceGraph& g, const LaunchDims& d, int pass, hipStream_t s) {
+    const One src{ g };
+    if (staged(d)) {
+        const size_t lds = lds_poses(d, 8 + 12 * d.np);
+        if (pass == 1) { ensure_lds(k_backsub<G, One, false, true, false, 1>, lds); hipLaunchKernelGGL((k_backsub<G, One, false, true, false, 1>), dim3(d.backsub_blocks), dim3(256), lds, s, src); }
+        else { ensure_lds(k_backsub<G, One, false, true, false, 2>, lds); hipLaunchKernelGGL((k_backsub<G, One, false, true, false, 2>), dim3(d.backsub_blocks), dim3(256), lds, s, src); }
+    } else {
+        if (pass == 1) hipLaunchKernelGGL((k_backsub<G, One, false, false, false, 1>), dim3(d.backsub_blocks), dim3(256), (size_t)8 * sizeof(double), s, src);
+        else hipLaunchKernelGGL((k_backsub<G, One, false, false, false, 2>), dim3(d.backsub_blocks), dim3(256), (size_t)8 * sizeof(double), s, src);
+    }
+}
+void launch_backsub_dogleg(const DeviceGraph& g, int pass, hipStream_t s) {
+    const LaunchDims d = dims_of(g);
+    switch (d.group) {
+        case 4: launch_backsub_dogleg_t<4>(g, d, pass, s); break;
+        case 8: launch_backsub_dogleg_t<8>(g, d, pass, s); break;
+        case 16: launch_backsub_dogleg_t<16>(g, d, pass, s); break;
+        case 32: launch_backsub_dogleg_t<32>(g, d, pass, s); break;
+        default: launch_backsub_dogleg_t<64>(g, d, pass, s); break;
+    }
+}
+void launch_dogleg_mid(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL((k_dogleg_mid<One>), dim3(1), dim3(256), 0, s, One{ g }); }
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
     launch_phase_end_src(One{ g }, dims_of(g), 1, phase_just_done, mark, next_max_iter, s);
 }

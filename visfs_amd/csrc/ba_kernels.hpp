@@ -33,6 +33,8 @@ void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s);   // speculati
 void launch_ceres_lin_finalize(const DeviceGraph& g, hipStream_t s);  // Optimizer/Framework=1: cost, ||g||_inf, ||x||, Jacobi scaling after every linearisation
 void launch_backsub_decide(const DeviceGraph& g, hipStream_t s);    // gated unit: the launch also takes the LM decision (no k_decide)
 void launch_decide(const DeviceGraph& g, hipStream_t s);
+void launch_backsub_dogleg(const DeviceGraph& g, int pass, hipStream_t s);   // Optimizer/Framework=1 + TrustRegion=1: the two landmark passes of the dogleg step
+void launch_dogleg_mid(const DeviceGraph& g, hipStream_t s);                  // ... the combination between them (coefficients, model cost change, trial poses)
 void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
 size_t band_lds_bytes(int npf, int B, int rows);                       // dynamic LDS of the banded direct solver (k_band_chol) with `rows` block rows resident
 constexpr int BAND_LDS_BUDGET = 156 * 1024;
@@ -52,7 +54,8 @@ void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t
 void launch_eval_mark(const DeviceGraph& g, hipStream_t s);           // stage hook: outlier pass on the committed estimate, ungated
 // test hook: one phase of the LM state machine on the host, through the functions the kernels run, on scripted trial outcomes
 int ceres_script_host(int max_iter, double cost0, double x_norm0, double grad_max0, int n, const int32_t* ok, const double* mcc, const double* cand_cost,
-                      const double* step_norm, const double* grad_max, const double* x_norm, LmState* st);
+                      const double* step_norm, const double* grad_max, const double* x_norm, LmState* st,
+                      const double* dogleg_step_norm = nullptr, double* mu_trace = nullptr);
 int lm_script_host(int gauss_newton, int n_iter, double chi0, double max_diag0, int n_trials, const double* temp_chi, const double* scale, const int32_t* ok, LmState* st);
 
 }  // namespace visfs_ba

@@ -294,6 +294,29 @@ BA_HD void sym3_inverse(const double h[6], double o[6]) {
     o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
 }
 
+// [ceres-upstream] DoglegStrategy::ComputeTraditionalDoglegStep (dogleg_strategy.cc, Ceres 2.0 / 2.1) from the four inner products of the
+// scaled space: S1 = ||g_s||^2, S2 = ||gn_s||^2, S3 = g_s . gn_s, JV2 = ||J v||^2 (v = the unscaled direction of -Cauchy / alpha).  The scaled
+// step is A g_s + B gn_s, i.e. A v + B dn in the unscaled variables; norm = its length (dogleg_step_norm_); mcc = the model cost change
+// -(g . step + step^T H step / 2) with v^T H v = JV2 and H dn = -g - mu M dn.
+BA_HD void dogleg_combine(const double S1, const double S2, const double S3, const double JV2, const double radius, const double mu,
+                          double& A, double& B, double& norm, double& mcc) {
+    const double gnorm = sqrt(S1), gn_norm = sqrt(S2), alpha = S1 / JV2;
+    if (gn_norm <= radius) { A = 0.0; B = 1.0; norm = gn_norm; }                          // case 1: the Gauss-Newton step lies inside the trust region
+    else if (gnorm * alpha >= radius) { A = -radius / gnorm; B = 0.0; norm = radius; }     // case 2: even the Cauchy point lies outside: scaled back
+    else {                                                                              // case 3: where the segment Cauchy -> Gauss-Newton leaves the region
+        const double b_dot_a = -alpha * S3;
+        const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+        const double bma_sq = a_sq - 2.0 * b_dot_a + gn_norm * gn_norm;
+        const double c = b_dot_a - a_sq;
+        const double d = sqrt(c * c + bma_sq * (radius * radius - a_sq));
+        const double beta = (c <= 0.0) ? (d - c) / bma_sq : (radius * radius - a_sq) / (d + c);
+        A = -alpha * (1.0 - beta); B = beta;
+        norm = sqrt(A * A * S1 + 2.0 * A * B * S3 + B * B * S2);
+    }
+    const double sHs = A * A * JV2 + 2.0 * A * B * (-S1 - mu * S3) + B * B * (-S3 - mu * S2);
+    mcc = -(A * S1 + B * S3 + 0.5 * sHs);
+}
+
 // ---- wheel-odometry edge: EdgePoseConstraint (OptimizeTypeDefine.cpp:35-88) ----
 // Bottom-right 3x3 of QuaternionLeft(a) * QuaternionRight(b) (Math.h:324-345; both positify their argument).
 BA_HD Mat3 quat_LR_br(const Quat& a_in, const Quat& b_in) {
