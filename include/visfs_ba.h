@@ -43,18 +43,18 @@ enum {
     VISFS_BA_ERR_HUGE_CHI2_1 = 4,  /* Optimizer.cpp:277-280 */
     VISFS_BA_ERR_HUGE_CHI2_2 = 5,  /* Optimizer.cpp:315-318 */
     VISFS_BA_ERR_BAD_ARGUMENT = 6,
-    VISFS_BA_ERR_UNSUPPORTED = 7,  /* Ceres DOGLEG strategy, a size beyond a kernel's limits, ... */
+    VISFS_BA_ERR_UNSUPPORTED = 7,  /* an unknown Optimizer/Framework, a size beyond a kernel's limits, ... */
     VISFS_BA_ERR_DEVICE = 8,       /* HIP runtime error / no MI355X present */
     VISFS_BA_ERR_NOT_LOADED = 9    /* no graph resident in the handle */
 };
 
 /* ---- parameters: the eight Optimizer keys (Parameters.h:184-191, read at Optimizer.cpp:37-54) */
 typedef struct visfs_ba_params {
-    int32_t framework;            /* Optimizer/Framework: 0 = the g2o branch (Optimizer.cpp:72-364), 1 = the Ceres branch (:366-593; its
-                                   * LEVENBERG_MARQUARDT strategy: trust_region 1 = DOGLEG is refused; solver is ignored — every
-                                   * linear_solver_type the branch selects is an exact dense solve) */
+    int32_t framework;            /* Optimizer/Framework: 0 = the g2o branch (Optimizer.cpp:72-364), 1 = the Ceres branch (:366-593;
+                                   * trust_region picks its strategy: 0 LEVENBERG_MARQUARDT, 1 DOGLEG (:515-519); solver is ignored —
+                                   * every linear_solver_type the branch selects is an exact dense solve) */
     int32_t solver;               /* Optimizer/Solver: 0 csparse, 1 cholmod, 3 eigen → direct Cholesky of S; 2 → block-Jacobi PCG */
-    int32_t trust_region;         /* Optimizer/TrustRegion: 0 Levenberg, 1 GaussNewton */
+    int32_t trust_region;         /* Optimizer/TrustRegion: 0 Levenberg, 1 GaussNewton (framework 1: 0 LM, 1 DOGLEG) */
     int32_t iterations;           /* Optimizer/Iterations (run as iterations/2 + iterations/2) */
     double  pixel_variance;       /* Optimizer/PixelVariance      (default 1.5)  */
     double  odometry_covariance;  /* Optimizer/OdometryCovariance (default 5e-5) */
