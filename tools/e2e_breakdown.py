@@ -26,7 +26,12 @@ def main():
             t3 = time.perf_counter(); s.download()
             t4 = time.perf_counter()
             t["pack"] += t1 - t0; t["upload"] += t2 - t1; t["optimize"] += t3 - t2; t["download"] += t4 - t3
-            t0 = time.perf_counter(); s.solve_window(abi.WindowBuffers(w)); t["window"] += time.perf_counter() - t0
+            # (round 3: the caller's input and output buffers exist before the clock starts — rounds 1-2 timed their construction in
+            # Python, 40 us at C2 / 250 us at C4, together with the call)
+            wbw = abi.WindowBuffers(w); rbw = abi.ResultBuffers(wbw.struct.n_poses, wbw.struct.n_refs)
+            rbw.outlier_feature[:] = 1; rbw.outlier_pose[:] = 1
+            t0 = time.perf_counter(); s.solve_window(wbw, rbw); t["window"] += time.perf_counter() - t0
+            t0 = time.perf_counter(); s.solve_window(abi.WindowBuffers(w)); t["window_r02"] = t.get("window_r02", 0.0) + time.perf_counter() - t0
         info = s.describe()
         print(cfg, {k: round(1e3 * v / n, 3) for k, v in t.items()}, "ms;  pairs", info["n_pairs"], "device MB", round(info["device_bytes"] / 1e6, 1), flush=True)
         s.close()

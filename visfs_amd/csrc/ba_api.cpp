@@ -201,12 +201,17 @@ namespace {
 
 int bad(visfs_ba_handle* h, const char* msg) { h->err = msg; return VISFS_BA_ERR_BAD_ARGUMENT; }
 
-// Host threads for the O(N_obs) passes of a window solve: VISFS_BA_THREADS in total (default: min(4, hardware threads)), 1 = none.
+// Host threads for the O(N_obs) passes of a window solve: VISFS_BA_THREADS in total, 1 = none.  Default: the cores that share the
+// last-level cache with the calling thread (half its CPUs: SMT siblings do not help a streaming loop), at most 8 — the workers are kept
+// on that cache domain (worker_pool.hpp), so more threads than it has cores would only queue up; min(4, hardware threads) when the
+// topology cannot be read.  The regions are bursts of 50-400 us per call; nothing spins between calls.
 WorkerPool* host_pool(visfs_ba_handle* h) {
     if (!h->pool_tried) {
         h->pool_tried = true;
         const char* e = std::getenv("VISFS_BA_THREADS");
-        int n = e ? std::atoi(e) : (int)std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+        const int llc = WorkerPool::llc_domain_cpus();
+        const int dflt = llc >= 2 ? std::min(8, std::max(1, llc / 2)) : (int)std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+        int n = e ? std::atoi(e) : dflt;
         n = std::max(1, std::min(n, 16));
         if (n > 1) { try { h->pool.reset(new WorkerPool(n - 1)); } catch (...) { h->pool.reset(); } }
     }
@@ -661,6 +666,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     Arena dyn{ nullptr, 0, static_bytes };
     DeviceGraph dg{};
     int32_t* d_hist = nullptr;
+    size_t zero_end = 0;
     auto layout_dyn = [&](Arena& A, DeviceGraph& g) {
         // device-built index arrays
         g.lm_ptr = A.take<int32_t>(Nl + 1);
@@ -685,9 +691,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.obs_level = A.take<uint8_t>(std::max(No, 1));
         g.obs_outlier = A.take<uint8_t>(std::max(No, 1));
         g.obs_chi2_out = A.take<double>(std::max(No, 1));
-        g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);
         g.obs_chi2 = A.take<double>(std::max(No, 1));
-        g.W = A.take<double>((size_t)std::max(No, 1) * 18);
         g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.bp = A.take<double>(std::max<size_t>(n6, 1));
         g.lin_part = A.take<double>((size_t)n_parts * 2);
@@ -710,10 +714,15 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.band_L = A.take<double>(band_B >= 0 && band_rows < Npf ? (size_t)Npf * (band_B + 1) * 36 : 1);
         g.chol_y = A.take<double>(chol_np);
         g.chol_linv = A.take<double>(2 * 32 * 32);
-        g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // filled on the device (k_build_pairs)
-        g.pose_lm = A.take<int32_t>(std::max(n_pose_obs, 1));                   // likewise
         g.stamps = A.take<unsigned long long>(128);
         g.st = A.take<LmState>(1);
+        // ---- from here on: arrays that are written in full before anything reads them — not part of the upload's clearing pass (a third
+        // of the arena at C2: the stage hooks' H_pl tiles and residuals exist for every window but are only written under `debug`)
+        zero_end = (A.used + 255) & ~size_t(255);
+        g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // every slot filled on the device (k_build_pairs: the counts are the summary's)
+        g.pose_lm = A.take<int32_t>(std::max(n_pose_obs, 1));                   // every slot filled by k_index_scatter
+        g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);               // debug: every observation, active or not (k_linearize)
+        g.W = A.take<double>((size_t)std::max(No, 1) * 18);                    // likewise
     };
     layout_dyn(dyn, dg);
     const size_t total_bytes = (dyn.used + 255) & ~size_t(255);
@@ -806,7 +815,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
     if (static_bytes) HIP_TRY(h, hipMemcpyAsync(w.d_base, w.h_base, static_bytes, hipMemcpyHostToDevice, w.stream));
-    HIP_TRY(h, hipMemsetAsync(w.d_base + static_bytes, 0, total_bytes - static_bytes, w.stream));
+    HIP_TRY(h, hipMemsetAsync(w.d_base + static_bytes, 0, zero_end - static_bytes, w.stream));
     if (configure_kernels(w.g) != 0) { h->err = "hipFuncSetAttribute failed"; return VISFS_BA_ERR_DEVICE; }
     launch_build_index(w.g, d_hist, w.stream);             // lm_ptr, obs_ok, pose_obs / obs_ppos: never exist on the host
     launch_build_pairs(w.g, w.stream);                     // the co-observation pair lists never exist on the host
@@ -1196,14 +1205,30 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
         while (k > 0 && k < Nr && w->ref_feature[k] == w->ref_feature[k - 1]) ++k;   // a feature's references (and its point_used flag) stay with one thread
         cut[t] = k;
     }
+    // signature ids of a sliding window are a short ascending range: the pose of a reference is found through a direct table
+    // (id - first id) instead of a search per reference; windows whose ids are spread wider than 64 k keep the search
+    const uint64_t pose_base = w->n_poses > 0 ? w->pose_ids[0] : 0;
+    const uint64_t pose_span = w->n_poses > 0 ? w->pose_ids[w->n_poses - 1] - pose_base : 0;
+    std::vector<int16_t> pose_tab;
+    if (w->n_poses > 0 && w->n_poses < 32768 && pose_span < 65536) {
+        pose_tab.assign((size_t)pose_span + 1, (int16_t)-1);
+        for (int i = 0; i < w->n_poses; ++i) pose_tab[(size_t)(w->pose_ids[i] - pose_base)] = (int16_t)i;
+    }
+    const int16_t* const ptab = pose_tab.empty() ? nullptr : pose_tab.data();
     struct Part { int no = 0, mono = 0, first_p = -1, first_c = -1, last_p = -1, last_c = -1; bool bad = false; };
     std::vector<Part> part(T);
     static const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
     if (timing) std::fprintf(stderr, "   pack: before the reference loop %.1f us\n", std::chrono::duration<double, std::micro>(tr0 - te0).count());
     std::atomic<int> by_caller{ 0 };
+    // (diagnostic, timing runs only — results are WRONG with it: 2 = no output stores, 4 = no point_used store, 8 = no summary accumulation)
+    static const int dbg = []() { const char* e = std::getenv("VISFS_BA_PACK_DEBUG"); return (e && std::getenv("VISFS_BA_TIMING")) ? std::atoi(e) : 0; }();
+    struct TaskLap { int slot; double t0, t1; };
+    std::vector<TaskLap> task_lap(timing ? T : 0);
     auto body = [&](int t, int slot) {
         if (timing && slot == 0) by_caller.fetch_add(1, std::memory_order_relaxed);
+        struct LapGuard { TaskLap* l; std::chrono::steady_clock::time_point z; ~LapGuard() { if (l) l->t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - z).count(); } } lap_guard{ nullptr, tr0 };
+        if (timing) { task_lap[t].slot = slot; task_lap[t].t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); lap_guard.l = &task_lap[t]; }
         SummaryPart* SP = ps ? &(*ps->part)[slot] : nullptr;
         if (SP && !SP->used) SP->begin(ps->Npf);
         Part& P = part[t];
@@ -1213,43 +1238,61 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
         auto find_hinted = [](const uint64_t* ids, int n, uint64_t id, int& hint) {
             if (hint < n && ids[hint] == id) return hint;
             if (hint + 1 < n && ids[hint + 1] == id) return ++hint;
+            if (hint < n && ids[hint] < id) {                                      // a few ids without references in between: walk, do not search
+                const int stop = std::min(n, hint + 10);
+                for (int q = hint + 2; q < stop; ++q) { if (ids[q] == id) { hint = q; return q; } if (ids[q] > id) break; }
+            }
             const int f = find_id(ids, n, id);
             if (f >= 0) hint = f;
             return f;
         };
-        for (int k = cut[t]; k < cut[t + 1]; ++k) {
-            const int p = find_hinted(w->point_ids, w->n_points, w->ref_feature[k], hint_p);
-            if (p < 0) continue;                                                    // :158
-            o.point_used[p] = 1;
-            const int c = find_hinted(w->pose_ids, w->n_poses, w->ref_pose[k], hint_c);
-            if (c < 0 || w->ref_pose[k] == 0) continue;                             // :172
-            const double depth = (double)w->ref_depth[k];                           // :174
-            if (std::isfinite(depth) && depth > 0.0 && baseLine > 0.0) {
+        // one feature at a time (its references are consecutive: nested-map order): the feature is looked up, flagged and handed to the
+        // structure summary once, the loop over its references only resolves the pose, tests the depth and stores
+        const bool fast_sum = SP && !(dbg & 8);
+        for (int k = cut[t]; k < cut[t + 1];) {
+            const uint64_t fid = w->ref_feature[k];
+            int k1 = k + 1;
+            while (k1 < cut[t + 1] && w->ref_feature[k1] == fid) ++k1;
+            const int p = find_hinted(w->point_ids, w->n_points, fid, hint_p);
+            if (p < 0) { k = k1; continue; }                                        // :158
+            if (!(dbg & 4)) o.point_used[p] = 1;
+            const bool pfixed = w->point_fixed[p] != 0;
+            const int no0 = no;
+            for (; k < k1; ++k) {
+                const uint64_t pid = w->ref_pose[k];
+                int c;
+                if (ptab) { const uint64_t off = pid - pose_base; c = off <= pose_span ? ptab[off] : -1; }
+                else c = find_hinted(w->pose_ids, w->n_poses, pid, hint_c);
+                if (c < 0 || pid == 0) continue;                                    // :172
+                const float depth = w->ref_depth[k];                                // :174
+                if (!(std::isfinite(depth) && depth > 0.0f && baseLine > 0.0)) { ++mono; continue; }   // the reference dereferences an uninitialised edge pointer here (:179, :197-210); we skip the observation
                 if (p < last_p || (p == last_p && c <= last_c)) { P.bad = true; return; }   // nested std::map order
                 if (P.first_p < 0) { P.first_p = p; P.first_c = c; }
                 last_p = p; last_c = c;
+                if (dbg & 2) { ++no; continue; }
                 if (o.obs_uvd) {
-                    o.obs_uvd[3 * (size_t)no + 0] = w->ref_u[k]; o.obs_uvd[3 * (size_t)no + 1] = w->ref_v[k]; o.obs_uvd[3 * (size_t)no + 2] = w->ref_depth[k];
+                    o.obs_uvd[3 * (size_t)no + 0] = w->ref_u[k]; o.obs_uvd[3 * (size_t)no + 1] = w->ref_v[k]; o.obs_uvd[3 * (size_t)no + 2] = depth;
                 } else {
-                    const float disparity = static_cast<float>(baseLine * w->fx / depth);           // :187
+                    const float disparity = static_cast<float>(baseLine * w->fx / (double)depth);   // :187
                     o.obs_uvr[3 * (size_t)no + 0] = (double)w->ref_u[k];
                     o.obs_uvr[3 * (size_t)no + 1] = (double)w->ref_v[k];
                     o.obs_uvr[3 * (size_t)no + 2] = (double)(w->ref_u[k] - disparity);              // float - float, :188
                 }
                 o.obs_point[no] = p; o.obs_pose[no] = c;
                 if (o.obs_ref) o.obs_ref[no] = k;
-                if (SP) SP->add(p, w->point_fixed[p] != 0, ps->pose_free[c]);
                 ++no;
-            } else {
-                ++mono;   // the reference dereferences an uninitialised edge pointer here (:179, :197-210); we skip the observation
             }
+            if (fast_sum && !(dbg & 2)) for (int q = no0; q < no; ++q) SP->add(p, pfixed, ps->pose_free[o.obs_pose[q]]);
         }
         if (SP) SP->flush();
         P.no = no - cut[t]; P.mono = mono; P.last_p = last_p; P.last_c = last_c;
     };
     if (T > 1) pool->run(T, body); else body(0, 0);
-    if (timing) std::fprintf(stderr, "   pack: poses + links + cuts, then %d tasks (%d by the caller): %.1f us since entry\n", T, by_caller.load(),
-                             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
+    if (timing) {
+        std::fprintf(stderr, "   pack: poses + links + cuts, then %d tasks (%d by the caller): %.1f us since entry\n", T, by_caller.load(),
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
+        if (T > 1 && std::getenv("VISFS_BA_TIMING_TASKS")) for (int t = 0; t < T; ++t) std::fprintf(stderr, "      task %2d on slot %d: %7.1f -> %7.1f us (%d references)\n", t, task_lap[t].slot, task_lap[t].t0, task_lap[t].t1, cut[t + 1] - cut[t]);
+    }
     int no = 0, mono = 0, last_p = -1, last_c = -1;
     for (int t = 0; t < T; ++t) {
         const Part& P = part[t];
@@ -1383,6 +1426,9 @@ int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, 
     }
     // outliers are appended at Optimizer.cpp:296, before the phase-2 abort check.  Large windows: counted and written by ranges of
     // observations on the pool (a range's outliers land where the serial loop would put them).
+    static const bool timing = std::getenv("VISFS_BA_TIMING") != nullptr;
+    auto F0 = std::chrono::steady_clock::now();
+    auto flap = [&](const char* what) { if (timing) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "  finish %-16s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - F0).count()); F0 = t; } };
     int n = 0;
     {
         const int No = pk.g.n_obs;
@@ -1390,19 +1436,29 @@ int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, 
         std::vector<int> cnt(T + 1, 0);
         auto count = [&](int t, int) {
             const int lo = (int)((int64_t)No * t / T), hi = (int)((int64_t)No * (t + 1) / T);
-            int c = 0, k = lo;
-            while (k < hi) {
-                if (k + 8 <= hi) { uint64_t eight; std::memcpy(&eight, outl + k, 8); if (eight == 0) { k += 8; continue; } }   // outliers are a few per cent as a rule
-                c += outl[k] != 0; ++k;
-            }
+            int c = 0;
+            for (int k = lo; k < hi; ++k) c += outl[k] != 0;            // (no branch: the compiler vectorises the byte sum)
             cnt[t + 1] = c;
         };
         if (T > 1) pool->run(T, count); else count(0, 0);
+        flap("count outliers");
         for (int t = 0; t < T; ++t) cnt[t + 1] += cnt[t];
         auto write = [&](int t, int) {
             const int lo = (int)((int64_t)No * t / T), hi = (int)((int64_t)No * (t + 1) / T);
             int at = cnt[t], k = lo;
             if (cnt[t + 1] == at) return;
+            if ((int64_t)(cnt[t + 1] - at) * 16 > hi - lo && cnt[t + 1] <= r->outlier_capacity) {
+                // many outliers (a window that started far off): a test per observation mispredicts every other time — store every
+                // observation's ids at the cursor and advance it by the flag (the slot after the last outlier of the range is the next
+                // range's first, or spare capacity: the caller sized the arrays for every reference)
+                const int end = cnt[t + 1];
+                for (; k < hi && at < end; ++k) {
+                    const int ref = pk.obs_ref[k];
+                    r->outlier_feature[at] = win->ref_feature[ref]; r->outlier_pose[at] = win->ref_pose[ref];
+                    at += outl[k] != 0;
+                }
+                return;
+            }
             while (k < hi) {
                 if (k + 8 <= hi) { uint64_t eight; std::memcpy(&eight, outl + k, 8); if (eight == 0) { k += 8; continue; } }
                 if (outl[k]) { if (at < r->outlier_capacity) { r->outlier_feature[at] = win->ref_feature[pk.obs_ref[k]]; r->outlier_pose[at] = win->ref_pose[pk.obs_ref[k]]; } ++at; }
@@ -1411,11 +1467,13 @@ int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, 
         };
         if (T > 1) pool->run(T, write); else write(0, 0);
         n = std::min(cnt[T], (int)r->outlier_capacity);
+        flap("write outliers");
     }
     r->n_outliers = n;
     if (rc != VISFS_BA_OK) return rc;
     for (int i = 0; i < Np; ++i) { r->pose_ids_out[i] = win->pose_ids[i]; visfs_ba_unpack_pose(pose + (size_t)pose_stride * i, win->Trc, r->pose_Twr_out + 12 * i); }   // :320-340
     r->n_poses_out = Np;
+    flap("poses");
     {
         const int T = (pool && Nl >= 16384) ? 2 * pool->size() : 1;
         auto body = [&](int t, int) {
@@ -1429,6 +1487,7 @@ int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, 
             }
         };
         if (T > 1) pool->run(T, body); else body(0, 0);
+        flap("landmarks");
     }
     return VISFS_BA_OK;
 }

@@ -1012,53 +1012,94 @@ __global__ __launch_bounds__(256) void k_index_count(const DeviceGraph g, int32_
         for (int q = lprev + 1; q <= l; ++q) lm_ptr[q] = k;                   // landmarks without observations get empty ranges
         if (k == g.No - 1) for (int q = l + 1; q <= g.Nl; ++q) lm_ptr[q] = g.No;
     }
+    // per-wavefront counts of every free pose among the wave's 64 observations (one ballot per DISTINCT pose present), summed over the
+    // four wavefronts: thread a scanning all 256 entries was 256 dependent LDS reads per thread
+    extern __shared__ int wcnt[];                                             // [4][Npf]
+    for (int q = tid; q < 4 * g.Npf; q += 256) wcnt[q] = 0;
     __syncthreads();
-    for (int a = tid; a < g.Npf; a += 256) {
-        int cnt = 0;
-        for (int i = 0; i < n; ++i) cnt += (sfree[i] == a);
-        hist[(size_t)blockIdx.x * g.Npf + a] = cnt;
+    {
+        const int a = tid < n ? sfree[tid] : -1;
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long todo = __ballot(a >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int key = __shfl(a, leader);
+            const unsigned long long m = __ballot(a == key);
+            if (lane == leader) wcnt[wave * g.Npf + key] = __popcll(m);
+            todo &= ~m;
+        }
     }
+    __syncthreads();
+    for (int a = tid; a < g.Npf; a += 256) hist[(size_t)blockIdx.x * g.Npf + a] = wcnt[a] + wcnt[g.Npf + a] + wcnt[2 * g.Npf + a] + wcnt[3 * g.Npf + a];
 }
-// exclusive scan of the per-block counts over the blocks, per pose, offset by where the pose's range starts in pose_obs
+// exclusive scan of the per-block counts over the blocks, per pose, offset by where the pose's range starts in pose_obs.
+// One workgroup per free pose: thread t sums a contiguous run of blocks, the 256 run sums are scanned in LDS, each thread writes its
+// run's exclusive prefixes back (one thread per pose walking all blocks was 10.7 us at C2's 196 blocks, a latency chain).
 __global__ __launch_bounds__(256) void k_index_scan(const DeviceGraph g, int32_t* __restrict__ hist, const int nblocks) {
     if (g.No == 0 && threadIdx.x == 0 && blockIdx.x == 0) { int32_t* lm_ptr = const_cast<int32_t*>(g.lm_ptr); for (int q = 0; q <= g.Nl; ++q) lm_ptr[q] = 0; }
-    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.x, tid = threadIdx.x;
     if (a >= g.Npf) return;
-    int run = g.chunk_ptr[g.pose_chunk_ptr[a]];
-    // (the loads of a batch of blocks are independent of the running sum: sixteen in flight per thread — one load per step made this
-    // 274 us at C4's 1172 blocks)
-    constexpr int U = 16;
-    for (int b0 = 0; b0 < nblocks; b0 += U) {
-        int c[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = (b0 + u < nblocks) ? hist[(size_t)(b0 + u) * g.Npf + a] : 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) { if (b0 + u < nblocks) hist[(size_t)(b0 + u) * g.Npf + a] = run; run += c[u]; }
-    }
-}
-__global__ __launch_bounds__(256) void k_index_scatter(const DeviceGraph g, const int32_t* __restrict__ base) {
-    __shared__ int sfree[IDX_T];
-    const int k0 = blockIdx.x * IDX_T, tid = threadIdx.x;
-    const int n = min(IDX_T, g.No - k0);
-    if (tid < n) sfree[tid] = g.pose_free[g.obs_pose[k0 + tid]];
+    __shared__ int ssum[256];
+    const int per = (nblocks + 255) / 256;
+    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += hist[(size_t)b * g.Npf + a];
+    ssum[tid] = sum;
     __syncthreads();
-    int32_t* pose_obs = const_cast<int32_t*>(g.pose_obs);
-    int32_t* obs_ppos = const_cast<int32_t*>(g.obs_ppos);
-    for (int a = tid; a < g.Npf; a += 256) {
-        int pos = base[(size_t)blockIdx.x * g.Npf + a];
-        for (int i = 0; i < n; ++i)
-            if (sfree[i] == a) { pose_obs[pos] = k0 + i; obs_ppos[k0 + i] = pos; ++pos; }
+    // inclusive scan over the 256 run sums (Hillis-Steele, 8 steps)
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? ssum[tid - off] : 0;
+        __syncthreads();
+        ssum[tid] += v;
+        __syncthreads();
+    }
+    int run = g.chunk_ptr[g.pose_chunk_ptr[a]] + ssum[tid] - sum;
+    for (int b = b0; b < b1; ++b) { const int c = hist[(size_t)b * g.Npf + a]; hist[(size_t)b * g.Npf + a] = run; run += c; }
+}
+// Stable multi-split, second half: observation k of free pose a goes to base[block][a] + (observations of a in the block's earlier
+// wavefronts) + (its rank among the equal-pose lanes below it in its own wavefront) — ballots, one per distinct pose of the wavefront.
+// Also writes the pose-major landmark list (pose_lm) the pair builder searches.
+__global__ __launch_bounds__(256) void k_index_scatter(const DeviceGraph g, const int32_t* __restrict__ base) {
+    extern __shared__ int wcnt[];                                             // [4][Npf]
+    const int k0 = blockIdx.x * IDX_T, tid = threadIdx.x, k = k0 + tid;
+    const int n = min(IDX_T, g.No - k0);
+    for (int q = tid; q < 4 * g.Npf; q += 256) wcnt[q] = 0;
+    __syncthreads();
+    const int a = tid < n ? g.pose_free[g.obs_pose[k]] : -1;
+    const int lane = tid & 63, wave = tid >> 6;
+    int rank = 0;
+    {
+        unsigned long long todo = __ballot(a >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int key = __shfl(a, leader);
+            const unsigned long long m = __ballot(a == key);
+            if (a == key) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == leader) wcnt[wave * g.Npf + key] = __popcll(m);
+            todo &= ~m;
+        }
+    }
+    __syncthreads();
+    if (a >= 0) {
+        int pos = base[(size_t)blockIdx.x * g.Npf + a] + rank;
+        for (int w = 0; w < wave; ++w) pos += wcnt[w * g.Npf + a];
+        const_cast<int32_t*>(g.pose_obs)[pos] = k;
+        const_cast<int32_t*>(g.obs_ppos)[k] = pos;
+        g.pose_lm[pos] = g.obs_pt[k];
     }
 }
 
-__global__ __launch_bounds__(256) void k_pose_landmarks(const DeviceGraph g) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < g.n_pose_obs) g.pose_lm[t] = g.obs_pt[g.pose_obs[t]];
-}
-
+// Co-observation pairs of every block (i <= j) of S: the observations of pose i whose (free) landmark pose j sees too, in pose i's order.
+// One wavefront per block.  Pose j's landmark list (ascending: observations are landmark-major) is staged in LDS once and every
+// observation of pose i runs a branch-free lower-bound search in it, PAIR_U searches in flight per lane — with the list in HBM the ten
+// dependent loads of a search were the whole 44 us of this kernel at C2 (one wave per block: latency, not bandwidth).  Lists longer
+// than PAIR_LDS entries are searched in HBM as before.
+constexpr int PAIR_LDS = 4096;        // entries of pose j's list per wavefront (16 KB; four wavefronts per workgroup)
+constexpr int PAIR_U = 8;
 __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int slist[4 * PAIR_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
     if (b >= g.n_blk) return;
     const int i = g.blk_i[b], j = g.blk_j[b];
     const int sA = g.chunk_ptr[g.pose_chunk_ptr[i]], eA = g.chunk_ptr[g.pose_chunk_ptr[i + 1]];
@@ -1066,25 +1107,46 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
     int base = g.blk_ptr[b];
     const int end = g.blk_ptr[b + 1];
     if (base == end) return;                              // a block that exists for its odometry edge only
+    const int nB = eB - sB;
     int top = 1;                                          // largest power of two <= |B| (uniform trip count of the search)
-    while (2 * top <= eB - sB) top *= 2;
-    constexpr int U = 4;                                  // observations per lane and round: U independent searches in flight
+    while (2 * top <= nB) top *= 2;
+    int* const mine = slist + wave * PAIR_LDS;
+    const bool in_lds = (i != j) && nB <= PAIR_LDS;
+    if (in_lds) {
+        for (int q = lane; q < nB; q += 64) mine[q] = g.pose_lm[sB + q];
+        __builtin_amdgcn_s_waitcnt(0);                    // (one wavefront reads what it wrote: no barrier, the stores only have to have left)
+        __builtin_amdgcn_wave_barrier();
+    }
+    constexpr int U = PAIR_U;
     for (int t0 = sA; t0 < eA; t0 += 64 * U) {
         int k1[U], l[U], lo[U];
         bool cand[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = t0 + 64 * u + lane;
-            cand[u] = false; k1[u] = 0; l[u] = 0; lo[u] = sB;
-            if (t < eA) { k1[u] = VISFS_BA_POSE_SEEDS ? t : g.pose_obs[t]; l[u] = g.pose_lm[t]; cand[u] = !g.pt_fixed[l[u]]; }
+            k1[u] = 0; l[u] = 0; lo[u] = 0;
+            if (t < eA) { k1[u] = VISFS_BA_POSE_SEEDS ? t : g.pose_obs[t]; l[u] = g.pose_lm[t]; }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cand[u] = (t0 + 64 * u + lane < eA) && !g.pt_fixed[l[u]];
         // lower bound of l in pose j's landmark list, branch-free: lo ends at the first entry >= l
         if (i != j) {
-            for (int step = top; step >= 1; step >>= 1) {
+            if (in_lds) {
+                for (int step = top; step >= 1; step >>= 1) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int probe = lo[u] + step - 1;
-                    if (cand[u] && probe < eB && g.pose_lm[probe] < l[u]) lo[u] += step;
+                    for (int u = 0; u < U; ++u) {
+                        const int probe = lo[u] + step - 1;
+                        const int v = mine[probe < nB ? probe : nB - 1];
+                        if (cand[u] && probe < nB && v < l[u]) lo[u] += step;
+                    }
+                }
+            } else {
+                for (int step = top; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int probe = lo[u] + step - 1;
+                        if (cand[u] && probe < nB && g.pose_lm[sB + probe] < l[u]) lo[u] += step;
+                    }
                 }
             }
         }
@@ -1092,7 +1154,10 @@ __global__ __launch_bounds__(256) void k_build_pairs(const DeviceGraph g) {
         for (int u = 0; u < U; ++u) {
             bool m = cand[u];
             int k2 = k1[u];
-            if (i != j) { m = m && lo[u] < eB && g.pose_lm[lo[u]] == l[u]; if (m) k2 = VISFS_BA_POSE_SEEDS ? lo[u] : g.pose_obs[lo[u]]; }
+            if (i != j) {
+                m = m && lo[u] < nB && (in_lds ? mine[lo[u] < nB ? lo[u] : 0] : g.pose_lm[sB + (lo[u] < nB ? lo[u] : 0)]) == l[u];
+                if (m) k2 = VISFS_BA_POSE_SEEDS ? sB + lo[u] : g.pose_obs[sB + lo[u]];
+            }
             const unsigned long long mask = __ballot(m);
             if (m) {
                 const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
@@ -3849,14 +3914,15 @@ static void launch_phase_end_src(const Src& src, const LaunchDims& d, int B, int
 // ---- single window
 void launch_build_index(const DeviceGraph& g, int32_t* hist, hipStream_t s) {
     const int nblocks = (g.No + IDX_T - 1) / IDX_T;
-    if (nblocks > 0) hipLaunchKernelGGL(k_index_count, dim3(nblocks), dim3(256), 0, s, g, hist);
-    hipLaunchKernelGGL(k_index_scan, dim3(std::max(1, (g.Npf + 255) / 256)), dim3(256), 0, s, g, hist, nblocks);
-    if (nblocks > 0) hipLaunchKernelGGL(k_index_scatter, dim3(nblocks), dim3(256), 0, s, g, hist);
+    const size_t lds = (size_t)4 * std::max(g.Npf, 1) * sizeof(int);          // per-wavefront pose counts (<= 16 KB at 1024 free poses)
+    ensure_lds(k_index_count, lds); ensure_lds(k_index_scatter, lds);      // (beyond 64 KB: more than 4096 free poses)
+    if (nblocks > 0) hipLaunchKernelGGL(k_index_count, dim3(nblocks), dim3(256), lds, s, g, hist);
+    hipLaunchKernelGGL(k_index_scan, dim3(std::max(1, g.Npf)), dim3(256), 0, s, g, hist, nblocks);
+    if (nblocks > 0) hipLaunchKernelGGL(k_index_scatter, dim3(nblocks), dim3(256), lds, s, g, hist);
 }
 int index_blocks(int No) { return (No + IDX_T - 1) / IDX_T; }
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
     if (g.n_blk <= 0) return;
-    if (g.n_pose_obs > 0) hipLaunchKernelGGL(k_pose_landmarks, dim3((g.n_pose_obs + 255) / 256), dim3(256), 0, s, g);
     hipLaunchKernelGGL(k_build_pairs, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
 }
 void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 0, s); }
