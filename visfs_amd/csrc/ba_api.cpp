@@ -468,6 +468,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
 
     // pose-major chunks
     std::vector<int32_t> chunk_pose, chunk_ptr, pose_chunk_ptr(Npf + 1, 0);
+    chunk_pose.reserve((size_t)cnt[Npf] / LIN_CHUNK + Npf + 1); chunk_ptr.reserve((size_t)cnt[Npf] / LIN_CHUNK + Npf + 2);
     for (int a = 0; a < Npf; ++a) {
         pose_chunk_ptr[a] = (int32_t)chunk_pose.size();
         for (int s = cnt[a]; s < cnt[a + 1]; s += LIN_CHUNK) { chunk_pose.push_back(a); chunk_ptr.push_back(s); }
@@ -478,19 +479,26 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     // k_linearize reads [chunk_ptr[c], chunk_ptr[c+1]) — consecutive chunks are contiguous: chunk c of pose a ends where the next starts
     for (int c = 0; c + 1 < n_chunks; ++c) if (chunk_ptr[c + 1] != std::min(chunk_ptr[c] + LIN_CHUNK, cnt[chunk_pose[c] + 1])) return bad(h, "internal: chunk layout");
 
-    // odometry incidence
+    // odometry incidence (per free pose: its edges in edge order, 2e = as `from`, 2e + 1 = as `to`; counting pass, then fill — no
+    // per-pose containers: this section runs on the caller's thread between the graph build and the first launch)
     std::vector<int32_t> pose_odo_ptr(Npf + 1, 0), pose_odo;
     {
-        std::vector<std::vector<int32_t>> inc(Npf);
         for (int e = 0; e < Ne; ++e) {
             const int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
-            if (a >= 0) inc[a].push_back(2 * e);
-            if (b >= 0) inc[b].push_back(2 * e + 1);
+            if (a >= 0) pose_odo_ptr[a + 1]++;
+            if (b >= 0) pose_odo_ptr[b + 1]++;
         }
         // the laser edges' aggregate lives in slot Ne of odo_blk as the "from" side of a pseudo edge (added last, as g2o does)
-        if (Nz > 0) inc[pose_free[gr->laser_pose]].push_back(2 * Ne);
-        for (int a = 0; a < Npf; ++a) { pose_odo_ptr[a] = (int32_t)pose_odo.size(); pose_odo.insert(pose_odo.end(), inc[a].begin(), inc[a].end()); }
-        pose_odo_ptr[Npf] = (int32_t)pose_odo.size();
+        if (Nz > 0) pose_odo_ptr[pose_free[gr->laser_pose] + 1]++;
+        for (int a = 0; a < Npf; ++a) pose_odo_ptr[a + 1] += pose_odo_ptr[a];
+        pose_odo.resize(pose_odo_ptr[Npf]);
+        std::vector<int32_t> at(pose_odo_ptr.begin(), pose_odo_ptr.end() - 1);
+        for (int e = 0; e < Ne; ++e) {
+            const int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
+            if (a >= 0) pose_odo[at[a]++] = 2 * e;
+            if (b >= 0) pose_odo[at[b]++] = 2 * e + 1;
+        }
+        if (Nz > 0) pose_odo[at[pose_free[gr->laser_pose]]++] = 2 * Ne;
     }
 
     // S block structure (g2o buildStructure analogue): per block (i<=j) the co-observation pairs
@@ -503,6 +511,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         has_odo[(size_t)a * Npf + b] = 1;
     }
     std::vector<int32_t> blk_i, blk_j, blk_ptr(1, 0), blk_of((size_t)Npf * Npf, -1);
+    blk_i.reserve((size_t)Npf * 16); blk_j.reserve((size_t)Npf * 16); blk_ptr.reserve((size_t)Npf * 16 + 1);
     int64_t npairs = 0;
     for (int a = 0; a < Npf; ++a)
         for (int b = a; b < Npf; ++b) {
@@ -517,32 +526,31 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         }
     const int n_blk = (int)blk_i.size();
     std::vector<int32_t> blk_odo_ptr(n_blk + 1, 0), blk_odo;
-    {
-        std::vector<std::vector<int32_t>> inc(n_blk);
-        for (int e = 0; e < Ne; ++e) {
+    if (Ne > 0) {
+        // Aij is (row = from, col = to): stored block is (min,max); transposed when from > to
+        auto slot = [&](int e, int& code) {
             const int a = pose_free[gr->odo_from[e]], b = pose_free[gr->odo_to[e]];
-            if (a < 0 || b < 0) continue;
-            // Aij is (row = from, col = to): stored block is (min,max); transposed when from > to
-            if (a < b) inc[blk_of[(size_t)a * Npf + b]].push_back(2 * e);
-            else inc[blk_of[(size_t)b * Npf + a]].push_back(2 * e + 1);
-        }
-        for (int b = 0; b < n_blk; ++b) { blk_odo_ptr[b] = (int32_t)blk_odo.size(); blk_odo.insert(blk_odo.end(), inc[b].begin(), inc[b].end()); }
-        blk_odo_ptr[n_blk] = (int32_t)blk_odo.size();
+            if (a < 0 || b < 0) return -1;
+            if (a < b) { code = 2 * e; return (int)blk_of[(size_t)a * Npf + b]; }
+            code = 2 * e + 1; return (int)blk_of[(size_t)b * Npf + a];
+        };
+        int code = 0;
+        for (int e = 0; e < Ne; ++e) { const int b = slot(e, code); if (b >= 0) blk_odo_ptr[b + 1]++; }
+        for (int b = 0; b < n_blk; ++b) blk_odo_ptr[b + 1] += blk_odo_ptr[b];
+        blk_odo.resize(blk_odo_ptr[n_blk]);
+        std::vector<int32_t> at(blk_odo_ptr.begin(), blk_odo_ptr.end() - 1);
+        for (int e = 0; e < Ne; ++e) { const int b = slot(e, code); if (b >= 0) blk_odo[at[b]++] = code; }
     }
-    // block-row adjacency of the symmetric S for the mat-vec
+    // block-row adjacency of the symmetric S for the mat-vec: row r = its transposed blocks (i < r, code 2b + 1) in ascending i, then its
+    // own blocks (j >= r, code 2b) in ascending j — the blocks are enumerated in (i, j) order, so both halves arrive sorted by column
     std::vector<int32_t> row_ptr(Npf + 1, 0), row_col, row_blk;
     {
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> adj(Npf);
-        for (int b = 0; b < n_blk; ++b) {
-            adj[blk_i[b]].push_back({ blk_j[b], 2 * b });
-            if (blk_i[b] != blk_j[b]) adj[blk_j[b]].push_back({ blk_i[b], 2 * b + 1 });
-        }
-        for (int a = 0; a < Npf; ++a) {
-            std::sort(adj[a].begin(), adj[a].end());
-            row_ptr[a] = (int32_t)row_col.size();
-            for (auto& pr : adj[a]) { row_col.push_back(pr.first); row_blk.push_back(pr.second); }
-        }
-        row_ptr[Npf] = (int32_t)row_col.size();
+        for (int b = 0; b < n_blk; ++b) { row_ptr[blk_i[b] + 1]++; if (blk_i[b] != blk_j[b]) row_ptr[blk_j[b] + 1]++; }
+        for (int a = 0; a < Npf; ++a) row_ptr[a + 1] += row_ptr[a];
+        row_col.resize(row_ptr[Npf]); row_blk.resize(row_ptr[Npf]);
+        std::vector<int32_t> at(row_ptr.begin(), row_ptr.end() - 1);
+        for (int b = 0; b < n_blk; ++b) if (blk_i[b] != blk_j[b]) { const int r = blk_j[b]; row_col[at[r]] = blk_i[b]; row_blk[at[r]] = 2 * b + 1; at[r]++; }
+        for (int b = 0; b < n_blk; ++b) { const int r = blk_i[b]; row_col[at[r]] = blk_j[b]; row_blk[at[r]] = 2 * b; at[r]++; }
     }
 
     // Schur chunks: <= SCH_CHUNK co-observation pairs of one block per wavefront
@@ -557,6 +565,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     { const char* e = std::getenv("VISFS_BA_SCH_PASSES"); if (e) { const int q = std::atoi(e); if (q >= 1 && q <= 8) sch_passes = q; } }
     const int sch_chunk = SCH_CHUNK * sch_passes;
     std::vector<int32_t> blk_chunk_ptr(n_blk + 1, 0), sch_blk, sch_ptr;
+    sch_blk.reserve((size_t)(npairs / sch_chunk) + n_blk + 1); sch_ptr.reserve((size_t)(npairs / sch_chunk) + n_blk + 1);
     for (int b = 0; b < n_blk; ++b) {
         blk_chunk_ptr[b] = (int32_t)sch_blk.size();
         for (int e = blk_ptr[b]; e < blk_ptr[b + 1]; e += sch_chunk) { sch_blk.push_back(b); sch_ptr.push_back(e); }
@@ -984,7 +993,9 @@ int batch_members_per_launch(visfs_ba_handle* h, const std::vector<Workspace*>& 
 }
 
 // Optimizer.cpp:261-318 on the resident graph.
-int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
+// fresh_upload: the caller has just uploaded this window and nothing has touched it since (the window layer) — the upload's own k_reset has
+// left exactly the state the reset below would produce.
+int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const bool fresh_upload = false) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
     // g2o branch: optimize(iterations / 2) twice (Optimizer.cpp:265,311); Ceres branch: one Solve with max_num_iterations = iterations (:521)
@@ -992,7 +1003,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats) {
     PcgLease pcg_lease;                                                                         // persistent PCG: co-residency budget of the device
     if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lease.acquire(h->device, pcg_wave_cost(dims_of(w.g), 1));
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
-    { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
+    if (!(fresh_upload && w.solves_since_upload == 0)) { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     if (w.fused) {
         // small window: both phases, the outlier pass and the final evaluation in one launch of one workgroup
         { ProfScope p(w, VISFS_BA_K_SMALL); launch_small_optimize(w.g, h->prm.solver, half, w.stream); }
@@ -1502,7 +1513,7 @@ int solve_window_on(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win
     lap("prepare");
     visfs_ba_stats st;
     w.want_outputs = true;                          // the outputs travel with the solve's state read
-    const int rc = ws_optimize(h, w, &st);
+    const int rc = ws_optimize(h, w, &st, /*fresh_upload=*/true);
     w.want_outputs = false;
     lap("optimize");
     const int rcf = finish_window(h, w, win, r, pk, rc, st, host_pool(h));
