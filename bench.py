@@ -276,6 +276,13 @@ def main():
                                      "frac": round(rate / 8000.0, 4), "floor_us_per_iteration": round(byts / 8e6, 2),
                                      "window_us_per_iteration": round(1e6 * elapsed * world * B / total_iters, 2),
                                      "aggregate_us_per_iteration_per_gpu": round(1e6 * elapsed * world / total_iters, 2)}
+    if world == 1 and B == 1:
+        # the drop-in's real call (Estimator.cpp:254): host buffers in, results out, one handle across frames — reported beside the
+        # resident headline, never as `value` (it crosses PCIe both ways)
+        try:
+            out["per_frame_call"] = per_frame_call(args, prm)
+        except Exception as e:
+            out["per_frame_call"] = {"error": str(e)[:120]}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, prm)
         # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
@@ -389,6 +396,29 @@ def pmc_traffic(config, kernel):
         return None
     except (KeyError, ValueError):
         return None
+
+
+def per_frame_call(args, prm, calls=24):
+    """visfs_ba_solve_window on ONE handle, `calls` times after 3 warm-up calls: graph build on the host threads, upload, index build,
+    the whole optimisation, write-back.  The caller's input and output buffers exist before the clock starts."""
+    from visfs_amd import abi, backend, synth
+    w = synth.make_window(args.config, window_index=0)
+    s = backend.Solver(prm)
+    n = calls if len(w["ref_feature"]) < 200000 else max(6, calls // 3)
+    wbs = [abi.WindowBuffers(w) for _ in range(n + 3)]
+    rbs = [abi.ResultBuffers(wb.struct.n_poses, wb.struct.n_refs) for wb in wbs]
+    for r in rbs:
+        r.outlier_feature[:] = 1; r.outlier_pose[:] = 1            # touched pages
+    for i in range(3):
+        s.solve_window(wbs[i], rbs[i])
+    t0 = time.perf_counter()
+    for i in range(n):
+        rc, rb = s.solve_window(wbs[3 + i], rbs[3 + i])
+    dt = (time.perf_counter() - t0) / n
+    its = int(rb.struct.iterations_run[0] + rb.struct.iterations_run[1])
+    s.close()
+    return {"ms_per_call": round(1e3 * dt, 4), "calls": n, "status": int(rc), "outer_iterations": its,
+            "iterations_per_s_incl_pcie": round(its / dt, 1), "host_threads": os.environ.get("VISFS_BA_THREADS", "default")}
 
 
 def cpu_baseline(args, prm):
