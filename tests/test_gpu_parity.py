@@ -579,6 +579,38 @@ def test_speculative_unit_equals_gated_unit(olib, monkeypatch, case):
         assert sum(st0.trials_run) > sum(st0.iterations_run)          # the window really rejects trials
 
 
+@pytest.mark.parametrize("case", ["C1", "PROD", "LASER", "HARD", "GN", "C3", "C2", "RAGGED", "S0"])
+def test_fused_speculative_unit_equals_the_two_launch_form_and_the_gated_unit(olib, monkeypatch, case):
+    """Round 3: the speculative unit's tail in ONE launch (k_backsub<LINA>: back-substitution, LM decision, role A of the trial's
+    linearisation; its pose-major role rides behind the next Schur gather) against the two-launch form it replaces and the gated
+    unit: every output, counter and trace entry bit-identical — rejected trials (HARD), Gauss-Newton, odometry (C3), laser, the direct
+    solver (S0) and ragged tracks included."""
+    kw = dict(iterations=20, solver=2)
+    if case == "LASER":
+        w = synth.make_laser_window(with_visual=True, n_points=400)
+    elif case == "HARD":
+        w = hard_window()
+    elif case == "RAGGED":
+        w = ragged_window(seed=7)
+    elif case == "GN":
+        w = synth.make_window("C1"); kw["trust_region"] = 1
+    elif case == "S0":
+        w = synth.make_window("C1"); kw["solver"] = 0
+    elif case == "C3":
+        w = synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400)
+    else:
+        w = synth.make_window(case)
+    _, rc0, st0, out0 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="0"), **kw)
+    _, rc1, st1, out1 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="1", VISFS_BA_SPEC_FUSED="0"), **kw)
+    _, rc2, st2, out2 = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SPEC="1", VISFS_BA_SPEC_FUSED="1"), **kw)
+    assert rc0 == rc1 == rc2 == abi.OK
+    assert _stats_tuple(st0) == _stats_tuple(st1) == _stats_tuple(st2)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out0, out2))
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out1, out2))
+    if case == "HARD":
+        assert sum(st0.trials_run) > sum(st0.iterations_run)
+
+
 @pytest.mark.parametrize("case", ["C1", "LASER", "HARD", "GN", "C3"])
 def test_decision_on_board_backsub_equals_separate_decide_launch(olib, monkeypatch, case):
     """The gated unit (batched windows, large windows, VISFS_BA_SPEC=0): one workgroup of k_backsub waits for the partial sums of all

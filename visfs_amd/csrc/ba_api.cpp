@@ -101,6 +101,7 @@ struct Workspace {
     bool outputs_staged = false;                   // ... they are in the staging arena (both estimate buffers; LmState::sel picks)
     int batch_hint = 1;                            // windows of the batch this workspace was uploaded for (kernel choices that depend on it)
     bool spec = false;                             // units end with the speculative linearisation + LM decision launch
+    bool spec_fused = false;                       // ... fused into the back-substitution launch, pose-major role deferred to the next Schur gather (k_backsub<LINA>)
     bool fused_decide = true;                      // gated units: k_backsub carries the LM decision (VISFS_BA_DECIDE_FUSED=0: k_decide, A/B runs and tests)
     int extra_units[2] = { 0, 0 };                 // rejected trials per phase of the previous solve: units enqueued on top of `half`
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
@@ -818,6 +819,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     // Optimizer/Framework=1 runs the plain gated unit with the direct solver (k_small_solve's Cholesky for reduced systems <= 64 x 64):
     // one unit = one iteration of Ceres' minimizer loop
     if (ceres) { w.fused = false; w.spec = false; }
+    // the fused form of the speculative unit: one launch less per iteration (VISFS_BA_SPEC_FUSED=0: the two-launch form, A/B runs and tests)
+    { const char* e = std::getenv("VISFS_BA_SPEC_FUSED"); w.spec_fused = w.spec && !(e && e[0] == '0'); }
     // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
     { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
     w.n_pairs = npairs; w.device_bytes = total_bytes + pbytes;
@@ -880,7 +883,7 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     if (!w.spec || first) { ProfScope p(w, VISFS_BA_K_LINEARIZE, w.g.Ne == 0 && w.g.Nz == 0); launch_linearize(w.g, w.stream); }
     if (w.g.ceres) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_ceres_lin_finalize(w.g, w.stream); }
     else if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_lin_finalize(w.g, 0, w.stream); }
-    { ProfScope p(w, VISFS_BA_K_SCHUR, true); launch_schur_partial(w.g, w.stream); }
+    { ProfScope p(w, VISFS_BA_K_SCHUR, true); if (w.spec_fused && !first) launch_schur_partial_roleb(w.g, w.stream); else launch_schur_partial(w.g, w.stream); }
     if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, h->prm.solver, w.stream); }
     else {
         { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
@@ -894,6 +897,7 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
         { ProfScope p(w, VISFS_BA_K_DECIDE, true); launch_decide(w.g, w.stream); }
         return;
     }
+    if (w.spec_fused) { ProfScope p(w, VISFS_BA_K_BACKSUB, true); launch_backsub_lin_decide(w.g, w.stream); return; }
     const bool fused_decide = w.fused_decide;     // the gated unit: the LM decision rides on k_backsub
     {   ProfScope p(w, VISFS_BA_K_BACKSUB, true);
         if (w.spec && (w.g.Ne > 0 || w.g.Nz > 0)) launch_backsub_odospec(w.g, w.stream);
@@ -1089,7 +1093,8 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const b
     if (stats) fill_stats(*w.h_state, stats);
     if (w.prof_mask) {
         const LmState& st = *w.h_state;
-        w.active[VISFS_BA_K_LINEARIZE] += w.spec ? st.n_active[3] + (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0) : st.n_active[0];
+        w.active[VISFS_BA_K_LINEARIZE] += w.spec_fused ? (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0)
+                                          : w.spec ? st.n_active[3] + (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0) : st.n_active[0];
         w.active[VISFS_BA_K_LIN_FINALIZE] += (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0);
         w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_SCHUR_FINALIZE] += st.n_active[1];
         if (!w.spec && !w.fused_decide) w.active[VISFS_BA_K_DECIDE] += st.n_active[1];

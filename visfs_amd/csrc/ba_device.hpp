@@ -73,6 +73,8 @@ struct LmState {
     int32_t spec_go;        // snapshot by k_backsub: this unit produced a trial state worth linearising
     int32_t spec_src;       // ... the estimate buffer holding it (sel ^ 1 at that time)
     int32_t spec_dst;       // ... the linearisation buffer to fill (lin_sel ^ 1 at that time)
+    int32_t lin_b_pending;  // fused speculative unit: the accepted trial's landmark-major linearisation is complete (k_backsub<LINA>), its pose-major
+                            // sums (hpp_part) are still to come — the role-B workgroups of the next k_schur_partial launch produce them
     int32_t ended;          // phase ends applied so far (0, 1, 2): k_eval / k_phase_end act only when the phase they close is done
     int32_t pcg_phase1;     // pcg_total when phase 1 ended
     int32_t n_edges_ok;     // stereo edges that can ever be active (not both ends fixed): the active set of phase 1

@@ -325,13 +325,15 @@ __device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k
 template <int G, bool STG = true>
 __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> P,
                                              const double* __restrict__ pt, const Intrinsics& K, const double iv, const double delta,
-                                             double& chi_acc, double& md, double* xn_acc = nullptr) {
+                                             double& chi_acc, double& md, double* xn_acc = nullptr, const Vec3* pw_reg = nullptr) {
     int k0 = 0, k1 = 0;
     Vec3 pw{ 0, 0, 0 };
     bool lfree = false;
     if (lvalid) {
         k0 = g.lm_ptr[l]; k1 = g.lm_ptr[l + 1];
-        pw = Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
+        // (pw_reg: the caller has the landmark in registers — k_backsub<LINA> linearises the trial landmark its own lanes have just formed;
+        // reading it back from pt would race with the one lane of the group that stores it)
+        pw = pw_reg ? *pw_reg : Vec3{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
         lfree = !g.pt_fixed[l];
     }
     // Optimizer/Framework=1: this pass also feeds the minimizer's bookkeeping (k_ceres_lin_finalize only adds the partials up): md
@@ -425,7 +427,8 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
 // The scalar half of [g2o-upstream] OptimizationAlgorithmLevenberg::solve (and the Gauss-Newton variant): one thread.
 // ok = the linear solve succeeded; chi / sc = robust chi2 at the trial state and computeScale's sum.
 // spec: the accepted trial's linearisation is already in the other buffer set (speculative linearise): flip lin_sel with sel.
-__host__ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc, const bool spec) {
+__host__ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, const double lambda, const double chi, const double sc, const int spec) {
+    st->lin_b_pending = 0;
     const int ph = st->phase;
     st->trials_run[ph] += 1;
     st->solver_failed = 0;
@@ -433,7 +436,7 @@ __host__ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, c
     if (st->pcg_timeout) { st->status = 8; st->done = 1; st->mode = 0; return; }     // VISFS_BA_ERR_DEVICE
     if (st->gauss_newton) {
         // OptimizationAlgorithmGaussNewton: always take the step; Fail ends the phase
-        if (ok) { st->sel ^= 1; if (spec) st->lin_sel ^= 1; }
+        if (ok) { st->sel ^= 1; if (spec) st->lin_sel ^= 1; if (spec == 2) st->lin_b_pending = 1; }
         if (st->n_trace < MAX_TRACE) { st->trace_lambda[st->n_trace] = 0.0; st->trace_chi2[st->n_trace] = st->current_chi; st->n_trace++; }
         if (ok) st->current_chi = chi;
         st->phase_iter += 1; st->iterations_run[ph] = st->phase_iter;
@@ -454,6 +457,7 @@ __host__ __device__ __forceinline__ void lm_decide(LmState* st, const bool ok, c
         st->current_chi = tempChi;
         st->sel ^= 1;                               // discardTop: the trial becomes the estimate
         if (spec) st->lin_sel ^= 1;
+        if (spec == 2) st->lin_b_pending = 1;
         st->trial_q += 1;
         iteration_over = true;
     } else {
@@ -574,7 +578,7 @@ __device__ __forceinline__ void ceres_decide_role(const DeviceGraph& g, LmState*
     ceres_decide(st, ok && finite_step, chi, sc, sqrt(n2));
 }
 
-__device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc, false); }
+__device__ __noinline__ void lm_decide_call(LmState* st, const bool ok, const double lambda, const double chi, const double sc) { lm_decide(st, ok, lambda, chi, sc, 0); }
 
 // The k_decide role: 256 threads sum the trial's chi2 / computeScale partials, thread 0 steps the LM state machine.
 __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, double* red, const bool spec) {
@@ -591,7 +595,7 @@ __device__ __forceinline__ void decide_role(const DeviceGraph& g, LmState* st, d
     sc = block_sum_256(sc, red);
     if (g.ceres) { ceres_decide_role(g, st, ok, chi, g.dogleg ? 2.0 * st->dl_mcc : sc, red); return; }   // (dogleg: the model cost change of k_dogleg_mid)
     if (tid != 0) return;
-    lm_decide(st, ok, lambda, chi, sc, spec);
+    lm_decide(st, ok, lambda, chi, sc, spec ? 1 : 0);
 }
 
 // The decision on board k_backsub (DEC): every workgroup publishes its two partial sums as hand-off words {tag:32 | half of a
@@ -612,7 +616,7 @@ __device__ __forceinline__ void publish_trial(const DeviceGraph& g, const int w,
 // thread, fetched again after a pause while a tag is missing — add them in decide_role's order and step the LM state
 // machine.  LmState is written only here, after every workgroup has published, i.e. after every workgroup has read its gate and
 // its lambda / sel.  A wait that never ends (never expected) surfaces like a PCG hand-off time-out: VISFS_BA_ERR_DEVICE.
-__device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, double* red) {
+__device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState* st, const unsigned ep, const bool ok, double* red, const int spec = 0) {
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const double lambda = st->lambda;
@@ -651,7 +655,7 @@ __device__ __forceinline__ void decide_gather_role(const DeviceGraph& g, LmState
     bad = __syncthreads_or(bad);
     if (tid != 0) return;
     if (bad) st->pcg_timeout = 1;
-    lm_decide(st, ok && !bad, lambda, chi, sc, false);
+    lm_decide(st, ok && !bad, lambda, chi, sc, spec);
     st->decide_epoch = ep;
 }
 // The deciders of a launch sit in its last grid row, behind the working workgroups: gridDim.x = working workgroups + gridDim.y,
@@ -662,12 +666,12 @@ __device__ __forceinline__ int decider_window() {
     return (blockIdx.y == gridDim.y - 1) ? (int)blockIdx.x - working : -2;          // -2: an idle filler of the rectangular grid
 }
 // The decider of window j.
-__device__ __forceinline__ void decider_run(const DeviceGraph& gd, double* red) {
+__device__ __forceinline__ void decider_run(const DeviceGraph& gd, double* red, const int spec = 0) {
     LmState* sd = gd.st;
-    if (sd->mode & MODE_TRIAL) decide_gather_role(gd, sd, sd->decide_epoch + 1u, !sd->solver_failed && !sd->pcg_timeout, red);
+    if (sd->mode & MODE_TRIAL) decide_gather_role(gd, sd, sd->decide_epoch + 1u, !sd->solver_failed && !sd->pcg_timeout, red, spec);
 }
-__device__ __forceinline__ void decider_of(const One& s, int, double* red) { decider_run(s.g, red); }
-__device__ __forceinline__ void decider_of(const Many& s, const int j, double* red) { decider_run(s.gs[j], red); }
+__device__ __forceinline__ void decider_of(const One& s, int, double* red, const int spec = 0) { decider_run(s.g, red, spec); }
+__device__ __forceinline__ void decider_of(const Many& s, const int j, double* red, const int = 0) { decider_run(s.gs[j], red); }
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
 // spec = 0: linearise the committed estimate (first unit of a phase, stage hooks, large windows) when the gate says so.
@@ -1297,18 +1301,48 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     schur_chunk<MULTI>(g, L, ch, lane, lambda, pose, dsc, e < dsc.y ? g.blk_pairs[e] : make_int4(0, 0, 0, 0));
 }
 
-template <bool MULTI, class Src, bool CERES = false>
+// ROLEB (single window, fused speculative unit): the workgroups behind this window's share of the chunk list are the pose-major role of
+// the linearisation the previous unit's k_backsub<LINA> left half done (LmState::lin_b_pending): upper triangle of Jx^T (rho' Omega) Jx
+// and -Jx^T (rho' Omega) e per chunk of a pose's observations, at the committed estimate, into the current set's hpp_part — read by
+// k_schur_finalize / k_small_solve, the launch after this one.
+template <bool MULTI, class Src, bool CERES = false, bool ROLEB = false>
 __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src src) {
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     const int lane = threadIdx.x & 63;
+    // (role B sits BEHIND the gather in dispatch order: in front of it — measured — it delays the chunk workgroups, which are the launch's
+    // critical path, and costs C2 4 %; behind it the launch is 1.5 us longer than the plain gather)
+    if (ROLEB) {
+        const int first_b = (((g.n_sch + 3) / 4) + 7) / 8 * 8;
+        if ((int)blockIdx.x >= first_b) {
+            __shared__ double redb[4 * 27];
+            const int c = (int)blockIdx.x - first_b;
+            if (c >= g.n_chunks || !st->lin_b_pending || !(st->mode & MODE_TRIAL)) return;
+            const int tid = threadIdx.x, wave = tid >> 6;
+            const int sel = st->sel;
+            const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
+            const int a = g.chunk_pose[c];
+            const int begin = g.chunk_ptr[c], end = g.chunk_ptr[c + 1];
+            double acc[27];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+            if (begin + tid < end) pose_obs_terms(g, g.pose_obs[begin + tid], pose_to_Rt(g.pose[sel] + POSE_STRIDE * g.free_pose[a]), g.pt[sel], intr_of(g), g.inv_pixel_var, g.huber_delta, acc);
+            int off = 0, len = 27;
+            ReduceScatter<27, 32>::run(acc, lane, off, len);
+            if (len >= 1) redb[wave * 27 + off] = acc[0];
+            __syncthreads();
+            if (tid < 27) L.hpp_part[27 * (size_t)c + tid] = redb[tid] + redb[27 + tid] + redb[54 + tid] + redb[81 + tid];
+            return;
+        }
+    }
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, chunks are sorted by block row, so give
     // every XCD one contiguous slice of the chunk list: the tiles of a block row are then served by ONE 4 MiB L2
     // instead of eight (speed only; any placement is correct).  gridDim.x is a multiple of 8.
     const int nwg = (((g.n_sch + 3) / 4) + 7) / 8 * 8;        // this window's share of the launch (== gridDim.x for a single window)
-    if ((int)blockIdx.x >= nwg) return;
+    const int bx = (int)blockIdx.x;
+    if (bx >= nwg) return;
     const int per_xcd = nwg >> 3;
-    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int wg = (bx & 7) * per_xcd + (bx >> 3);
     const int ch = wg * 4 + (threadIdx.x >> 6);
     if (ch >= g.n_sch) return;
     // the chunk descriptor and the lane's first pair do not depend on the LM state: fetch them BEFORE the gate, so the gate's own
@@ -2806,7 +2840,7 @@ template <int G, bool STG = true, int DL = 0>
 __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const LinBuf& L, const int l, const bool lvalid, const int sub, const PoseSrc<STG> Pt, const PoseSrc<STG> P0,
                                                  const double* __restrict__ pt, double* __restrict__ pt_t, const double lambda, const Intrinsics& K,
                                                  const double iv, const double delta, double& chi_acc, double& scale_acc, double* step_acc = nullptr,
-                                                 double* dot_acc = nullptr, const double dlA = 0.0, const double dlB = 1.0) {
+                                                 double* dot_acc = nullptr, const double dlA = 0.0, const double dlB = 1.0, Vec3* pn_out = nullptr) {
     int k0 = 0, k1 = 0;
     Vec3 pw{ 0, 0, 0 };
     bool lfree = false;
@@ -2877,6 +2911,7 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
         }
     }
     const Vec3 pn{ pw.x + d0, pw.y + d1, pw.z + d2 };         // VertexPointXYZ::oplus
+    if (pn_out) *pn_out = pn;                                // (every lane of the group holds the same value)
     if (lvalid && sub == 0) {
         pt_t[3 * l] = pn.x; pt_t[3 * l + 1] = pn.y; pt_t[3 * l + 2] = pn.z;
         if (DL != 2) { g.dxl[3 * (size_t)l] = d0; g.dxl[3 * (size_t)l + 1] = d1; g.dxl[3 * (size_t)l + 2] = d2; }
@@ -2930,14 +2965,21 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // last ones of the launch, takes the LM decision on the trial (decide_gather_role) — k_decide (6.3 us + a launch gap per unit) leaves.
 // The batched instantiation drifts from 90 to 114 VGPRs with the role on board (one wave per SIMD less for a bandwidth-bound
 // launch): it is held at five waves per SIMD (96 VGPRs, a dozen spill slots outside the loops).
-template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false, int DL = 0>
+// LINA (single window, two linearisation sets; with DEC): the fused tail of the speculative unit — every landmark workgroup, having
+// published its share of the trial's chi2, goes on to linearise ITS landmarks at the trial state into the other set (role A of
+// k_linearize: the trial landmark is in registers, the trial poses are staged), the odometry workgroup does the same for its edges
+// (ODOSPEC), and the decider, which flips lin_sel on acceptance, marks the pose-major sums as pending (LmState::lin_b_pending): they
+// need EVERY trial landmark, so the role-B workgroups of the next k_schur_partial launch form them.  One launch (and its ~5 us of
+// dependent-dispatch latency) less per iteration than k_backsub followed by k_linearize<SPEC>.
+template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false, int DL = 0, bool LINA = false>
 __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void k_backsub(const Src src) {
-    static_assert(!(DEC && ODOSPEC), "the decision rides on the gated unit only");
+    static_assert(!(DEC && ODOSPEC) || LINA, "the decision rides on the gated unit only");
     static_assert(DL == 0 || (!DEC && !ODOSPEC), "the dogleg passes are plain launches");
+    static_assert(!LINA || (DEC && LinSel<Src>::two_sets && DL == 0), "the fused tail is the single-window speculative unit");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (DEC) {
         const int dw = decider_window();
-        if (dw >= 0) { decider_of(src, dw, smem); return; }
+        if (dw >= 0) { decider_of(src, dw, smem, LINA ? 2 : 0); return; }
         if (dw == -2) return;
     }
     const DeviceGraph& g = graph_of(src);
@@ -2948,7 +2990,7 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     // (the tag is read where it is used: nothing of the decision's bookkeeping stays live across the landmark role)
     if (DEC && trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, st->decide_epoch + 1u, 0.0, 0.0);
     // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
-    if (!DEC && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
+    if (!DEC && !LINA && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
     if (!go) return;
     double* sRt = smem;
     double* red = smem + (STG ? 12 * g.Np : 0);
@@ -3019,7 +3061,8 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     const int l = bid * LPW + tid / G, sub = tid % G;
     const bool lvalid = l < g.Nl;
     double chi_acc = 0.0, scale_acc = 0.0, step_acc = 0.0, dot_acc = 0.0;
-    backsub_landmark<G, STG, DL>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc, &step_acc, &dot_acc, st->dl_A, st->dl_B);
+    Vec3 pn{ 0.0, 0.0, 0.0 };
+    backsub_landmark<G, STG, DL>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc, &step_acc, &dot_acc, st->dl_A, st->dl_B, LINA ? &pn : nullptr);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
     if (DL == 1) {
@@ -3029,6 +3072,16 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     }
     if (g.ceres) { const double st_tot = block_sum_256(step_acc, red); if (tid == 0) g.aux_part[bid] = st_tot; }
     if (tid == 0) { if (DEC) publish_trial(g, bid, st->decide_epoch + 1u, chi_tot, sc_tot); else { g.trial_part[2 * bid] = chi_tot; g.trial_part[2 * bid + 1] = sc_tot; } }
+    if (LINA) {
+        // role A of the speculative linearisation for this workgroup's landmarks (LmState is not read from here on: the decider may
+        // already be rewriting it — sel / ls are the values read at the top)
+        const LinSel<Src> lspec(g, ls ^ 1);
+        double chi2 = 0.0, md2 = 0.0;
+        lin_landmark<G, STG>(g, lspec.get(), l, lvalid, sub, Pt, pt_t, K, iv, delta, chi2, md2, nullptr, &pn);
+        const double chi2_tot = block_sum_256(chi2, red);
+        const double md2_tot = block_max_256(md2, red);
+        if (tid == 0) { g.lin_part[2 * bid] = chi2_tot; g.lin_part[2 * bid + 1] = md2_tot; }
+    }
 }
 
 // Between the two dogleg passes (one workgroup): the inner products summed in a fixed order, the step coefficients and the model cost
@@ -3155,7 +3208,7 @@ __device__ __noinline__ void phase_end_update(const DeviceGraph& g, LmState* st,
         st->phase = 1; st->phase_iter = 0; st->max_iter = next_max_iter; st->trial_q = 0;
         st->solver_failed = 0; st->pcg_residual = -1.0;
         st->done = (st->status != 0 || next_max_iter <= 0 || g.huber_delta <= 0.0) ? 1 : 0;
-        st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL);
+        st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->lin_b_pending = 0;
     } else {
         st->chi2_final = chi;
         if (!g.ceres && chi > 1000000000000.0) st->status = 5;           // VISFS_BA_ERR_HUGE_CHI2_2
@@ -3197,7 +3250,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
         if (restore) st->sel = 0;
         st->pcg_max = 0; st->pcg_timeout = 0;
-        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1; st->ended = 0; st->pcg_phase1 = 0; st->n_edges_ok = g.n_edges_ok;
+        st->lin_sel = 0; st->spec_go = 0; st->spec_src = 0; st->spec_dst = 1; st->lin_b_pending = 0; st->ended = 0; st->pcg_phase1 = 0; st->n_edges_ok = g.n_edges_ok;
         st->n_active[0] = st->n_active[1] = st->n_active[2] = st->n_active[3] = 0;
         st->phase = 0; st->max_iter = max_iter; st->phase_iter = 0; st->trial_q = 0;
         st->done = (max_iter <= 0) ? 1 : 0; st->mode = st->done ? 0 : (MODE_LIN | MODE_TRIAL); st->solver_failed = 0;
@@ -3936,6 +3989,33 @@ void launch_backsub(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(On
 void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 1, 0, s); }
 void launch_backsub_decide(const DeviceGraph& g, hipStream_t s) { launch_backsub_src(One{ g }, dims_of(g), 1, 0, 1, s); }
 void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
+// The fused speculative unit (single window, staged poses): its last launch — back-substitution, trial chi2, the LM decision and role A
+// of the trial's linearisation — and its first — the Schur gather with the pending role-B workgroups behind it.
+template <int G>
+static void launch_backsub_lin_t(const DeviceGraph& g, const LaunchDims& d, hipStream_t s) {
+    const One src{ g };
+    const size_t lds = (size_t)std::max(24 * d.np + 8, 128) * sizeof(double);
+    if (d.has_odo) { ensure_lds(k_backsub<G, One, true, true, true, 0, true>, lds); TIMED_LAUNCH((k_backsub<G, One, true, true, true, 0, true>), dim3(d.backsub_blocks + 1, 1), dim3(256), lds, s, src); }
+    else { ensure_lds(k_backsub<G, One, false, true, true, 0, true>, lds); TIMED_LAUNCH((k_backsub<G, One, false, true, true, 0, true>), dim3(d.backsub_blocks + 1, 1), dim3(256), lds, s, src); }
+}
+void launch_backsub_lin_decide(const DeviceGraph& g, hipStream_t s) {
+    const LaunchDims d = dims_of(g);
+    switch (d.group) {
+        case 4: launch_backsub_lin_t<4>(g, d, s); break;
+        case 8: launch_backsub_lin_t<8>(g, d, s); break;
+        case 16: launch_backsub_lin_t<16>(g, d, s); break;
+        case 32: launch_backsub_lin_t<32>(g, d, s); break;
+        default: launch_backsub_lin_t<64>(g, d, s); break;
+    }
+}
+void launch_schur_partial_roleb(const DeviceGraph& g, hipStream_t s) {
+    const LaunchDims d = dims_of(g);
+    const int grid = d.sch_wgs + g.n_chunks;
+    if (grid <= 0) return;
+    const One src{ g };
+    if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, One, false, true>), dim3(grid, 1), dim3(256), 0, s, src);
+    else TIMED_LAUNCH((k_schur_partial<false, One, false, true>), dim3(grid, 1), dim3(256), 0, s, src);
+}
 // Optimizer/Framework=1 with the DOGLEG strategy: pass 1 (Gauss-Newton landmark step + the inner products), the combination, pass 2 (trial state)
 template <int G>
 static void launch_backsub_dogleg_t(const DeviceGraph& g, const LaunchDims& d, int pass, hipStream_t s) {

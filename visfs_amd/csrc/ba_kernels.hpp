@@ -31,6 +31,8 @@ void launch_direct(const DeviceGraph& g, hipStream_t s);             // dense as
 void launch_backsub(const DeviceGraph& g, hipStream_t s);
 void launch_backsub_odospec(const DeviceGraph& g, hipStream_t s);   // speculative unit with odometry / laser edges: also linearises them at the trial poses
 void launch_ceres_lin_finalize(const DeviceGraph& g, hipStream_t s);  // Optimizer/Framework=1: cost, ||g||_inf, ||x||, Jacobi scaling after every linearisation
+void launch_backsub_lin_decide(const DeviceGraph& g, hipStream_t s); // fused speculative unit: back-substitution + LM decision + role A of the trial's linearisation
+void launch_schur_partial_roleb(const DeviceGraph& g, hipStream_t s);  // ... its Schur gather, with the pending pose-major role of that linearisation behind it
 void launch_backsub_decide(const DeviceGraph& g, hipStream_t s);    // gated unit: the launch also takes the LM decision (no k_decide)
 void launch_decide(const DeviceGraph& g, hipStream_t s);
 void launch_backsub_dogleg(const DeviceGraph& g, int pass, hipStream_t s);   // Optimizer/Framework=1 + TrustRegion=1: the two landmark passes of the dogleg step
