@@ -3310,6 +3310,65 @@ __device__ __forceinline__ int ld_state(const int* p) { return __hip_atomic_load
 
 // [g2o-upstream] LinearSolverPCG on the dense S in LDS: wave 0, lane r owns scalar row r (n6 <= 64).  Same recurrence,
 // tolerance and residual carry-over as k_pcg.
+// The same PCG with lane r's row of S in registers and the direction vector broadcast lane by lane with readlanes (uniform indices after
+// unrolling) instead of through LDS: the mat-vec of the LDS form was n6 dependent round trips (two ds_reads, a wait and an FMA per
+// column: 1.2 us per PCG iteration at the production window's order 30).  Same products, same order of the sums: bit-identical.
+// Only instantiated in k_small_solve (the fused kernel keeps the LDS-row version: compile time).
+template <int NMAX>
+__device__ __forceinline__ void sm_pcg_reg(const DeviceGraph& g, LmState* st, const int n6, const double* sA, const double* sb, double* sx) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < n6;
+    const int blk0 = 6 * (r / 6);
+    double m[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) m[c] = act ? g.Minv[36 * (size_t)(r / 6) + 6 * (r % 6) + c] : 0.0;
+    double Arow[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) Arow[c] = (act && c < n6) ? sA[r * SM_LD + c] : 0.0;
+    double rr = act ? sb[r] : 0.0;
+    auto apply_minv = [&](const double v) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sacc += m[c] * __shfl(v, (blk0 + c) & 63, 64);
+        return sacc;
+    };
+    double d = apply_minv(rr);
+    double dn = wave_sum(rr * d);
+    double d0 = 1e-6 * dn;
+    const double res_in = st->pcg_res_in;
+    if (res_in > 0.0 && res_in > d0) d0 = res_in;
+    double x = 0.0;
+    int iter = 0;
+    while (true) {
+        if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
+        double q = 0.0;
+#pragma unroll
+        for (int c0 = 0; c0 < NMAX; c0 += 6) {
+            if (c0 < n6) {                                   // (n6 is a multiple of 6 and wave-uniform: a scalar branch per block column)
+#pragma unroll
+                for (int c = c0; c < c0 + 6 && c < NMAX; ++c) q += Arow[c] * readlane_f64(d, c);
+            }
+        }
+        const double dq = wave_sum(d * q);
+        const double alpha = dn / dq;
+        x += alpha * d;
+        rr -= alpha * q;
+        const double sv = apply_minv(rr);
+        const double dnn = wave_sum(rr * sv);
+        const double beta = dnn / dn;
+        d = sv + beta * d;
+        dn = dnn;
+        iter += 1;
+    }
+    if (act) sx[r] = x;
+    if (r == 0) {
+        st->pcg_residual = 0.5 * dn;
+        st->pcg_iter = iter;
+        st->pcg_total += iter;
+        if (iter > st->pcg_max) st->pcg_max = iter;
+    }
+}
+
 __device__ __forceinline__ void sm_pcg(const DeviceGraph& g, LmState* st, const int n6, const double* sA, const double* sb, double* sd, double* sx) {
     const int r = threadIdx.x & 63;
     const bool act = r < n6;
@@ -3493,11 +3552,11 @@ template <class Src>
 __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int solver) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!(st->mode & MODE_TRIAL)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     __shared__ double sA[SM_MAX_N6 * SM_LD];
     __shared__ double sb[SM_MAX_N6], sx[SM_MAX_N6], sd[SM_MAX_N6];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef VISFS_BA_STAMPS
 #define SS_STAMP(slot) do { if (tid == 0) g.stamps[64 + (slot)] = wall_clock64(); } while (0)
 #else
@@ -3575,7 +3634,10 @@ __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int so
     __syncthreads();
     SS_STAMP(2);
     if (wave == 0) {
-        if (solver == 2) sm_pcg(g, st, n6, sA, sb, sd, sx);
+        if ((solver & 0xff) == 2) {
+            if (solver & 0x100) sm_pcg(g, st, n6, sA, sb, sd, sx);                   // (A/B runs: VISFS_BA_SMALL_PCG_LDS=1, the LDS-row form)
+            else if (n6 <= 36) sm_pcg_reg<36>(g, st, n6, sA, sb, sx); else sm_pcg_reg<60>(g, st, n6, sA, sb, sx);
+        }
         else {
             const bool failed = (n6 <= 32) ? sm_cholesky_factor_reg<32>(n6, sA) : sm_cholesky_factor_reg<64>(n6, sA);
             if (failed) { if (lane == 0) st->solver_failed = 1; }
@@ -4053,7 +4115,8 @@ void launch_reset(const DeviceGraph& g, int max_iter, int gauss_newton, int rest
     hipLaunchKernelGGL((k_reset<One>), dim3(dims_of(g).reset_blocks), dim3(256), 0, s, One{ g }, max_iter, gauss_newton, restore);
 }
 void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s) {
-    TIMED_LAUNCH((k_small_solve<One>), dim3(1), dim3(512), 0, s, One{ g }, solver);
+    static const int pcg_lds = []() { const char* e = std::getenv("VISFS_BA_SMALL_PCG_LDS"); return (e && e[0] == '1') ? 0x100 : 0; }();
+    TIMED_LAUNCH((k_small_solve<One>), dim3(1), dim3(512), 0, s, One{ g }, solver | (solver == 2 ? pcg_lds : 0));
 }
 void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s) {
     hipLaunchKernelGGL((k_small_optimize<One>), dim3(1), dim3(SM_T), 0, s, One{ g }, solver, half);
