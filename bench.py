@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--windows-per-gpu", type=int, default=1)
     ap.add_argument("--solver", type=int, default=2, help="Optimizer/Solver: 2 = PCG (headline), 0 = direct Cholesky")
     ap.add_argument("--framework", type=int, default=0, help="Optimizer/Framework: 0 = the g2o branch (headline), 1 = the Ceres branch (one pass of <= Iterations trust-region iterations, direct solver)")
+    ap.add_argument("--trust-region", type=int, default=0, help="Optimizer/TrustRegion: g2o branch 0 = Levenberg, 1 = Gauss-Newton; Ceres branch 0 = LEVENBERG_MARQUARDT, 1 = DOGLEG")
     ap.add_argument("--iterations", type=int, default=20, help="Optimizer/Iterations (10+10, as the shipped launch files)")
     ap.add_argument("--batch-mode", default="launch", choices=("launch", "streams"),
                     help="--windows-per-gpu > 1: 'launch' = one sequence of batched launches for all resident windows "
@@ -98,7 +99,7 @@ def main():
     red_dev = f"cuda:{dev}" if (world > 1 and dist_backend == "nccl") else "cpu"
     bar_dev = dev if (world > 1 and dist_backend == "nccl") else None
 
-    prm = abi.default_params(iterations=args.iterations, solver=args.solver, framework=args.framework)
+    prm = abi.default_params(iterations=args.iterations, solver=args.solver, framework=args.framework, trust_region=args.trust_region)
     if args.framework == 1:
         args.solver = 0                                                                   # the branch's dense solvers: Schur + direct Cholesky
     lib = backend.load_library()
@@ -240,7 +241,7 @@ def main():
         "config": {"workload": f"{args.config}: {d['n_poses']} KF / {d['n_points']} landmarks / {d['n_obs']} stereo observations"
                                f" / {d['n_odo']} odometry edges, Schur + {'PCG' if args.solver == 2 else 'direct Cholesky'}, "
                                + (f"Iterations={args.iterations} ({args.iterations // 2}+{args.iterations // 2})" if args.framework == 0 else
-                                  f"Optimizer/Framework=1 (Ceres branch: one pass, <= {args.iterations} trust-region iterations, each counted as one BA iteration)")
+                                  f"Optimizer/Framework=1 (Ceres branch, {'DOGLEG' if args.trust_region == 1 else 'LEVENBERG_MARQUARDT'}: one pass, <= {args.iterations} trust-region iterations, each counted as one BA iteration)")
                                + f", {B} window(s) per GPU",
                    "windows_per_gpu": B, "solver": args.solver, "iterations_per_solve": int(total_iters / (args.steps * world * B)),
                    "pcg_iterations_per_solve": int(last.pcg_iterations) if last is not None else 0,

@@ -23,6 +23,9 @@ timeout -k 10 300 python3 bench.py --config C4 --solver 0 --iterations 10 --step
 for CFG in C2 PROD; do
   timeout -k 10 300 python3 bench.py --config $CFG --framework 1 --steps 20 --warmup 3 > "$OUT/${TAG}_bench_ceres_$CFG.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
+for CFG in C2 PROD; do
+  timeout -k 10 300 python3 bench.py --config $CFG --framework 1 --trust-region 1 --steps 20 --warmup 3 > "$OUT/${TAG}_bench_dogleg_$CFG.json" 2>> "$OUT/${TAG}_c2_bench.err"
+done
 timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu 8 --solver 0 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x8_solver0.json" 2>> "$OUT/${TAG}_c2_bench.err"
 step "batches on one GPU"
 for B in 8 16; do
@@ -30,6 +33,7 @@ for B in 8 16; do
 done
 step "per-frame call path"
 timeout -k 10 300 python3 tools/e2e_breakdown.py > "$OUT/${TAG}_e2e_breakdown.log" 2>&1
+for CFG in PROD C1 C2 C4; do timeout -k 10 120 python3 tools/frame_loop.py $CFG 30; done > "$OUT/${TAG}_frame_loop.log" 2>&1
 cd /tmp
 step "kernel statistics"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats_c2" -o c2 -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/${TAG}_c2_bench_under_rocprof.json"
