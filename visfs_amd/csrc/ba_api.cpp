@@ -698,8 +698,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.lin_stride = reinterpret_cast<char*>(g.lin[1].obs_w) - reinterpret_cast<char*>(g.lin[0].obs_w);
         g.pose[0] = A.take<double>((size_t)Np * POSE_STRIDE); g.pose[1] = A.take<double>((size_t)Np * POSE_STRIDE);
         g.pt[0] = A.take<double>((size_t)std::max(Nl, 1) * 3); g.pt[1] = A.take<double>((size_t)std::max(Nl, 1) * 3);
+        g.obs_outlier = A.take<uint8_t>(std::max(No, 1));   // (right behind the estimates: pose[0] .. obs_outlier are one span in the order and alignment of
+                                                             // output_stage_of, so a solve's outputs come back in ONE device-to-host copy)
         g.obs_level = A.take<uint8_t>(std::max(No, 1));
-        g.obs_outlier = A.take<uint8_t>(std::max(No, 1));
         g.obs_chi2_out = A.take<double>(std::max(No, 1));
         g.obs_chi2 = A.take<double>(std::max(No, 1));
         g.Hpp = A.take<double>((size_t)std::max(Npf, 1) * 36);
@@ -863,11 +864,20 @@ int ws_read_state(visfs_ba_handle* h, Workspace& w) {
         // which estimate buffer is the final one is only known from the state that is coming back: fetch both (poses are tiny, landmarks
         // 24 bytes each) — the caller's download then needs neither a copy nor a second synchronisation
         const DeviceGraph& g = w.g;
-        for (int k = 0; k < 2; ++k) {
-            HIP_TRY(h, hipMemcpyAsync(w.h_base + os.pose[k], g.pose[k], (size_t)g.Np * POSE_STRIDE * 8, hipMemcpyDeviceToHost, w.stream));
-            if (g.Nl) HIP_TRY(h, hipMemcpyAsync(w.h_base + os.pt[k], g.pt[k], (size_t)g.Nl * 24, hipMemcpyDeviceToHost, w.stream));
+        const char* d0 = reinterpret_cast<const char*>(g.pose[0]);
+        const bool one_span = reinterpret_cast<const char*>(g.pose[1]) - d0 == (ptrdiff_t)os.pose[1] && reinterpret_cast<const char*>(g.pt[0]) - d0 == (ptrdiff_t)os.pt[0] &&
+                              reinterpret_cast<const char*>(g.pt[1]) - d0 == (ptrdiff_t)os.pt[1] && reinterpret_cast<const char*>(g.obs_outlier) - d0 == (ptrdiff_t)os.out;
+        if (one_span) {
+            // the device arena holds the five arrays in the staging layout (ws_upload): one copy instead of five — each is a few microseconds
+            // of copy-engine latency on the tail of every per-frame call
+            HIP_TRY(h, hipMemcpyAsync(w.h_base, d0, os.end, hipMemcpyDeviceToHost, w.stream));
+        } else {
+            for (int k = 0; k < 2; ++k) {
+                HIP_TRY(h, hipMemcpyAsync(w.h_base + os.pose[k], g.pose[k], (size_t)g.Np * POSE_STRIDE * 8, hipMemcpyDeviceToHost, w.stream));
+                if (g.Nl) HIP_TRY(h, hipMemcpyAsync(w.h_base + os.pt[k], g.pt[k], (size_t)g.Nl * 24, hipMemcpyDeviceToHost, w.stream));
+            }
+            if (g.No) HIP_TRY(h, hipMemcpyAsync(w.h_base + os.out, g.obs_outlier, (size_t)g.No, hipMemcpyDeviceToHost, w.stream));
         }
-        if (g.No) HIP_TRY(h, hipMemcpyAsync(w.h_base + os.out, g.obs_outlier, (size_t)g.No, hipMemcpyDeviceToHost, w.stream));
     }
     HIP_TRY(h, hipStreamSynchronize(w.stream));
     w.outputs_staged = with_outputs;
