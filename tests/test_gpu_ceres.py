@@ -139,7 +139,7 @@ def test_ceres_dogleg_laser_only_and_window_entry(olib):
     et, er = synth.pose_errors(rb_g.pose_Twr_out[:12], rb_o.pose_Twr_out[:12])
     assert et < 1e-6 and er < 1e-6 and rb_g.outliers() == rb_o.outliers()
     assert list(rb_g.struct.iterations_run) == list(rb_o.struct.iterations_run)
-    # visfs_ba_solve_batch solves DOGLEG windows one after another (no batched launches for them): the same results
+    # visfs_ba_solve_batch: the same results as single solves
     prm = abi.default_params(framework=1, trust_region=1, iterations=10)
     s = backend.Solver(prm)
     ws = [synth.make_window("PROD", window_index=i) for i in range(3)]
@@ -200,12 +200,14 @@ def test_random_window_matches_oracle_ceres_branch(olib, i):
         assert rel_err(wb_g.point_xyz, wb_o.point_xyz) < 1e-6
 
 
-def test_ceres_branch_in_batched_launches(olib):
+@pytest.mark.parametrize("trust_region", [0, 1])
+def test_ceres_branch_in_batched_launches(olib, trust_region):
     """Optimizer/Framework=1 through visfs_ba_solve_batch: windows whose reduced system is small (k_small_solve) or banded (k_band_chol)
     share every launch — k_ceres_lin_finalize after every linearisation, the per-variable damping in the Schur gather, one pass of
-    <= Iterations trust-region iterations, no second phase — and come out as the bytes of their single-window solves."""
+    <= Iterations trust-region iterations, no second phase; with the DOGLEG strategy (trust_region = 1) the two back-substitution passes
+    and k_dogleg_mid as well — and come out as the bytes of their single-window solves."""
     from visfs_amd import backend
-    prm = abi.default_params(iterations=12, framework=1)
+    prm = abi.default_params(iterations=12, framework=1, trust_region=trust_region)
     ws = [synth.make_window("PROD", window_index=i) for i in range(5)]
     ws += [synth.make_window("custom", n_kf=24, n_lm=500, n_obs=4000, seed=400 + i) for i in range(4)]
     ws.append(hard_window())

@@ -1850,7 +1850,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             const Workspace& ws = *h->batch[i];
             // (the direct solver shares launches when the window's S is banded: k_band_chol, one workgroup per window)
             const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
-            const bool batchable = batching && !ws.g.dogleg && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
+            const bool batchable = batching && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
@@ -1948,7 +1948,6 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
             const Workspace& ws = *h->batch[i];
             const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
             if (!(h->prm.solver == 2 || ws.small_solve || ws.fused || band)) { h->err = "batched launches need Optimizer/Solver=2, a banded reduced system (direct solver) or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
-            if (ws.g.dogleg) { h->err = "Optimizer/Framework=1 with Optimizer/TrustRegion=1 (DOGLEG) has no batched launches: solve the windows one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
             groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);

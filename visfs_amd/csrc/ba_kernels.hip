@@ -3895,6 +3895,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.band = g.band_B >= 0 ? 1 : 0;                    // direct solver: every window of a launch on the banded factorisation (k_band_chol)
     d.band_lds = g.band_B >= 0 ? g.band_lds_bytes : 0;
     d.ceres = g.ceres;
+    d.dogleg = g.dogleg;
     return d;
 }
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
@@ -3907,6 +3908,7 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.pcg_cu = a.pcg_cu & b.pcg_cu;
     d.band = a.band & b.band; d.band_lds = std::max(a.band_lds, b.band_lds);
     d.ceres = a.ceres & b.ceres;                       // (a handle has one framework: all windows of a launch agree)
+    d.dogleg = a.dogleg & b.dogleg;                    // ... and one trust-region strategy
     return d;
 }
 // dynamic LDS of the kernels that stage every pose of the window as R|t (12 doubles each); windows beyond MAX_STAGED_POSES use the
@@ -4150,6 +4152,21 @@ void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int m
     hipLaunchKernelGGL((k_reset<Many>), dim3(d.reset_blocks, B), dim3(256), 0, s, Many{ gs }, max_iter, gauss_newton, restore);
 }
 // One unit of the LM state machine for every window of the batch (PCG or, for reduced systems <= 64 x 64, k_small_solve).
+template <int G>
+static void launch_backsub_dogleg_many_t(const Many& src, const LaunchDims& d, int B, int pass, hipStream_t s) {
+    const size_t lds = lds_poses(d, 8 + 12 * d.np);
+    if (pass == 1) { ensure_lds(k_backsub<G, Many, false, true, false, 1>, lds); hipLaunchKernelGGL((k_backsub<G, Many, false, true, false, 1>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src); }
+    else { ensure_lds(k_backsub<G, Many, false, true, false, 2>, lds); hipLaunchKernelGGL((k_backsub<G, Many, false, true, false, 2>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src); }
+}
+static void launch_backsub_dogleg_many(const Many& src, const LaunchDims& d, int B, int pass, hipStream_t s) {
+    switch (d.group) {
+        case 4: launch_backsub_dogleg_many_t<4>(src, d, B, pass, s); break;
+        case 8: launch_backsub_dogleg_many_t<8>(src, d, B, pass, s); break;
+        case 16: launch_backsub_dogleg_many_t<16>(src, d, B, pass, s); break;
+        case 32: launch_backsub_dogleg_many_t<32>(src, d, B, pass, s); break;
+        default: launch_backsub_dogleg_many_t<64>(src, d, B, pass, s); break;
+    }
+}
 void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, hipStream_t s) {
     const Many src{ gs };
     launch_linearize_src(src, d, B, 0, s);             // batched windows keep the gated unit (LinSel<Many>: set 0 only)
@@ -4165,6 +4182,14 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
         hipLaunchKernelGGL((k_band_chol<Many>), dim3(1, B), dim3(BAND_T), (size_t)d.band_lds, s, src);
     }
     else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
+    if (d.dogleg) {
+        // Optimizer/Framework=1 with the DOGLEG strategy: the two back-substitution passes around the point on the dogleg path, then the decision
+        launch_backsub_dogleg_many(src, d, B, 1, s);
+        hipLaunchKernelGGL((k_dogleg_mid<Many>), dim3(1, B), dim3(256), 0, s, src);
+        launch_backsub_dogleg_many(src, d, B, 2, s);
+        hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
+        return;
+    }
     // the LM decision rides on k_backsub (fused_decide = false: one k_decide launch for all windows, as in round 1)
     launch_backsub_src(src, d, B, 0, fused_decide ? 1 : 0, s);
     if (!fused_decide) hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
