@@ -1,7 +1,9 @@
 """Soak: the randomised window parity of tests/test_gpu_random.py over many more seeds than the suite runs (one process).
 Every seed is classified: exact (the suite's criteria), benign mismatches the reference algorithm itself produces —
-`converged` (poses / chi2 agree to 1e-9 but the LM loop, already at machine precision, stopped one iteration apart: the sign of
-a 1e-13 chi2 change decides), `pcg tolerance` (Solver=2 stops at a RELATIVE residual of 1e-6: on an ill-conditioned window two
+`converged` (chi2 agrees to 1e-9 and the outlier sets are equal, but the LM loop, already at machine precision, stopped some
+iterations apart: the sign of a 1e-13 chi2 change decides; the poses agree to the suite's own 1e-7 — seed 3363 is the case that
+set this bound: 8e-9 between the HIP path and the oracle with EITHER direct solver, the dense one running the oracle's 10 + 10
+iterations, the banded one 10 + 4, `tools/soak_case.py 3363`), `pcg tolerance` (Solver=2 stops at a RELATIVE residual of 1e-6: on an ill-conditioned window two
 correct implementations agree to about that, not to the suite's 1e-7), `gauss-newton` (trust region 1 is undamped: after the
 outlier pass has culled a landmark's observations the system is rank-deficient and either implementation returns rounding
 noise; the oracle's own chi2 often RISES) — or FAILED, which must stay empty."""
@@ -41,7 +43,7 @@ def classify(olib, i):
     et, er = synth.pose_errors(rb_g.pose_Twr_out[:n], rb_o.pose_Twr_out[:n])
     chi_rel = abs(rb_g.struct.chi2_final - rb_o.struct.chi2_final) / max(abs(rb_o.struct.chi2_final), 1e-9)
     same_out = rb_g.outliers() == rb_o.outliers()
-    if et < 1e-9 and er < 1e-9 and chi_rel <= 1e-9 and same_out:
+    if et < 1e-7 and er < 1e-7 and chi_rel <= 1e-9 and same_out:
         return "converged", kw
     if kw["trust_region"] == 1:
         return "gauss-newton", kw
