@@ -193,7 +193,7 @@ struct DeviceGraph {
 
     // ---- linearisation products ----
     double* obs_err;            // [No][3]   (written only when debug != 0)
-    double* obs_chi2;           // [No]
+    double* obs_chi2;           // [No] (written under `debug` only: the stage hooks)
     double* W;                  // [No][18]  Hpl tiles, 6x3 row-major — written only for the stage hooks (debug)
     LinBuf lin[2];              // rho' weights, tile seeds, Hll, b_l, Hpp partials, odometry blocks: two sets (LmState::lin_sel)
     long long lin_stride;       // bytes from a member of lin[0] to the same member of lin[1]

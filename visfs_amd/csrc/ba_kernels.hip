@@ -356,8 +356,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
         double rho0 = c2, rho1 = 1.0;
         robustify(g, c2, delta, rho0, rho1);
         L.obs_w[k] = active ? rho1 : 0.0;
-        g.obs_chi2[k] = active ? c2 : 0.0;
-        if (g.debug) { g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
+        if (g.debug) { g.obs_chi2[k] = active ? c2 : 0.0; g.obs_err[3 * k] = active ? e.x : 0.0; g.obs_err[3 * k + 1] = active ? e.y : 0.0; g.obs_err[3 * k + 2] = active ? e.z : 0.0; }
         const bool pfree = g.pose_free[ip] >= 0;
         double wo_tile = 0.0;
         if (active) {
@@ -3078,9 +3077,8 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
         const LinSel<Src> lspec(g, ls ^ 1);
         double chi2 = 0.0, md2 = 0.0;
         lin_landmark<G, STG>(g, lspec.get(), l, lvalid, sub, Pt, pt_t, K, iv, delta, chi2, md2, nullptr, &pn);
-        const double chi2_tot = block_sum_256(chi2, red);
-        const double md2_tot = block_max_256(md2, red);
-        if (tid == 0) { g.lin_part[2 * bid] = chi2_tot; g.lin_part[2 * bid + 1] = md2_tot; }
+        // (no lin_part here: the chi2 of an accepted trial is the trial's, max |diag H| is only read at the first iteration of a phase,
+        // which linearises with k_linearize)
     }
 }
 
