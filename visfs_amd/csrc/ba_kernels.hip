@@ -989,8 +989,9 @@ __global__ __launch_bounds__(1024) void k_ceres_lin_finalize(const Src src) {
 //   lm_ptr    CSR over the landmark-major observations (observations arrive sorted by (point, pose): boundaries of obs_pt);
 //   obs_ok    !(pose fixed && point fixed);
 //   pose_obs  the pose-major permutation (free poses only, ascending observation id inside a pose), obs_ppos its inverse.
-// The permutation is a stable multi-split: blocks of IDX_T observations, thread a of a block counts / ranks the observations of free
-// pose a by scanning the block's poses in LDS (every thread reads the same word: a broadcast) — no atomics, order fixed.
+// The permutation is a stable multi-split over blocks of IDX_T observations: inside a wavefront one ballot per DISTINCT free pose gives
+// every lane its rank among the equal-pose lanes below it and the wavefront's count of that pose (k_index_count sums the four
+// wavefronts' counts per block, k_index_scan turns the block counts into offsets, k_index_scatter places) — no atomics, order fixed.
 constexpr int IDX_T = 256;
 __global__ __launch_bounds__(256) void k_index_count(const DeviceGraph g, int32_t* __restrict__ hist) {
     __shared__ int sfree[IDX_T];
