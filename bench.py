@@ -33,12 +33,22 @@ def algorithmic_bytes(kernel, d):
     def avg(weights, fn):
         tot = sum(weights)
         return sum(wt * fn(e) for wt, e in zip(weights, edges)) / tot if tot > 0 else fn(edges[0])
+    # The fused speculative unit (unit_form 2) moves stage A of an accepted trial into the two launches around it: its
+    # landmark-major half (the point Jacobians, weights and errors: 72 + 40 B/obs, 96 B/landmark) into the k_backsub launch, its
+    # pose-major half (the pose Jacobians: 144 B/obs, 336 B/pose) behind the next k_schur_partial launch; k_linearize itself only runs
+    # at the first iteration of a phase.  Per launch of the class: lin[p] - 1 of a phase's tr[p] launches carry the extra half.
+    fused = d.get("unit_form", 0) == 2
+    extra = [max(l - 1, 0) / t if t > 0 else 0.0 for l, t in zip(lin, tr)]
+
+    def avg_x(fn, fx):
+        tot = sum(tr)
+        return sum(wt * (fn(e) + (x * fx(e) if fused else 0.0)) for wt, e, x in zip(tr, edges, extra)) / tot if tot > 0 else fn(edges[0])
     if kernel == "k_linearize":      # stage A of §8d: 256 B/obs + 96 B/landmark + 336 B/pose
         return avg(lin, lambda No: 256 * No + 96 * Nl + 336 * Np)
     if kernel == "k_schur_partial":  # stage B: 144 B/obs (Hpl) + 96 B/landmark + 288 B/stored block + 48 B/pose
-        return avg(tr, lambda No: 144 * No + 96 * Nl + 288 * nblk + 48 * Np)
+        return avg_x(lambda No: 144 * No + 96 * Nl + 288 * nblk + 48 * Np, lambda No: 144 * No + 336 * Np)
     if kernel == "k_backsub":        # stages D+E: 144 + 112 + 8 B/obs, (72+24+24)+48 B/landmark, 112 B/pose
-        return avg(tr, lambda No: 264 * No + 168 * Nl + 112 * Np)
+        return avg_x(lambda No: 264 * No + 168 * Nl + 112 * Np, lambda No: 112 * No + 96 * Nl)
     if kernel == "k_pcg":            # stage C, k iterations in one launch: k * (288 B/block + 4*48 B/pose)
         return d["pcg_iters_per_launch"] * (288 * nblk + 192 * Np)
     if kernel == "k_direct":         # direct solve of the reduced system: every stored block of S once, b_s in, x out

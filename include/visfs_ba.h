@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VISFS_BA_ABI_VERSION 5
+#define VISFS_BA_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------- */
 /* The reference signals failure by returning an EMPTY pose map
@@ -313,6 +313,11 @@ typedef struct visfs_ba_graph_info {
     int32_t band_blocks;          /* direct solver: block half-bandwidth of S when k_band_chol serves the window, -1 otherwise */
     int32_t graph_replayed;       /* 1: the LAST visfs_ba_optimize of this resident graph ran as a hipGraph replay of its launch sequence (only
                                    * re-optimisations of the same resident graph are ever replayed; a per-frame visfs_ba_solve_window never is) */
+    int32_t unit_form;            /* how a damped solve is launched: 0 the gated unit (k_linearize when a trial was accepted ... k_backsub + decision),
+                                   * 1 the speculative unit in two launches (k_backsub, then k_linearize of the trial beside the decision),
+                                   * 2 the fused speculative unit (k_backsub also carries the decision and the landmark-major half of the
+                                   *   trial's linearisation; the pose-major half rides behind the next k_schur_partial): what the kernel
+                                   *   classes of the profile hooks contain depends on it */
 } visfs_ba_graph_info;
 /* GRAPH layer for a batch of independent windows (BASELINE config 5): n graphs resident side by side; one optimise call runs
  * them through ONE sequence of launches (blockIdx.y = window, each window gated by its own LM state).  Needs

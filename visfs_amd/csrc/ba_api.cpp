@@ -1985,6 +1985,7 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     out->fused_path = w.fused ? 1 : 0;
     out->band_blocks = (h->prm.solver != 2 && !w.small_solve) ? w.g.band_B : -1;
     out->graph_replayed = w.last_replayed ? 1 : 0;
+    out->unit_form = w.spec_fused ? 2 : w.spec ? 1 : 0;
     out->solver_kernel = w.small_solve ? 5 : h->prm.solver != 2 ? (w.g.band_B >= 0 ? 7 : 6) : w.g.pcg_cu ? 4 : w.g.pcg1_code ? 1 : w.g.Npf > MAX_PCG_ONE_ROW_POSES ? 3 : 2;
     return VISFS_BA_OK;
 }
