@@ -732,6 +732,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         zero_end = (A.used + 255) & ~size_t(255);
         g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // every slot filled on the device (k_build_pairs: the counts are the summary's)
         g.pose_lm = A.take<int32_t>(std::max(n_pose_obs, 1));                   // every slot filled by k_index_scatter
+        g.pose_rec = A.take<DeviceGraph::PoseRec>(std::max(n_pose_obs, 1));     // likewise
         g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);               // debug: every observation, active or not (k_linearize)
         g.W = A.take<double>((size_t)std::max(No, 1) * 18);                    // likewise
     };

@@ -169,6 +169,9 @@ struct DeviceGraph {
     const int32_t* blk_j;       // [n_blk] (col), j >= i
     const int32_t* blk_ptr;     // [n_blk+1] into blk_pairs
     int32_t* pose_lm;           // [n_pose_obs] landmark of each entry of pose_obs (ascending within a pose); built on the device at upload
+    struct PoseRec { int32_t k, l_ok; double u, v, ur; };   // observation id, landmark (bit 31: the edge is NOT usable: both ends fixed), the measurement
+    PoseRec* pose_rec;          // [n_pose_obs] pose-major copy of what the pose-major role of the linearisation reads per observation (static: written by
+                                // k_index_scatter): one 32-byte record instead of a chain pose_obs -> obs_pt / obs_ok / obs_uvr
     int4* blk_pairs;            // (tile of pose i, tile of pose j, landmark, 0) — tiles as pose-major positions: co-observations of one landmark, in landmark order
                                 // per block; built on the device at upload (k_build_pairs) from the pose-major observation lists
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block

@@ -320,6 +320,33 @@ __device__ __forceinline__ void pose_obs_terms(const DeviceGraph& g, const int k
     for (int r = 0; r < 6; ++r) acc[21 + r] = -(Jx[r] * wo * e.x + Jx[6 + r] * wo * e.y + Jx[12 + r] * wo * e.z);
 }
 
+// The same terms from the pose-major record of the observation (DeviceGraph::pose_rec): the record does not depend on the LM state, so
+// a kernel can have it in flight before its gate; what is left behind the gate is obs_level (the outlier pass moves edges to level 1)
+// and the landmark.  Same arithmetic as pose_obs_terms on the same values.
+__device__ __forceinline__ void pose_obs_terms_rec(const DeviceGraph& g, const DeviceGraph::PoseRec& rec, const Rt& T, const double* __restrict__ pt,
+                                                   const Intrinsics& K, const double iv, const double delta, double acc[27]) {
+    const bool active = (g.obs_level[rec.k] == 0) && rec.l_ok >= 0;
+    if (!active) return;
+    const int l = rec.l_ok;
+    const Vec3 pw{ pt[3 * l], pt[3 * l + 1], pt[3 * l + 2] };
+    Vec3 pc;
+    const Vec3 e = stereo_error(T, pw, rec.u, rec.v, rec.ur, K, pc);
+    const double c2 = chi2_of(e, iv);
+    double rho0 = c2, rho1 = 1.0;
+    robustify(g, c2, delta, rho0, rho1);
+    const double wo = rho1 * iv;
+    double Jx[18];
+    stereo_jacobian_pose(pc, K, Jx);
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = r; cc < 6; ++cc, ++q)
+            acc[q] = Jx[r] * wo * Jx[cc] + Jx[6 + r] * wo * Jx[6 + cc] + Jx[12 + r] * wo * Jx[12 + cc];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] = -(Jx[r] * wo * e.x + Jx[6 + r] * wo * e.y + Jx[12 + r] * wo * e.z);
+}
+
 // Role A for one landmark handled by G lanes (sub = lane within the group): weights, chi2, tile seeds, Hll, b_l.
 // Shared by k_linearize<G> and the fused small-window kernel (G = 1: one thread per landmark).
 template <int G, bool STG = true>
@@ -726,7 +753,7 @@ __global__ __launch_bounds__(256) void k_linearize(const Src src) {
         double acc[27];
 #pragma unroll
         for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-        if (begin + tid < end) pose_obs_terms(g, g.pose_obs[begin + tid], P.get(g.free_pose[a]), pt, K, iv, delta, acc);
+        if (begin + tid < end) pose_obs_terms_rec(g, g.pose_rec[begin + tid], P.get(g.free_pose[a]), pt, K, iv, delta, acc);   // (one coalesced 32-byte record per observation)
         const int wave = tid >> 6, lane = tid & 63;
         int off = 0, len = 27;
         ReduceScatter<27, 32>::run(acc, lane, off, len);
@@ -1089,7 +1116,13 @@ __global__ __launch_bounds__(256) void k_index_scatter(const DeviceGraph g, cons
         for (int w = 0; w < wave; ++w) pos += wcnt[w * g.Npf + a];
         const_cast<int32_t*>(g.pose_obs)[pos] = k;
         const_cast<int32_t*>(g.obs_ppos)[k] = pos;
-        g.pose_lm[pos] = g.obs_pt[k];
+        const int l = g.obs_pt[k];
+        g.pose_lm[pos] = l;
+        // (obs_ok and obs_uvr of this observation were written by k_index_count, the launch before the scan)
+        DeviceGraph::PoseRec rec;
+        rec.k = k; rec.l_ok = g.obs_ok[k] ? l : (l | (int)0x80000000);
+        rec.u = g.obs_uvr[3 * (size_t)k]; rec.v = g.obs_uvr[3 * (size_t)k + 1]; rec.ur = g.obs_uvr[3 * (size_t)k + 2];
+        g.pose_rec[pos] = rec;
     }
 }
 
@@ -1317,16 +1350,23 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
         if ((int)blockIdx.x >= first_b) {
             __shared__ double redb[4 * 27];
             const int c = (int)blockIdx.x - first_b;
-            if (c >= g.n_chunks || !st->lin_b_pending || !(st->mode & MODE_TRIAL)) return;
+            if (c >= g.n_chunks) return;
+            // chunk -> pose, range, record: none of it depends on the LM state — in flight before the gate
             const int tid = threadIdx.x, wave = tid >> 6;
-            const int sel = st->sel;
-            const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
             const int a = g.chunk_pose[c];
             const int begin = g.chunk_ptr[c], end = g.chunk_ptr[c + 1];
+            const bool mine = begin + tid < end;
+            DeviceGraph::PoseRec rec;
+            rec.k = 0; rec.l_ok = -1; rec.u = rec.v = rec.ur = 0.0;
+            if (mine) rec = g.pose_rec[begin + tid];
+            const int ipose = g.free_pose[a];
+            if (!st->lin_b_pending || !(st->mode & MODE_TRIAL)) return;
+            const int sel = st->sel;
+            const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
             double acc[27];
 #pragma unroll
             for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-            if (begin + tid < end) pose_obs_terms(g, g.pose_obs[begin + tid], pose_to_Rt(g.pose[sel] + POSE_STRIDE * g.free_pose[a]), g.pt[sel], intr_of(g), g.inv_pixel_var, g.huber_delta, acc);
+            if (mine) pose_obs_terms_rec(g, rec, pose_to_Rt(g.pose[sel] + POSE_STRIDE * ipose), g.pt[sel], intr_of(g), g.inv_pixel_var, g.huber_delta, acc);
             int off = 0, len = 27;
             ReduceScatter<27, 32>::run(acc, lane, off, len);
             if (len >= 1) redb[wave * 27 + off] = acc[0];
