@@ -3024,6 +3024,12 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     }
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
+#ifdef VISFS_BA_STAMPS
+#define BS_STAMP(slot) do { if (LINA && threadIdx.x == 0 && blockIdx.x == (unsigned)g.stamp_wg) g.stamps[32 + (slot)] = wall_clock64(); } while (0)
+#else
+#define BS_STAMP(slot) do { } while (0)
+#endif
+    BS_STAMP(0);
     const bool trial = (st->mode & MODE_TRIAL) != 0;
     const bool go = trial && !st->solver_failed && !st->pcg_timeout;
     // a failed solve: nothing to compute, but the decision may only be taken once every workgroup has read the gate
@@ -3090,11 +3096,13 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
         return;
     }
     double* sRt0 = red + 8;                   // poses of the linearisation point (tiles are rebuilt there)
+    BS_STAMP(1);
     if (STG) {
         stage_poses(pose_t, g.Np, sRt);
         stage_poses(g.pose[sel], g.Np, sRt0);
         __syncthreads();
     }
+    BS_STAMP(2);
     const PoseSrc<STG> Pt{ STG ? sRt : pose_t }, P0{ STG ? sRt0 : (const double*)g.pose[sel] };
     const LinSel<Src> lsel(g, ls); const LinBuf& L = lsel.get();
     constexpr int LPW = 256 / G;
@@ -3103,8 +3111,10 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     double chi_acc = 0.0, scale_acc = 0.0, step_acc = 0.0, dot_acc = 0.0;
     Vec3 pn{ 0.0, 0.0, 0.0 };
     backsub_landmark<G, STG, DL>(g, L, l, lvalid, sub, Pt, P0, pt, pt_t, lambda, K, iv, delta, chi_acc, scale_acc, &step_acc, &dot_acc, st->dl_A, st->dl_B, LINA ? &pn : nullptr);
+    BS_STAMP(3);
     const double chi_tot = block_sum_256(chi_acc, red);
     const double sc_tot = block_sum_256(scale_acc, red);
+    BS_STAMP(4);
     if (DL == 1) {
         const double s2_tot = block_sum_256(step_acc, red), s3_tot = block_sum_256(dot_acc, red);
         if (tid == 0) { g.dl_part[4 * (size_t)bid] = chi_tot; g.dl_part[4 * (size_t)bid + 1] = sc_tot; g.dl_part[4 * (size_t)bid + 2] = s2_tot; g.dl_part[4 * (size_t)bid + 3] = s3_tot; }
@@ -3120,6 +3130,7 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
         lin_landmark<G, STG>(g, lspec.get(), l, lvalid, sub, Pt, pt_t, K, iv, delta, chi2, md2, nullptr, &pn);
         // (no lin_part here: the chi2 of an accepted trial is the trial's, max |diag H| is only read at the first iteration of a phase,
         // which linearises with k_linearize)
+        BS_STAMP(5);
     }
 }
 
