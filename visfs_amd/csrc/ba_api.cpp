@@ -634,10 +634,16 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         }
     }
     lap("structure");
-    // lanes per landmark: smallest power of two >= mean track length, in [4, 64]
+    // lanes per landmark: smallest power of two >= mean track length, in [4, 64] — but at most 8 once the window has a thousand landmarks:
+    // the landmark-major kernels of a 200-key-frame window or of a batch of 50-key-frame windows need more than one round of resident
+    // waves at 16 lanes per landmark (k_backsub: 121 VGPRs, four waves per SIMD), and a lane that loops twice over a track of ten costs
+    // less than the second round (measured: C4 5 631 -> 6 007 it/s, C4R 5 040 -> 5 330, 16 resident C2 windows 73.0 k -> 80.9 k,
+    // 8 windows 63.1 k -> 66.2 k; one C2 window flat: 20.3 k / 20.2 k).  A property of the WINDOW alone: a window's result never
+    // depends on what it is batched with.
     int group = 4;
     const double mean_track = Nl > 0 ? (double)No / Nl : 1.0;
     while (group < 64 && group < mean_track) group *= 2;
+    if (Nl >= 1024 && group > 8) group = 8;
     { const char* e = std::getenv("VISFS_BA_GROUP"); if (e) { const int gq = std::atoi(e); if (gq == 4 || gq == 8 || gq == 16 || gq == 32 || gq == 64) group = gq; } }   // tuning override
     const int n_lin_a = std::max(1, (Nl + (256 / group) - 1) / (256 / group));
     const int n_eval = (No + 255) / 256 + 1;
