@@ -236,14 +236,18 @@ def test_a_window_s_result_never_depends_on_the_size_of_its_batch(olib, monkeypa
 def test_describe_names_the_kernel_that_solves_the_reduced_system(olib):
     """visfs_ba_graph_info::solver_kernel: the symbol a kernel trace shows for the solver class (bench.py's roofline.kernel_symbol)."""
     from visfs_amd import backend
-    cases = [("PROD", dict(solver=2), 5), ("PROD", dict(solver=0), 5), ("C2", dict(solver=2), 1), ("C2", dict(solver=0), 7),
-             ("C2", dict(solver=2, framework=1), 7), ("C4", dict(solver=2), 2)]
-    for cfg, kw, want in cases:
+    # (unit_form: 2 = the fused speculative unit — windows of <= 150 k observations on their own —, 0 = the gated unit: large windows, Ceres)
+    cases = [("PROD", dict(solver=2), 5, 2), ("PROD", dict(solver=0), 5, 2), ("C2", dict(solver=2), 1, 2), ("C2", dict(solver=0), 7, 2),
+             ("C2", dict(solver=2, framework=1), 7, 0), ("C4", dict(solver=2), 2, 0)]
+    for cfg, kw, want, form in cases:
         prm = abi.default_params(iterations=2, **kw)
         s = backend.Solver(prm)
         gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(synth.make_window(cfg)))
         s.upload(gb)
-        assert s.describe()["solver_kernel"] == want, (cfg, kw, s.describe()["solver_kernel"])
+        info = s.describe()
+        assert info["solver_kernel"] == want and info["unit_form"] == form, (cfg, kw, info["solver_kernel"], info["unit_form"])
+        # lanes per landmark: at most 8 once the window has a thousand landmarks (DESIGN.md §4)
+        assert info["lanes_per_landmark"] <= 8 or info["n_points"] < 1024
         s.close()
 
 
