@@ -2,6 +2,8 @@
 persistent PCG (one grid at a time per device; a batched launch never carries more block rows than the device holds)."""
 import threading
 
+import os
+
 import numpy as np
 import pytest
 
@@ -247,7 +249,7 @@ def test_describe_names_the_kernel_that_solves_the_reduced_system(olib):
         info = s.describe()
         assert info["solver_kernel"] == want and info["unit_form"] == form, (cfg, kw, info["solver_kernel"], info["unit_form"])
         # lanes per landmark: at most 8 once the window has a thousand landmarks
-        assert info["lanes_per_landmark"] <= 8 or info["n_points"] < 1024
+        assert info["lanes_per_landmark"] <= 8 or info["n_points"] < 1024 or "VISFS_BA_GROUP" in os.environ     # (the tuning override)
         s.close()
 
 
