@@ -1,8 +1,7 @@
 """GPU parity tests of the BASELINE.json workloads that round 1 left without a `-m gpu` test, and of the residency rules of the
 persistent PCG (one grid at a time per device; a batched launch never carries more block rows than the device holds)."""
-import threading
-
 import os
+import threading
 
 import numpy as np
 import pytest
