@@ -87,17 +87,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config5", choices=("auto", "on", "off"), default="auto",
                     help="also measure BASELINE config 5's per-GPU share in the same run (8 resident C2-size windows per GPU sharing every launch, "
-                         "results all_gather'ed and checked): 'auto' = whenever --gpus > 1, so a scaling run covers config 5 without extra flags")
+                         "results all_gather'ed and checked): 'auto' = on, so every driver-run line (N = 1 included) carries a config-5 number")
     args = ap.parse_args()
 
-    from visfs_amd import abi, synth, backend, dist as vdist
-    import torch
-
+    from visfs_amd import dist as vdist
     rank, local_rank, world = vdist.env_rank()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): the N ranks run as a CHILD process group under torch.distributed.run; this
+        # process has not touched (and never touches) a GPU, relays rank 0's JSON line and exits with the child's code
+        raise SystemExit(vdist.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if world != args.gpus:
-        # never a silent single-GPU line for a multi-GPU request (and never a re-exec of a process that may have touched the GPU)
+        # never a silent single-GPU line for a multi-GPU request
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 "
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+    if os.environ.get("VISFS_BENCH_DRY_RUN") == "1":
+        return dry_run(args, rank, world, vdist)
+    from visfs_amd import abi, synth, backend
+    import torch
     dev = local_rank if world > 1 else 0
     # rehearsal on a 1-GPU box: VISFS_BENCH_DEVICE pins every rank to one device, VISFS_BENCH_DIST_BACKEND=gloo replaces RCCL
     if os.environ.get("VISFS_BENCH_DEVICE") is not None:
@@ -207,7 +213,8 @@ def main():
     # all_gather (RCCL over xGMI when the backend is nccl); rank 0 checks them against its own single-rank solves of the same windows
     gathered = gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_dev, vdist, abi, synth, backend, torch)
     c5 = None
-    if args.config5 == "on" or (args.config5 == "auto" and world > 1):
+    # 'auto' = always (round 4): the driver's plain `bench.py --gpus 1` line then carries a driver-timed config-5 number too
+    if args.config5 in ("on", "auto"):
         # (the headline line must survive whatever happens in this extra leg: every rank takes the same path through its collectives
         # unless its own solve fails, and a failure is reported instead of raised)
         try:
@@ -299,6 +306,23 @@ def main():
         # parity of the timed configuration against the oracle (max pose error metric of BASELINE.json)
         out["max_pose_err_vs_oracle"] = parity_vs_oracle(args, prm, solvers[0])
     print(json.dumps(out))
+
+
+def dry_run(args, rank, world, vdist):
+    """VISFS_BENCH_DRY_RUN=1 (CPU test of the launch path, tests/test_bench_launch.py): the ranks rendezvous over gloo, run the
+    contract's collectives on dummy numbers and rank 0 prints a line — no GPU, no solver."""
+    import torch
+    if world > 1:
+        vdist.init_process_group("gloo", rank, world)
+    vdist.barrier(world)
+    elapsed = vdist.reduce_max(1.0 + rank, world)
+    total = vdist.reduce_sum(10.0, world)
+    ids = vdist.gather_results(torch.tensor([[float(rank)]], dtype=torch.float64), world).numpy().ravel()
+    vdist.barrier(world)
+    vdist.shutdown(world)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "max_elapsed": elapsed, "sum": total,
+                          "ranks_seen": [int(x) for x in ids], "self_launched": os.environ.get("VISFS_BENCH_SELF_LAUNCHED") == "1"}))
 
 
 def config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, synth, backend, torch, per_gpu=8):

@@ -1,5 +1,6 @@
 """GPU parity tests of the BASELINE.json workloads that round 1 left without a `-m gpu` test, and of the residency rules of the
 persistent PCG (one grid at a time per device; a batched launch never carries more block rows than the device holds)."""
+import ctypes as C
 import os
 import threading
 
@@ -412,3 +413,99 @@ def test_reference_default_solver_in_batched_launches(olib):
     o, g, gb = make_pair(olib, ws[0], iterations=10, solver=0)
     check_optimize(o, g)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("solver", [2, 0])
+def test_batch_members_on_the_fused_speculative_unit_equal_the_gated_unit(olib, monkeypatch, solver):
+    """Round 4: the windows of a batched launch can run the fused speculative unit of a lone window (k_linearize only
+    at the first iteration of a phase, the pose-major role behind the Schur gather, back-substitution + LM decision + landmark-major role
+    in one launch: 4 launches per iteration instead of 6).  It performs the arithmetic of the gated unit: every window of a mixed batch
+    — a window that rejects trials, odometry, k_small_solve members, a refused window — must come out bit for bit the same in both forms
+    (the gated unit stays the default for batch members: profiles/r04_batch_fused_unit_ab.log)."""
+    from visfs_amd import backend
+    from helpers import hard_window
+    prm = abi.default_params(iterations=10, solver=solver)
+    ws = [synth.make_window("C1", window_index=i) for i in range(3)]
+    ws += [synth.make_window("PROD", window_index=i) for i in range(3)]
+    ws.append(hard_window())
+    ws.append(synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11))
+    ws.append(synth.make_window("C3", n_kf=12, n_lm=300, n_obs=2400))
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VISFS_BA_BATCH_SPEC", mode)
+        s = backend.Solver(prm)
+        wbs = [abi.WindowBuffers(w) for w in ws]
+        rbs = s.solve_batch(wbs)
+        got[mode] = (rbs, wbs)
+        s.close()
+    for a, b, wa, wb in zip(got["0"][0], got["1"][0], got["0"][1], got["1"][1]):
+        assert a.struct.status == b.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert np.array_equal(wa.point_xyz, wb.point_xyz, equal_nan=True)
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run) and a.struct.chi2_final == b.struct.chi2_final
+
+
+def test_c5_share_on_the_fused_unit_is_bit_identical_to_the_gated_unit(olib, monkeypatch):
+    # the per-GPU workload of BASELINE config 5 (resident C2-size windows, GRAPH layer) in both unit forms
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=20, solver=2)
+    gbs = [abi.pack_window_with(backend.load_library().visfs_ba_pack_window, prm, abi.WindowBuffers(synth.make_window("C5", window_index=i)))[0] for i in range(4)]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VISFS_BA_BATCH_SPEC", mode)
+        s = backend.Solver(prm)
+        s.batch_upload(gbs); s.batch_reset()
+        rc, stats = s.batch_optimize()
+        assert rc == abi.OK
+        outs[mode] = ([s.batch_download(i) for i in range(4)], [(list(st.iterations_run), list(st.trials_run), st.pcg_iterations, st.chi2_final) for st in stats])
+        s.close()
+    assert outs["0"][1] == outs["1"][1]
+    for a, b in zip(outs["0"][0], outs["1"][0]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_a_failed_upload_leaves_no_graph_resident(olib):
+    """ws_upload overwrites the primary device arrays before the graph is validated — after a REJECTED upload the handle must
+    not keep the previous graph marked resident (its index structures over the rejected graph's arrays would be walked by the kernels)."""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=2)
+    lib = backend.load_library()
+    s = backend.Solver(prm)
+    gb = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(synth.make_window("C1")))[0]
+    s.upload(gb)
+    rc, _ = s.optimize()
+    assert rc == abi.OK
+    bad = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(synth.make_window("C1", window_index=1)))[0]
+    bad.obs_pose[[0, 1]] = bad.obs_pose[[1, 0]]                      # observations no longer sorted by (point, pose)
+    rc_bad = s.lib.visfs_ba_graph_upload(s.h, C.byref(bad.struct))
+    assert rc_bad == abi.ERR_BAD_ARGUMENT
+    rc2 = s.lib.visfs_ba_optimize(s.h, None)
+    assert rc2 == abi.ERR_NOT_LOADED
+    s.upload(gb)                                                     # the handle stays usable
+    rc3, _ = s.optimize()
+    assert rc3 == abi.OK
+    s.close()
+
+
+@pytest.mark.parametrize("seed", [559, 764, 873, 1136, 1242])
+def test_banded_solver_keeps_the_checker_s_accuracy_on_ill_conditioned_systems(olib, seed):
+    """VERDICT r03 item 3.  Windows without enough landmarks on some pose (random cases whose reduced system has cond(S) of 1e8 at
+    lambda = 1e-2 and 1e11 at 1e-5): the reference-default solver is a backward-stable Cholesky (Parameters.h:185), and production windows
+    have no fixed pose (Estimator.cpp:252), so S is routinely this badly conditioned.  k_band_chol must solve ITS system as accurately as
+    the checker's scalar Cholesky solves its own — measured against numpy.linalg.solve on each side's S and b_s; round 3's closed-form
+    pivot inverses were 1e2 (lambda = 1e-2) to 4e4 (1e-5) times worse (profiles/r03_stage_precision.log, profiles/r04_band_pivot_study.log)."""
+    import test_gpu_random as T
+    w, kw = T.random_case(seed)
+    o, s, gb = make_pair(olib, w, iterations=10, solver=0, robust_kernel_delta=kw["robust_kernel_delta"])
+    assert s.describe()["solver_kernel"] == 7                                       # k_band_chol
+    o.linearize(); s.linearize()
+    n6 = 6 * o.npf
+    for lam in (1e-2, 1e-5):
+        ot, gt = o.trial(lam), s.trial(lam)
+        assert ot[3] == gt[3] == 1                                                  # both factorisations succeed
+        So = o.fetch(abi.BUF_S).reshape(n6, n6); Sg = s.fetch(abi.BUF_S).reshape(n6, n6)
+        xo, xg = o.fetch(abi.BUF_DX_POSE), s.fetch(abi.BUF_DX_POSE)
+        eo = rel_err(xo, np.linalg.solve(So, o.fetch(abi.BUF_BS)))
+        eg = rel_err(xg, np.linalg.solve(Sg, s.fetch(abi.BUF_BS)))
+        assert eg <= 10.0 * max(eo, 1e-13), (seed, lam, eo, eg)
+    s.close(); o.close()

@@ -390,6 +390,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     auto lap = [&](const char* what) { if (timing) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "  upload %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - T0).count()); T0 = t; } };
     const visfs_ba_params& prm = h->prm;
     const bool ceres = prm.framework == 1;
+    // From the first mutation below (the primary arrays are overwritten before the graph has been validated) until the upload has gone
+    // through, NO graph is resident: a failed upload must not leave the previous graph's index structures marked usable over the
+    // rejected graph's arrays (visfs_ba_optimize then returns VISFS_BA_ERR_NOT_LOADED instead of walking them).
+    w.loaded = false;
     // (Optimizer.cpp:405-422: the Ceres branch never adds a wheel-odometry factor — links between two window poses fall in its "TODO" arm)
     const int Np = gr->n_poses, Nl = gr->n_points, No = gr->n_obs, Ne = ceres ? 0 : gr->n_odo;
     if (Np < 1 || Nl < 0 || No < 0 || Ne < 0) return bad(h, "negative sizes");
@@ -823,12 +827,18 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     // speculative linearise: a rejected trial wastes one linearisation, an accepted one saves k_decide + a launch gap — worth it
     // while the linearisation is cheap (latency-bound windows); large windows (C4: half the trials are rejected) and batch
     // members keep the gated form.
-    { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (!w.batch_member && No <= 150000)) && Np <= MAX_STAGED_POSES; }
+    { const char* e = std::getenv("VISFS_BA_SPEC"); w.spec = (e ? (e[0] == '1') : (No <= 150000)) && Np <= MAX_STAGED_POSES; }
     // Optimizer/Framework=1 runs the plain gated unit with the direct solver (k_small_solve's Cholesky for reduced systems <= 64 x 64):
     // one unit = one iteration of Ceres' minimizer loop
     if (ceres) { w.fused = false; w.spec = false; }
     // the fused form of the speculative unit: one launch less per iteration (VISFS_BA_SPEC_FUSED=0: the two-launch form, A/B runs and tests)
     { const char* e = std::getenv("VISFS_BA_SPEC_FUSED"); w.spec_fused = w.spec && !(e && e[0] == '0'); }
+    // Batch members (round 4) CAN run the same fused unit — 4 launches per iteration instead of the gated unit's 6; the two-launch form
+    // does not exist for them.  Measured (profiles/r04_batch_fused_unit_ab.log): a batched launch is bound by its arithmetic, not by its
+    // launch boundaries — fusing moves the linearisation's work into k_backsub (at 128 instead of 96 VGPRs) and behind the gather without
+    // removing any of it: 16 x C2 80.3 k -> 74.4 k it/s, 8 x C2 66.9 k -> 65.8 k.  So the gated unit stays the default for batch members
+    // (VISFS_BA_BATCH_SPEC=1 selects the fused unit: tests, A/B runs).
+    if (w.batch_member) { const char* e = std::getenv("VISFS_BA_BATCH_SPEC"); if (!w.spec_fused || !(e && e[0] == '1')) { w.spec = false; w.spec_fused = false; } }
     // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
     { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
     w.n_pairs = npairs; w.device_bytes = total_bytes + pbytes;
@@ -1024,7 +1034,8 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const b
     PcgLease pcg_lease;                                                                         // persistent PCG: co-residency budget of the device
     if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lease.acquire(h->device, pcg_wave_cost(dims_of(w.g), 1));
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
-    if (!(fresh_upload && w.solves_since_upload == 0)) { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
+    const bool reset_launched = !(fresh_upload && w.solves_since_upload == 0);
+    if (reset_launched) { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     if (w.fused) {
         // small window: both phases, the outlier pass and the final evaluation in one launch of one workgroup
         { ProfScope p(w, VISFS_BA_K_SMALL); launch_small_optimize(w.g, h->prm.solver, half, w.stream); }
@@ -1033,7 +1044,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const b
         if (rcs != VISFS_BA_OK) return rcs;
         if (w.h_state->status == VISFS_BA_ERR_DEVICE) { h->err = "fused LM loop did not terminate"; return VISFS_BA_ERR_DEVICE; }
         if (stats) fill_stats(*w.h_state, stats);
-        if (w.prof_mask) { w.active[VISFS_BA_K_SMALL] += 1; w.active[VISFS_BA_K_RESET] += 1; }
+        if (w.prof_mask) { w.active[VISFS_BA_K_SMALL] += 1; if (reset_launched) w.active[VISFS_BA_K_RESET] += 1; }
         return w.h_state->status;
     }
     // Both phases, their ends and the outlier pass are enqueued BEFORE the host knows how the first phase went: the phase-end
@@ -1117,7 +1128,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const b
         if (!w.spec && !w.fused_decide) w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
         w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT] += st.n_active[1];
         w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
-        w.active[VISFS_BA_K_PHASE_END] += 2; w.active[VISFS_BA_K_RESET] += 1;
+        w.active[VISFS_BA_K_PHASE_END] += 2; if (reset_launched) w.active[VISFS_BA_K_RESET] += 1;
     }
     return w.h_state->status;
 }
@@ -1190,6 +1201,9 @@ struct PackSummary { std::vector<SummaryPart>* part = nullptr; std::vector<int32
 int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph* g, int32_t* n_mono_skipped, WorkerPool* pool, PackSummary* ps = nullptr) {
     std::memset(g, 0, sizeof(*g));
     const auto te0 = std::chrono::steady_clock::now();
+    // std::map order (the direct pose table below and the hinted searches rely on it; visfs_ba_pack_window is public)
+    for (int i = 1; i < w->n_poses; ++i) if (w->pose_ids[i] <= w->pose_ids[i - 1]) return VISFS_BA_ERR_BAD_ARGUMENT;
+    for (int i = 1; i < w->n_points; ++i) if (w->point_ids[i] <= w->point_ids[i - 1]) return VISFS_BA_ERR_BAD_ARGUMENT;
     // poses: Twc = Twr * Trc ; Tcw = Twc^-1 as CameraPose(R,t) ; fixed iff id == rootId   (Optimizer.cpp:100-114)
     for (int i = 0; i < w->n_poses; ++i) {
         double Twc[12], Tcw[12];
@@ -1572,12 +1586,12 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     std::vector<DeviceGraph>& hg = bs.host_graphs;
     hg.resize(B);
     LaunchDims d = dims_of(ws[members[0]]->g);
-    bool fused = true, small_solve = true, fused_decide = true;
+    bool fused = true, small_solve = true, fused_decide = true, spec_fused = true;
     for (int b = 0; b < B; ++b) {
         const Workspace& w = *ws[members[b]];
         hg[b] = w.g;
         d = dims_max(d, dims_of(w.g));
-        fused = fused && w.fused; small_solve = small_solve && w.small_solve; fused_decide = fused_decide && w.fused_decide;
+        fused = fused && w.fused; small_solve = small_solve && w.small_solve; fused_decide = fused_decide && w.fused_decide; spec_fused = spec_fused && w.spec_fused;
     }
     PcgLease pcg_lease;                                                                // persistent PCG: co-residency budget of the device
     if (!fused && !small_solve && !d.pcg_cu && h->prm.solver == 2) pcg_lease.acquire(h->device, pcg_wave_cost(d, B));
@@ -1593,7 +1607,7 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     // come back in ONE copy; windows that rejected trials are topped up from what comes back.  Every launch is gated per window,
     // so the same sequence is safe for windows at different points of the schedule.
     const int half2 = (h->prm.robust_kernel_delta > 0.0 && !ceres) ? half : 0;                      // :310-311
-    auto units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, fused_decide, stream); first = false; } };
+    auto units = [&](int n, bool first) { for (int u = 0; u < n; ++u) { launch_unit_batch(bs.d_graphs, B, d, first, small_solve, h->prm.solver, fused_decide, spec_fused, stream); first = false; } };
     auto phase_end = [&](int which) {
         if (which == 0) launch_phase_end_batch(bs.d_graphs, B, d, 0, 1, half2, stream);             // :270-303
         else launch_phase_end_batch(bs.d_graphs, B, d, 1, 0, 0, stream);                            // :315-318
@@ -1850,7 +1864,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
         // groups: lanes per landmark, PCG variant class, small-solve / fused flags must agree inside one batched launch
         const char* env = std::getenv("VISFS_BA_BATCH");
         const bool batching = !(env && env[0] == '0');
-        std::map<std::array<int, 4>, std::vector<int>> groups;
+        std::map<std::array<int, 5>, std::vector<int>> groups;
         std::vector<int> singles;
         for (int i = 0; i < n; ++i) {
             if (!need[i]) continue;
@@ -1860,7 +1874,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             const bool batchable = batching && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
-            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
+            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0, ws.spec_fused ? 1 : 0 }].push_back(i);
         }
         std::vector<visfs_ba_stats> stats(n);
         int worst = VISFS_BA_OK;
@@ -1950,14 +1964,14 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
     return guarded(h, [&]() -> int {
         const int n = h->n_batch;
         if (n == 0) { h->err = "no batch resident"; return VISFS_BA_ERR_NOT_LOADED; }
-        std::map<std::array<int, 4>, std::vector<int>> groups;
+        std::map<std::array<int, 5>, std::vector<int>> groups;
         for (int i = 0; i < n; ++i) {
             const Workspace& ws = *h->batch[i];
             const bool band = h->prm.solver != 2 && !ws.small_solve && !ws.fused && ws.g.band_B >= 0;
             if (!(h->prm.solver == 2 || ws.small_solve || ws.fused || band)) { h->err = "batched launches need Optimizer/Solver=2, a banded reduced system (direct solver) or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
             if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
-            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0 }].push_back(i);
+            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0, ws.spec_fused ? 1 : 0 }].push_back(i);
         }
         int worst = VISFS_BA_OK;
         for (auto& kv : groups) {

@@ -214,8 +214,8 @@ __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Int
 // Where a kernel finds its window.  One: the DeviceGraph travels by value in the kernel arguments (single window).
 // Many: independent windows solved side by side — blockIdx.y selects the window from an array in HBM,
 // every window is gated by its own LmState, so the same launch serves windows at different points of their LM loops.
-struct One { DeviceGraph g; };
-struct Many { const DeviceGraph* gs; };
+struct One { DeviceGraph g; static constexpr bool batched = false; };
+struct Many { const DeviceGraph* gs; static constexpr bool batched = true; };
 // host side of the launchers: the by-value graph of a single window (a batch never reaches the callers of this: see staged())
 inline const DeviceGraph& graph_of_host(const One& s) { return s.g; }
 inline const DeviceGraph& graph_of_host(const Many&) { static const DeviceGraph none{}; return none; }
@@ -230,22 +230,15 @@ __device__ __forceinline__ const DeviceGraph& graph_of(const Many& s) {
 }
 
 // chi2() = e . (Omega e), Omega = I3 / pixelVariance (Optimizer.cpp:153)
-// How a kernel gets its linearisation set.  A window on its own (One) may run the speculative unit, so the set is chosen at run
-// time (lin_of: six pointers in SGPRs).  The windows of a batched launch (Many) never do — their set is always lin[0], read
-// in place from the graph in HBM at the point of use (computing six pointers up front cost k_linearize / k_backsub 9-13 %
-// in the batched launches: the graph of a batch is read with vector loads and the pointers stayed live in VGPRs).
-template <class Src> struct LinSel;
-template <> struct LinSel<One> {
+// How a kernel gets its linearisation set: chosen at run time (LmState::lin_sel; lin_of: seven pointers in SGPRs).  Round 4: the
+// windows of a batched launch (Many) run the fused speculative unit too, so they select between their two sets like a window on its
+// own (round 1-3: always lin[0], read in place — computing the pointers up front had cost the batched k_linearize / k_backsub 9-13 %
+// while the graph of a batch was still read with vector loads; it now arrives through the constant address space, in SGPRs).
+template <class Src> struct LinSel {
     static constexpr bool two_sets = true;
     LinBuf L;
     __device__ __forceinline__ LinSel(const DeviceGraph& g, const int k) : L(lin_of(g, k)) {}
     __device__ __forceinline__ const LinBuf& get() const { return L; }
-};
-template <> struct LinSel<Many> {
-    static constexpr bool two_sets = false;
-    const LinBuf& R;
-    __device__ __forceinline__ LinSel(const DeviceGraph& g, const int) : R(g.lin[0]) {}
-    __device__ __forceinline__ const LinBuf& get() const { return R; }
 };
 
 __device__ __forceinline__ double chi2_of(const Vec3& e, double iv) { return e.x * (iv * e.x) + e.y * (iv * e.y) + e.z * (iv * e.z); }
@@ -697,7 +690,10 @@ __device__ __forceinline__ void decider_run(const DeviceGraph& gd, double* red, 
     if (sd->mode & MODE_TRIAL) decide_gather_role(gd, sd, sd->decide_epoch + 1u, !sd->solver_failed && !sd->pcg_timeout, red, spec);
 }
 __device__ __forceinline__ void decider_of(const One& s, int, double* red, const int spec = 0) { decider_run(s.g, red, spec); }
-__device__ __forceinline__ void decider_of(const Many& s, const int j, double* red, const int = 0) { decider_run(s.gs[j], red); }
+__device__ __forceinline__ void decider_of(const Many& s, const int j, double* red, const int spec = 0) {
+    typedef const __attribute__((address_space(4))) DeviceGraph* ConstGraphPtr;
+    decider_run(*(const DeviceGraph*)(ConstGraphPtr)(s.gs + j), red, spec);
+}
 
 // ================================================================= K1/K2/K4: linearise the stereo edges
 // spec = 0: linearise the committed estimate (first unit of a phase, stage hooks, large windows) when the gate says so.
@@ -858,7 +854,7 @@ __device__ __forceinline__ double odo_role(const DeviceGraph& g, const LinBuf& L
 
 template <class Src>
 __global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec_arg) {
-    const bool spec = LinSel<Src>::two_sets && spec_arg;
+    const bool spec = !Src::batched && spec_arg;
     const DeviceGraph& g = graph_of(src);
     const LmState* st = g.st;
     int sel, ls;
@@ -2487,19 +2483,19 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
 // block-BANDED: block (i, j) exists only for |i - j| <= B, B = longest track - 1 (C2 / C4: B = 9 of 49 / 199 block rows), and a
 // triangular factor keeps that band.  This kernel factors the band block column by block column inside one workgroup — no dense
 // matrix, no launch per panel — and solves in the same launch.  The factorisation is the BLOCK form S = L D L^T (6x6 blocks, L unit
-// lower, D block diagonal: the SPD analogue of Cholesky with the square roots left out): its sequential chain per block column is one
-// 6x6 SPD inverse through two closed-form 3x3 inverses (~35 dependent fp64 operations at ~8 ns each) instead of six dependent
-// pivots with rsqrt + Newton (~100).
+// lower, D block diagonal).  The pivot block D_k is Cholesky-factored (six dependent pivots) and D_k^-1 is applied through the inverse of
+// its triangular factor, X^T (X g) — backward stable where round 3's explicit closed-form inverse (two 3x3 adjugates: a shorter chain)
+// was not: see band_chol6_inv.
 //   ring  [rows][B + 1][36]  LDS: block (I, I - d) of the lower band at [(I mod rows)][d]; rows == Npf when the whole band fits
 //                            (C2: 141 KB), else a sliding window of rows >= B + 2 block rows and the factor streams to band_L (HBM);
-//   step k:  A  wave 0: D_k^-1 (every lane redundantly, operands by LDS broadcast: no cross-lane traffic), positive-definiteness
-//               by Sylvester's criterion on the two 3x3 stages;  wave 1: forward-substitution step k - 1, hidden behind it;
+//   step k:  A  wave 0: D_k = C C^T and X = C^-1 (every lane redundantly, operands by LDS broadcast: no cross-lane traffic), positive
+//               definiteness = positive pivots;  waves 1..3: the rest of the trailing update of column k - 1, hidden behind it;
 //            B  L_ik = G_ik D_k^-1 for the <= B blocks below (G = the updated, unscaled block; two threads per block row),
 //               G kept aside for step C;
 //            C  A_ij -= L_ik G_jk^T for k < j <= i <= k + B (a thread per 3x3 tile); the next block row of S enters the ring;
 //   then the backward substitution on one wavefront (right-looking: x_k final, z_j -= L_kj^T x_k) and K8 (pose oplus).
-// Every sum has a fixed order: results are bitwise reproducible.  A block D_k that is not positive definite (what a non-positive
-// Cholesky pivot is) or not finite sets LmState::solver_failed: g2o's solver returns false and the LM trial is rejected.
+// Every sum has a fixed order: results are bitwise reproducible.  A non-positive or non-finite pivot sets LmState::solver_failed: g2o's
+// solver returns false and the LM trial is rejected.
 constexpr int BAND_T = 256;
 constexpr int BAND_MAX_W = 22;                                  // (B + 1) <= 22: a (B + 2)-row ring of 6x6 blocks fits the LDS budget
 size_t band_lds_bytes(const int npf, const int B, const int rows) {
@@ -2523,66 +2519,68 @@ bool band_plan(const int npf, const int B, int* rows, int* lds_bytes) {
     return true;
 }
 
-// 1 / x: v_rcp_f64 seed + two Newton steps (an IEEE division is ~10 dependent operations more)
-__device__ __forceinline__ double fast_rcp(const double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return y;
-}
-// Inverse of the symmetric 3x3 [a b c; b d e; c e f] (h = a b c d e f) in cofactor form; returns whether it is positive definite
-// (Sylvester: the nested principal minors f, d f - e^2 and the determinant).
-__device__ __forceinline__ bool spd3_inverse(const double h[6], double o[6]) {
-    const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
-    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    const double det = a * c00 + b * c01 + c * c02;
-    const double id = fast_rcp(det);
-    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
-    o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
-    return f > 0.0 && c00 > 0.0 && det > 0.0 && det <= DBL_MAX;
-}
-__device__ __forceinline__ int sym3(const int r, const int c) { return r <= c ? (r * (5 - r)) / 2 + c : (c * (5 - c)) / 2 + r; }   // index of (r, c) in (00 01 02 11 12 22)
-// Inverse of the SPD 6x6 block D = [P Q; Q^T R] (row-major; only its lower triangle is read) through two 3x3 inverses:
-//   Pi = P^-1, T = Pi Q, Sc = R - Q^T T, Si = Sc^-1, U = -T Si, V = Pi - U T^T;  D^-1 = [V U; U^T Si].
-// Every lane computes the whole inverse (operands arrive as LDS broadcasts); returns false when D is not positive definite.
-__device__ __forceinline__ bool band_inv6(const double* __restrict__ D, double inv[36]) {
-    double P[6], R[6], Q[9];                                   // Q[3 m + a] = D[3 + a][m]
+// Round 4: Cholesky of the SPD 6x6 pivot block D = C C^T (row-major in LDS, lower triangle read) and the INVERSE OF ITS FACTOR, X = C^-1
+// (lower triangular; written row-major with explicit zeros above the diagonal).  D^-1 = X^T X is never formed: it is APPLIED as
+// X^T (X g).  Why: a pose that sees few landmarks (or a window without a fixed pose, Estimator.cpp:252) has a nearly singular pivot
+// block, and L_ik = G_ik D_k^-1 through ANY explicit inverse of D_k carries a relative error eps * cond(D_k) into the factor — the
+// closed-form inverse of round 3 (band_inv6: two 3x3 adjugates) lost the whole solution at cond(S) = 8e10 where the scalar Cholesky of
+// the checker keeps five digits (profiles/r03_stage_precision.log: 7.3e-1 vs 1.8e-5).  The two triangular products are backward stable
+// (error eps * cond(C) = eps * sqrt(cond(D))): the dense NumPy study of the variants is in profiles/r04_band_pivot_study.log.
+// Every lane computes the whole factor redundantly (operands arrive as LDS broadcasts: no cross-lane traffic); six dependent pivots,
+// each v_rsq_f64 + two Newton steps.  Returns false when a pivot is not positive (what a failed Cholesky is) or not finite.
+__device__ __forceinline__ constexpr int tri6(const int i, const int j) { return i * (i + 1) / 2 + j; }       // j <= i
+__device__ __forceinline__ bool band_chol6_inv(const double* __restrict__ D, double X[36]) {
+    double a[21], r[6];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int c = r; c < 3; ++c) { P[sym3(r, c)] = D[6 * c + r]; R[sym3(r, c)] = D[6 * (3 + c) + 3 + r]; }
+        for (int j = 0; j <= i; ++j) a[tri6(i, j)] = D[6 * i + j];
+    bool ok = true;
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int j = 0; j < 6; ++j) {
+        const double p = a[tri6(j, j)];
+        ok = ok && (p > 0.0) && (p <= DBL_MAX);
+        r[j] = fast_rsqrt(p);
 #pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2) Q[3 * m + a2] = D[6 * (3 + a2) + m];
-    double Pi[6], T[9], Sc[6], Si[6], U[9];
-    const bool okP = spd3_inverse(P, Pi);
+        for (int i = j; i < 6; ++i) a[tri6(i, j)] *= r[j];                       // column j of C (C_jj = p / sqrt(p))
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+        for (int i = j + 1; i < 6; ++i)
 #pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) T[3 * m + b2] = Pi[sym3(m, 0)] * Q[b2] + Pi[sym3(m, 1)] * Q[3 + b2] + Pi[sym3(m, 2)] * Q[6 + b2];
+            for (int k = j + 1; k <= i; ++k) a[tri6(i, k)] -= a[tri6(i, j)] * a[tri6(k, j)];
+    }
+    // X = C^-1 by forward substitution, column by column: X_jj = 1 / C_jj = r_j, X_ij = -r_i sum_{m = j}^{i - 1} C_im X_mj
 #pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2)
+    for (int q = 0; q < 36; ++q) X[q] = 0.0;
 #pragma unroll
-        for (int b2 = a2; b2 < 3; ++b2) Sc[sym3(a2, b2)] = R[sym3(a2, b2)] - (Q[a2] * T[b2] + Q[3 + a2] * T[3 + b2] + Q[6 + a2] * T[6 + b2]);
-    const bool okS = spd3_inverse(Sc, Si);
+    for (int j = 0; j < 6; ++j) {
+        X[6 * j + j] = r[j];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+        for (int i = j + 1; i < 6; ++i) {
+            double sacc = 0.0;
 #pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) U[3 * m + b2] = -(T[3 * m] * Si[sym3(0, b2)] + T[3 * m + 1] * Si[sym3(1, b2)] + T[3 * m + 2] * Si[sym3(2, b2)]);
-#pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-        for (int b2 = a2; b2 < 3; ++b2) {
-            const double v = Pi[sym3(a2, b2)] - (U[3 * a2] * T[3 * b2] + U[3 * a2 + 1] * T[3 * b2 + 1] + U[3 * a2 + 2] * T[3 * b2 + 2]);
-            inv[6 * a2 + b2] = v; inv[6 * b2 + a2] = v;
-            inv[6 * (3 + a2) + 3 + b2] = Si[sym3(a2, b2)]; inv[6 * (3 + b2) + 3 + a2] = Si[sym3(a2, b2)];
+            for (int m = j; m < i; ++m) sacc += a[tri6(i, m)] * X[6 * m + j];
+            X[6 * i + j] = -r[i] * sacc;
         }
+    }
+    return ok;
+}
+// y = D^-1 g = X^T (X g) for the six-vector g, entries [c0, c0 + NC) of the result (static indices: X comes as LDS broadcasts)
+template <int NC>
+__device__ __forceinline__ void band_apply_dinv(const double* __restrict__ X, const double g[6], const int c0, double out[NC]) {
+    double t[6];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int i = 0; i < 6; ++i) {
+        double v = X[6 * i] * g[0];
 #pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) { inv[6 * m + 3 + b2] = U[3 * m + b2]; inv[6 * (3 + b2) + m] = U[3 * m + b2]; }
-    return okP && okS;
+        for (int j = 1; j <= i; ++j) v += X[6 * i + j] * g[j];
+        t[i] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        // (rows above the diagonal of column c0 + c hold exact zeros: six terms with static register indices whatever c0 is)
+        const double* col = X + c0 + c;
+        out[c] = ((col[0] * t[0] + col[6] * t[1]) + (col[12] * t[2] + col[18] * t[3])) + (col[24] * t[4] + col[30] * t[5]);
+    }
 }
 
 template <class Src>
@@ -2609,7 +2607,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     double* ring = band_lds;                                   // [RR][W][36]
     double* gk = ring + (size_t)RR * rowsz;                    // [2][W][36] the unscaled blocks G_ik of column k in half k & 1 (slot m = i - k)
     double* cvec = gk + 2 * rowsz;                             // [6 Npf] right-hand side -> L^-1 b -> D^-1 L^-1 b -> x
-    double* dinv = cvec + 6 * Npf;                             // [2][36] D_k^-1 of the current / previous step
+    double* dinv = cvec + 6 * Npf;                             // [2][36] X_k = C_k^-1 (D_k = C_k C_k^T) of the current / previous step
     double* g1buf = dinv + 72;                                 // [36] G_{k+1,k}, read by every thread of step B while its slot is being overwritten
     int* sflag = reinterpret_cast<int*>(g1buf + 36);           // (8 doubles reserved)
     int* scode = reinterpret_cast<int*>(g1buf + 36 + 8);       // [Npf][W] stored block ids (DeviceGraph::band_code)
@@ -2661,10 +2659,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
         for (int c = 0; c < 6; ++c) cs[c] = cvec[6 * s_ + c];
         const int nb = min(B, Npf - 1 - s_);
         double z = 0.0;
-        if (lane < 6) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) z += Di[6 * lane + c] * cs[c];
-        }
+        if (lane < 6) { double zz[1]; band_apply_dinv<1>(Di, cs, lane, zz); z = zz[0]; }
         for (int e = lane; e < 6 * nb; e += 64) {
             const int m = e / 6 + 1, rr = e - 6 * (m - 1);
             const double* L = ring_row(ks, m) + 36 * m + 6 * rr;
@@ -2718,7 +2713,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
             double g1 = 0.0;
             if (nb > 0 && lane < 36) g1 = (ring_row(kk, 1) + 36)[lane];
             double inv[36];
-            const bool ok = band_inv6(rowk, inv);
+            const bool ok = band_chol6_inv(rowk, inv);             // (inv: X = C_k^-1, lower triangular; D_k^-1 is applied as X^T X)
             if (nb > 0 && lane < 36) g1buf[lane] = g1;
             if (lane == 0) {
                 if (!ok) sflag[0] = 1;
@@ -2768,20 +2763,17 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
                 double* rowi = ring_row(kk, m);
                 double* row = rowi + 36 * m + 6 * rr;
                 double* C = rowi + 36 * (m - 1) + 6 * rr + 3 * hf;    // block (k + m, k + 1), columns 3 hf ..
-                const double* dcol = Dk + 18 * hf;                    // rows 3 hf .. of the symmetric D^-1 = its columns
                 const double* g1r = g1buf + 18 * hf;                  // rows 3 hf .. of G_{k+1,k}
                 // every load first (one LDS round trip), static register indices throughout (hf only ever enters addresses and selects)
-                double a[6], dc[18], g1[18], cv[3];
+                double a[6], g1[18], cv[3];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) a[c] = row[c];
 #pragma unroll
-                for (int q = 0; q < 18; ++q) { dc[q] = dcol[q]; g1[q] = g1r[q]; }
+                for (int q = 0; q < 18; ++q) g1[q] = g1r[q];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) cv[c] = C[c];
                 double o[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    o[c] = ((a[0] * dc[6 * c] + a[1] * dc[6 * c + 1]) + (a[2] * dc[6 * c + 2] + a[3] * dc[6 * c + 3])) + (a[4] * dc[6 * c + 4] + a[5] * dc[6 * c + 5]);
+                band_apply_dinv<3>(Dk, a, 3 * hf, o);                  // row rr of L_ik = G_ik D_k^-1, columns 3 hf ..: X^T (X g)
                 double* gr = G + 36 * m + 6 * rr + 3 * hf;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { gr[c] = hf ? a[3 + c] : a[c]; row[3 * hf + c] = o[c]; }   // (the partner lane has read the row: same wavefront, program order)
@@ -3011,11 +3003,14 @@ __device__ __forceinline__ void backsub_landmark(const DeviceGraph& g, const Lin
 // (ODOSPEC), and the decider, which flips lin_sel on acceptance, marks the pose-major sums as pending (LmState::lin_b_pending): they
 // need EVERY trial landmark, so the role-B workgroups of the next k_schur_partial launch form them.  One launch (and its ~5 us of
 // dependent-dispatch latency) less per iteration than k_backsub followed by k_linearize<SPEC>.
+#ifndef VISFS_BA_BATCH_LINA_WAVES
+#define VISFS_BA_BATCH_LINA_WAVES 4      // waves per SIMD the batched fused tail is compiled for (A/B builds)
+#endif
 template <int G, class Src, bool ODOSPEC, bool STG = true, bool DEC = false, int DL = 0, bool LINA = false>
-__global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void k_backsub(const Src src) {
+__global__ __launch_bounds__(256, (DEC && Src::batched) ? (LINA ? (ODOSPEC ? 2 : VISFS_BA_BATCH_LINA_WAVES) : 5) : 1) void k_backsub(const Src src) {
     static_assert(!(DEC && ODOSPEC) || LINA, "the decision rides on the gated unit only");
     static_assert(DL == 0 || (!DEC && !ODOSPEC), "the dogleg passes are plain launches");
-    static_assert(!LINA || (DEC && LinSel<Src>::two_sets && DL == 0), "the fused tail is the single-window speculative unit");
+    static_assert(!LINA || (DEC && DL == 0), "the fused tail carries the decision");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (DEC) {
         const int dw = decider_window();
@@ -3036,7 +3031,7 @@ __global__ __launch_bounds__(256, (DEC && !LinSel<Src>::two_sets) ? 5 : 1) void 
     // (the tag is read where it is used: nothing of the decision's bookkeeping stays live across the landmark role)
     if (DEC && trial && !go && (int)blockIdx.x <= g.n_lin_a && threadIdx.x == 0) publish_trial(g, blockIdx.x, st->decide_epoch + 1u, 0.0, 0.0);
     // snapshot for the speculative linearisation that may follow (its workgroups must not read what the LM decision writes)
-    if (!DEC && !LINA && LinSel<Src>::two_sets && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
+    if (!DEC && !LINA && !Src::batched && blockIdx.x == 0 && threadIdx.x == 0) { st->spec_go = go ? 1 : 0; st->spec_src = st->sel ^ 1; st->spec_dst = st->lin_sel ^ 1; }
     if (!go) return;
     double* sRt = smem;
     double* red = smem + (STG ? 12 * g.Np : 0);
@@ -3931,6 +3926,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.group = g.group;
     d.np = g.Np;
     d.lin_blocks = g.n_lin_a + g.n_chunks;
+    d.chunks = g.n_chunks;
     d.backsub_blocks = g.n_lin_a + 1;
     d.sch_wgs = g.n_sch > 0 ? (((g.n_sch + 3) / 4) + 7) / 8 * 8 : 0;
     d.sch_multi = g.sch_chunk > 64 ? 1 : 0;
@@ -3950,7 +3946,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
 }
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     LaunchDims d = a;
-    d.np = std::max(a.np, b.np); d.lin_blocks = std::max(a.lin_blocks, b.lin_blocks); d.backsub_blocks = std::max(a.backsub_blocks, b.backsub_blocks);
+    d.np = std::max(a.np, b.np); d.lin_blocks = std::max(a.lin_blocks, b.lin_blocks); d.chunks = std::max(a.chunks, b.chunks); d.backsub_blocks = std::max(a.backsub_blocks, b.backsub_blocks);
     d.sch_wgs = std::max(a.sch_wgs, b.sch_wgs); d.fin_wgs = std::max(a.fin_wgs, b.fin_wgs); d.pcg_rows = std::max(a.pcg_rows, b.pcg_rows);
     d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
     d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
@@ -3977,7 +3973,7 @@ static void launch_lin_t(const Src& src, const LaunchDims& d, int B, int spec, h
         TIMED_LAUNCH((k_linearize<G, One, false, false>), dim3(d.lin_blocks, B), dim3(256), lds, s, One{ graph_of_host(src) });
         return;
     }
-    if (LinSel<Src>::two_sets && spec) { ensure_lds(k_linearize<G, Src, LinSel<Src>::two_sets>, lds); TIMED_LAUNCH((k_linearize<G, Src, LinSel<Src>::two_sets>), dim3(d.lin_blocks + 1, B), dim3(256), lds, s, src); }
+    if (!Src::batched && spec) { ensure_lds(k_linearize<G, Src, !Src::batched>, lds); TIMED_LAUNCH((k_linearize<G, Src, !Src::batched>), dim3(d.lin_blocks + 1, B), dim3(256), lds, s, src); }
     else { ensure_lds(k_linearize<G, Src, false>, lds); TIMED_LAUNCH((k_linearize<G, Src, false>), dim3(d.lin_blocks, B), dim3(256), lds, s, src); }
 }
 // dec: the launch carries the LM decision (one workgroup more; k_decide is then not launched)
@@ -3988,10 +3984,10 @@ static void launch_backsub_t(const Src& src, const LaunchDims& d, int B, int odo
         else TIMED_LAUNCH((k_backsub<G, One, false, false>), dim3(d.backsub_blocks, B), dim3(256), (size_t)8 * sizeof(double), s, One{ graph_of_host(src) });
         return;
     }
-    if (LinSel<Src>::two_sets && odospec) {
+    if (!Src::batched && odospec) {
         const size_t lds = (size_t)std::max(24 * d.np + 8, 128) * sizeof(double);
-        ensure_lds(k_backsub<G, Src, LinSel<Src>::two_sets>, lds);
-        TIMED_LAUNCH((k_backsub<G, Src, LinSel<Src>::two_sets>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
+        ensure_lds(k_backsub<G, Src, !Src::batched>, lds);
+        TIMED_LAUNCH((k_backsub<G, Src, !Src::batched>), dim3(d.backsub_blocks, B), dim3(256), lds, s, src);
     } else if (dec) {
         const size_t lds = (size_t)(24 * d.np + 8) * sizeof(double);
         ensure_lds(k_backsub<G, Src, false, true, true>, lds);
@@ -4046,7 +4042,7 @@ static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream
         static const int gv = []() { const char* e = std::getenv("VISFS_BA_PCG_GATHER"); return e ? std::atoi(e) : 1; }();
         // the XCD-local form only for a window on its own: its <= 64 one-wave workgroups are resident even if the dispatcher packs
         // them all onto one XCD (that is the intent); a batch on one XCD would not be (co-residency must not depend on placement)
-        if (gv == 3 && LinSel<Src>::two_sets) TIMED_LAUNCH((k_pcg1<One, 3>), dim3(8 * d.pcg_rows, B), dim3(64), 0, s, One{ graph_of_host(src) });
+        if (gv == 3 && !Src::batched) TIMED_LAUNCH((k_pcg1<One, 3>), dim3(8 * d.pcg_rows, B), dim3(64), 0, s, One{ graph_of_host(src) });
         else if (gv >= 2) TIMED_LAUNCH((k_pcg1<Src, 2>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else if (gv == 1) TIMED_LAUNCH((k_pcg1<Src, 1>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else TIMED_LAUNCH((k_pcg1<Src, 0>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
@@ -4105,31 +4101,32 @@ void launch_backsub_decide(const DeviceGraph& g, hipStream_t s) { launch_backsub
 void launch_decide(const DeviceGraph& g, hipStream_t s) { TIMED_LAUNCH((k_decide<One>), dim3(1), dim3(256), 0, s, One{ g }); }
 // The fused speculative unit (single window, staged poses): its last launch — back-substitution, trial chi2, the LM decision and role A
 // of the trial's linearisation — and its first — the Schur gather with the pending role-B workgroups behind it.
-template <int G>
-static void launch_backsub_lin_t(const DeviceGraph& g, const LaunchDims& d, hipStream_t s) {
-    const One src{ g };
+template <int G, class Src>
+static void launch_backsub_lin_t(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     const size_t lds = (size_t)std::max(24 * d.np + 8, 128) * sizeof(double);
-    if (d.has_odo) { ensure_lds(k_backsub<G, One, true, true, true, 0, true>, lds); TIMED_LAUNCH((k_backsub<G, One, true, true, true, 0, true>), dim3(d.backsub_blocks + 1, 1), dim3(256), lds, s, src); }
-    else { ensure_lds(k_backsub<G, One, false, true, true, 0, true>, lds); TIMED_LAUNCH((k_backsub<G, One, false, true, true, 0, true>), dim3(d.backsub_blocks + 1, 1), dim3(256), lds, s, src); }
+    // grid: the landmark workgroups + the odometry / laser workgroup of the largest window, then one decider per window in the last grid row
+    if (d.has_odo) { ensure_lds(k_backsub<G, Src, true, true, true, 0, true>, lds); TIMED_LAUNCH((k_backsub<G, Src, true, true, true, 0, true>), dim3(d.backsub_blocks + B, B), dim3(256), lds, s, src); }
+    else { ensure_lds(k_backsub<G, Src, false, true, true, 0, true>, lds); TIMED_LAUNCH((k_backsub<G, Src, false, true, true, 0, true>), dim3(d.backsub_blocks + B, B), dim3(256), lds, s, src); }
 }
-void launch_backsub_lin_decide(const DeviceGraph& g, hipStream_t s) {
-    const LaunchDims d = dims_of(g);
+template <class Src>
+static void launch_backsub_lin_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
     switch (d.group) {
-        case 4: launch_backsub_lin_t<4>(g, d, s); break;
-        case 8: launch_backsub_lin_t<8>(g, d, s); break;
-        case 16: launch_backsub_lin_t<16>(g, d, s); break;
-        case 32: launch_backsub_lin_t<32>(g, d, s); break;
-        default: launch_backsub_lin_t<64>(g, d, s); break;
+        case 4: launch_backsub_lin_t<4>(src, d, B, s); break;
+        case 8: launch_backsub_lin_t<8>(src, d, B, s); break;
+        case 16: launch_backsub_lin_t<16>(src, d, B, s); break;
+        case 32: launch_backsub_lin_t<32>(src, d, B, s); break;
+        default: launch_backsub_lin_t<64>(src, d, B, s); break;
     }
 }
-void launch_schur_partial_roleb(const DeviceGraph& g, hipStream_t s) {
-    const LaunchDims d = dims_of(g);
-    const int grid = d.sch_wgs + g.n_chunks;
+template <class Src>
+static void launch_schur_partial_roleb_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    const int grid = d.sch_wgs + d.chunks;                    // (a window's role-B workgroups start right behind ITS share of the chunk list)
     if (grid <= 0) return;
-    const One src{ g };
-    if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, One, false, true>), dim3(grid, 1), dim3(256), 0, s, src);
-    else TIMED_LAUNCH((k_schur_partial<false, One, false, true>), dim3(grid, 1), dim3(256), 0, s, src);
+    if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src, false, true>), dim3(grid, B), dim3(256), 0, s, src);
+    else TIMED_LAUNCH((k_schur_partial<false, Src, false, true>), dim3(grid, B), dim3(256), 0, s, src);
 }
+void launch_backsub_lin_decide(const DeviceGraph& g, hipStream_t s) { launch_backsub_lin_src(One{ g }, dims_of(g), 1, s); }
+void launch_schur_partial_roleb(const DeviceGraph& g, hipStream_t s) { launch_schur_partial_roleb_src(One{ g }, dims_of(g), 1, s); }
 // Optimizer/Framework=1 with the DOGLEG strategy: pass 1 (Gauss-Newton landmark step + the inner products), the combination, pass 2 (trial state)
 template <int G>
 static void launch_backsub_dogleg_t(const DeviceGraph& g, const LaunchDims& d, int pass, hipStream_t s) {
@@ -4217,12 +4214,16 @@ static void launch_backsub_dogleg_many(const Many& src, const LaunchDims& d, int
         default: launch_backsub_dogleg_many_t<64>(src, d, B, pass, s); break;
     }
 }
-void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, hipStream_t s) {
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, bool spec_fused, hipStream_t s) {
     const Many src{ gs };
-    launch_linearize_src(src, d, B, 0, s);             // batched windows keep the gated unit (LinSel<Many>: set 0 only)
+    // spec_fused (round 4): the members run the fused speculative unit of a window on its own — k_linearize only in the first unit of a
+    // phase, the Schur gather with the pending pose-major role behind it, the back-substitution with the LM decision and the landmark-major
+    // role of the trial's linearisation on board: 4 launches per unit instead of 6 (3 instead of 5 with k_small_solve)
+    if (!spec_fused || first) launch_linearize_src(src, d, B, 0, s);
     if (d.ceres) launch_ceres_lin_finalize_src(src, B, s);   // Optimizer/Framework=1: cost, gradient test, Jacobi scaling after EVERY linearisation
     else if (first) launch_lin_finalize_src(src, 0, B, s);
-    launch_schur_partial_src(src, d, B, s);
+    if (spec_fused) launch_schur_partial_roleb_src(src, d, B, s);
+    else launch_schur_partial_src(src, d, B, s);
     if (small_solve) hipLaunchKernelGGL((k_small_solve<Many>), dim3(1, B), dim3(512), 0, s, src, solver);
     else if (solver != 2) {
         // the reference-default linear solver in batched launches: one workgroup per window factors its banded S (callers only group
@@ -4240,6 +4241,7 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
         hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
         return;
     }
+    if (spec_fused) { launch_backsub_lin_src(src, d, B, s); return; }
     // the LM decision rides on k_backsub (fused_decide = false: one k_decide launch for all windows, as in round 1)
     launch_backsub_src(src, d, B, 0, fused_decide ? 1 : 0, s);
     if (!fused_decide) hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);

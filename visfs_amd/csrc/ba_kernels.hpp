@@ -9,7 +9,7 @@
 namespace visfs_ba {
 
 // Launch geometry of one window, or the element-wise maximum over a batch of windows (same lanes-per-landmark group).
-struct LaunchDims { int group, np, lin_blocks, backsub_blocks, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave, pcg_cu, band, band_lds, ceres, dogleg; };
+struct LaunchDims { int group, np, chunks, lin_blocks, backsub_blocks, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave, pcg_cu, band, band_lds, ceres, dogleg; };
 LaunchDims dims_of(const DeviceGraph& g);
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b);
 
@@ -48,7 +48,7 @@ bool small_path_fits(const DeviceGraph& g);                          // the wind
 void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s);   // both phases + outlier pass in one launch
 // batches of independent windows: gs = B DeviceGraphs in HBM, blockIdx.y = window
 void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int max_iter, int gauss_newton, int restore, hipStream_t s);
-void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, hipStream_t s);
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, bool spec_fused, hipStream_t s);
 void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -50,21 +51,24 @@ public:
     }
     // fn(task, slot) for every task in [0, n), slot = 0 for the caller and 1 .. size() - 1 for the workers (per-thread accumulators);
     // returns when all have finished.  Tasks are claimed one by one, so a worker that wakes late still takes what is left: hand out
-    // several tasks per thread.  fn must not throw.
+    // several tasks per thread.  A task that throws (the bodies allocate: std::bad_alloc) never escapes a worker thread and never
+    // leaves the region early: the exception is swallowed where it is thrown, every task is still counted, and run() rethrows
+    // std::bad_alloc on the CALLER's thread once all tasks have drained (the C ABI's guarded() turns it into an error code).
     void run(int n, const std::function<void(int, int)>& fn) {
         if (n <= 0) return;
         if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
         place_near_caller();
         { std::lock_guard<std::mutex> lk(m_);
           region_ += 1; fn_ = &fn; n_ = n;
+          failed_.store(false, std::memory_order_relaxed);
           left_.store(n, std::memory_order_relaxed);
           ticket_.store((unsigned long long)region_ << 32, std::memory_order_release);
           gen_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         work(0);
         while (left_.load(std::memory_order_acquire) > 0) { /* a worker is finishing its last task */ }
-        std::lock_guard<std::mutex> lk(m_);
-        fn_ = nullptr;
+        { std::lock_guard<std::mutex> lk(m_); fn_ = nullptr; }
+        if (failed_.load(std::memory_order_acquire)) throw std::bad_alloc();
     }
 private:
     // The caller has just produced (or is about to consume) the arrays a region works on: they sit in ITS last-level cache.  A worker on
@@ -123,7 +127,7 @@ private:
             const int i = (int)(t & 0xffffffffull);
             if (i >= n) return;
             if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
-            (*f)(i, slot);
+            try { (*f)(i, slot); } catch (...) { failed_.store(true, std::memory_order_release); }
             left_.fetch_sub(1, std::memory_order_acq_rel);
             t = ticket_.load(std::memory_order_acquire);
         }
@@ -151,6 +155,7 @@ private:
     std::atomic<unsigned> gen_{ 0 };
     std::atomic<unsigned long long> ticket_{ 0 };
     std::atomic<int> left_{ 0 };
+    std::atomic<bool> failed_{ false };
     const std::function<void(int, int)>* fn_ = nullptr;
     int n_ = 0;
     unsigned region_ = 0;

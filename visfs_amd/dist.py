@@ -13,6 +13,26 @@ def env_rank():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
+def self_launch(script, argv, n_ranks, python=None, timeout=None):
+    """`python script --gpus N ...` started PLAINLY (no torchrun environment): start the N ranks as a CHILD process —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> script argv...` —
+    relay its stdout / stderr and return its exit code.  Never an exec: the caller must not have touched the GPU (and does not need
+    to: it only waits), the ranks are its grandchildren.  The port is one the kernel has just handed out as free."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env["VISFS_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.run(cmd, env=env, timeout=timeout)      # stdout / stderr inherited: rank 0's JSON line goes straight through
+    return proc.returncode
+
+
 def shard_windows(n_windows, rank, world_size):
     """Contiguous blocks: window w → rank w // ceil(n/world). Returns the window indices owned by `rank`."""
     per = (n_windows + world_size - 1) // world_size
