@@ -459,8 +459,74 @@ def per_frame_call(args, prm, calls=24):
             "iterations_per_s_incl_pcie": round(its / dt, 1), "host_threads": os.environ.get("VISFS_BA_THREADS", "default")}
 
 
+def _cpu_topology_pick(n):
+    """n CPUs for the OpenMP baseline, packed into as few last-level-cache domains as possible, starting with the domain this process
+    runs on; one hardware thread per core first (SMT siblings only when the allowed cores run out).  Returns (cpus, n_domains)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+
+    def read_list(path):
+        try:
+            out = []
+            for part in open(path).read().strip().split(","):
+                if not part:
+                    continue
+                lo, _, hi = part.partition("-")
+                out += list(range(int(lo), int(hi or lo) + 1))
+            return out
+        except (OSError, ValueError):
+            return None
+    dom_of, core_of = {}, {}
+    for c in allowed:
+        d = read_list(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list")
+        sib = read_list(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")
+        dom_of[c] = min(d) if d else 0
+        core_of[c] = min(sib) if sib else c
+    try:
+        here = os.sched_getcpu() if hasattr(os, "sched_getcpu") else allowed[0]
+    except OSError:
+        here = allowed[0]
+    doms = sorted(set(dom_of.values()), key=lambda d: (d != dom_of.get(here, -1), d))
+    primary, siblings = [], []
+    for d in doms:
+        seen = set()
+        for c in allowed:
+            if dom_of[c] != d:
+                continue
+            (siblings if core_of[c] in seen else primary).append(c)
+            seen.add(core_of[c])
+    pick = (primary + siblings)[:n]
+    return pick, len({dom_of[c] for c in pick})
+
+
+def _time_oracle(olib, prm, gb, threads, pin, budget_s, min_runs=10, max_runs=40):
+    """Median / spread of full solves of the resident window on `threads` threads (pin: CPU list for oracle_omp_pin, or None)."""
+    import oracle_lib
+    s = oracle_lib.OracleSystem(olib, prm, gb, threads)
+    bound = 0
+    if pin:
+        arr = (C.c_int32 * len(pin))(*pin)
+        bound = olib.oracle_omp_pin(arr, len(pin))
+    secs, its = [], 0
+    for _ in range(2):                                  # warm-ups (page faults, thread team start)
+        s.reset(); s.optimize()
+    t_end = time.perf_counter() + budget_s
+    while len(secs) < min_runs or (time.perf_counter() < t_end and len(secs) < max_runs):
+        s.reset()
+        rc, st, sec = s.optimize()
+        secs.append(sec); its = st.iterations_run[0] + st.iterations_run[1]
+    s.close()
+    if pin:
+        olib.oracle_omp_unpin()
+    secs = np.array(secs)
+    return {"its": int(its), "runs": int(len(secs)), "median_s": float(np.median(secs)), "min_s": float(secs.min()), "max_s": float(secs.max()), "threads_bound": int(bound)}
+
+
 def cpu_baseline(args, prm):
-    """The CPU oracle ('port' of the g2o algorithm) timed on this box's host cores: bounded sample."""
+    """The CPU oracle ('port' of the g2o algorithm) timed on this box's host cores: bounded sample (>= 10 full solves each,
+    median).  Two builds — x86-64-v3 (the checker's: AVX2, no contraction) and, where the CPU has AVX-512, x86-64-v4 with contraction
+    into FMAs (what -O3 -march=native gives on the GPU boxes' Zen 5 hosts) — the faster one is the reported value.  The OpenMP team is
+    PINNED: one thread per core, packed into as few L3 domains as the granted core count allows, starting with this process's own
+    (unpinned, the same binary measured 181 / 673 / 465 it/s in rounds 1-3: VERDICT r03)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from visfs_amd import abi, synth
     import oracle_lib
@@ -468,16 +534,14 @@ def cpu_baseline(args, prm):
     w = synth.make_window(args.config, window_index=0)
     wb = abi.WindowBuffers(w)
     gb, *_ = abi.pack_window_with(olib.oracle_pack_window, prm, wb)
-    s = oracle_lib.OracleSystem(olib, prm, gb, 1)
-    secs, its = [], 0
-    t_budget = time.perf_counter() + 15.0
-    runs = 0
-    while runs < 3 or (time.perf_counter() < t_budget and runs < 25):
-        s.reset()
-        rc, st, sec = s.optimize()
-        secs.append(sec); its = st.iterations_run[0] + st.iterations_run[1]; runs += 1
-    s.close()
-    med = float(np.median(secs))
+    big = len(w["ref_feature"]) >= 200000
+    builds = [("x86-64-v3", False)] + ([("x86-64-v4+fma", True)] if oracle_lib.cpu_has_avx512() else [])
+    serial = {}
+    for name, v4 in builds:
+        lib = oracle_lib.load(v4=v4)
+        serial[name] = _time_oracle(lib, prm, gb, 1, None, 4.0 if big else 6.0, min_runs=3 if big else 10)
+    best = min(serial, key=lambda k: serial[k]["median_s"])
+    r = serial[best]
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -493,26 +557,30 @@ def cpu_baseline(args, prm):
         quota = None if q == "max" else float(q) / float(per)
     except (OSError, ValueError):
         pass
-    out = {"value": round(its / med, 2), "unit": "BA iterations/s", "cores": 1, "kind": "port",
+    out = {"value": round(r["its"] / r["median_s"], 2), "unit": "BA iterations/s", "cores": 1, "kind": "port",
            "cpu_model": cpu_model, "nproc": os.cpu_count(), "usable_cores": usable, "cgroup_cpu_quota_cores": quota,
-           "sample": f"{runs} full solves of the same {args.config} window ({its} outer iterations each), median; "
-                     f"g2o-algorithm restatement in C (oracle/), single thread, gcc -O3 x86-64-v3"}
+           "build": best, "builds": {k: round(v["its"] / v["median_s"], 2) for k, v in serial.items()},
+           "spread": {"runs": r["runs"], "min": round(r["its"] / r["max_s"], 2), "max": round(r["its"] / r["min_s"], 2)},
+           "sample": f"{r['runs']} full solves of the same {args.config} window ({r['its']} outer iterations each), median; "
+                     f"g2o-algorithm restatement in C (oracle/), single thread, gcc -O3, fastest of {list(serial)}"}
     # SURVEY §8d also asks for the OpenMP build of the same restatement over the host cores (g2o's own default is serial)
     try:
         # every core this process may use: the affinity mask, capped by the cgroup CPU quota (threads beyond the quota only get throttled)
         nthr = max(1, int(min(usable, quota) if quota else usable))
-        olib_omp = oracle_lib.load(omp=True)
-        so = oracle_lib.OracleSystem(olib_omp, prm, gb, nthr)
-        secs_o, t_budget = [], time.perf_counter() + 6.0
-        while len(secs_o) < 3 or (time.perf_counter() < t_budget and len(secs_o) < 25):
-            so.reset()
-            rc, st, sec = so.optimize()
-            secs_o.append(sec)
-        so.close()
-        out["openmp"] = {"value": round((st.iterations_run[0] + st.iterations_run[1]) / float(np.median(secs_o)), 2), "cores": nthr,
+        pin, ndom = _cpu_topology_pick(nthr)
+        omp = {}
+        for name, v4 in builds:
+            lib = oracle_lib.load(omp=True, v4=v4)
+            omp[name] = _time_oracle(lib, prm, gb, nthr, pin, 3.0 if big else 4.0, min_runs=3 if big else 10)
+        bo = min(omp, key=lambda k: omp[k]["median_s"])
+        ro = omp[bo]
+        out["openmp"] = {"value": round(ro["its"] / ro["median_s"], 2), "cores": nthr, "build": bo,
+                         "builds": {k: round(v["its"] / v["median_s"], 2) for k, v in omp.items()},
+                         "spread": {"runs": ro["runs"], "min": round(ro["its"] / ro["max_s"], 2), "max": round(ro["its"] / ro["min_s"], 2)},
+                         "placement": f"{ro['threads_bound']} of {nthr} threads bound one per CPU {pin[:4]}..{pin[-1]} in {ndom} L3 domain(s), starting with this process's own",
                          "note": "OpenMP build of the same restatement; threads = usable cores (affinity mask capped by the cgroup CPU quota)"}
     except Exception as e:      # the OpenMP library is optional
-        out["openmp"] = {"error": str(e)[:80]}
+        out["openmp"] = {"error": str(e)[:120]}
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VISFS_BA_ABI_VERSION 6
+#define VISFS_BA_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------- */
 /* The reference signals failure by returning an EMPTY pose map
@@ -128,7 +128,8 @@ typedef struct visfs_ba_result {
     double   chi2_phase1;         /* Optimizer.cpp:271 */
     double   chi2_final;          /* Optimizer.cpp:315 */
     int32_t  warn_mono_skipped;   /* observations that would take the reference's uninitialised mono branch (Optimizer.cpp:197-210): skipped */
-    int32_t  reserved;
+    int32_t  solver_fallback;     /* ABI 7: 1 = Optimizer/Solver=2's persistent PCG could not keep its workgroups resident (another process on the
+                                   * GPU) and this window was solved again, in the same call, on the direct solver — see visfs_ba_stats */
 } visfs_ba_result;
 
 /* ---- GRAPH layer: the factor graph of Optimizer.cpp:100-223 as flat arrays ---- */
@@ -175,6 +176,11 @@ typedef struct visfs_ba_stats {
     /* ABI 3: what the two phases actually worked on (measurement: a phase-2 launch touches only the edges left at level 0) */
     int32_t n_active_edges[2];    /* stereo edges in the active set of phase 1 / phase 2 (level 0, not both ends fixed); [1] = [0] - n_outliers */
     int32_t pcg_iterations_phase[2];   /* PCG iterations of the solves of phase 1 / phase 2 (sum = pcg_iterations) */
+    /* ABI 7: 1 = the persistent PCG's hand-off timed out (its grid could not stay resident: a GPU shared with another process) and the
+     * solve was re-run from the uploaded estimates on the direct solver (k_band_chol / the dense blocked Cholesky) — the reference's
+     * linear solver cannot fail for lack of residency (Optimizer.cpp:76-91).  The result is then the exact-solve one (pcg_iterations = 0). */
+    int32_t solver_fallback;
+    int32_t reserved;
 } visfs_ba_stats;
 
 typedef struct visfs_ba_handle visfs_ba_handle;

@@ -6,6 +6,7 @@
  * Reference citations are relative to /root/reference/.  [g2o-upstream] marks
  * statements restated from g2o's published sources (not vendored by the reference).
  */
+#define _GNU_SOURCE            /* sched_setaffinity / CPU_SET for oracle_omp_pin (bench.py's cpu_baseline leg) */
 #define _POSIX_C_SOURCE 200809L
 #include "visfs_ba_oracle.h"
 
@@ -1678,3 +1679,37 @@ int oracle_solve_window(const visfs_ba_params* prm, const visfs_ba_window* w, vi
     free(pose_tq); free(pose_fixed); free(used); free(op); free(oc); free(oref); free(uvr); free(of); free(ot); free(otq);
     return status;
 }
+
+
+/* ---- measurement helper (bench.py's cpu_baseline leg): where the OpenMP threads run ----
+ * The GPU box grants a few cores of a host with 16 last-level-cache domains; unpinned, the scheduler spreads the team over them and the
+ * same binary measured 181 / 673 / 465 it/s in three rounds.  oracle_omp_pin(cpus, n): thread t of the team (libgomp keeps
+ * its threads between regions) binds itself to cpus[t]; the calling thread's own mask is saved and given back by oracle_omp_unpin().
+ * Returns the number of threads that could be bound (0 in the serial build). */
+#if defined(_OPENMP) && defined(__linux__)
+#include <sched.h>
+static cpu_set_t g_saved_mask;
+static int g_saved = 0;
+int oracle_omp_pin(const int32_t* cpus, int n) {
+    int bound = 0;
+    if (n < 1) return 0;
+    if (!g_saved && sched_getaffinity(0, sizeof(g_saved_mask), &g_saved_mask) == 0) g_saved = 1;
+#pragma omp parallel num_threads(n) reduction(+:bound)
+    {
+        const int t = omp_get_thread_num();
+        if (t < n) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpus[t], &set);
+            if (sched_setaffinity(0, sizeof(set), &set) == 0) bound += 1;
+        }
+    }
+    return bound;
+}
+void oracle_omp_unpin(void) {
+    if (g_saved) (void)sched_setaffinity(0, sizeof(g_saved_mask), &g_saved_mask);   /* the calling thread only: the team stays where it is */
+}
+#else
+int oracle_omp_pin(const int32_t* cpus, int n) { (void)cpus; (void)n; return 0; }
+void oracle_omp_unpin(void) {}
+#endif

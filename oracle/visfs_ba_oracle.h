@@ -104,6 +104,11 @@ void oracle_dogleg_combine(double S1, double S2, double S3, double JV2, double r
 /* localOptimize-equivalent on host buffers (pack → optimise → write-back). */
 int oracle_solve_window(const visfs_ba_params* params, const visfs_ba_window* w, visfs_ba_result* r, int num_threads);
 
+/* bench.py's cpu_baseline leg only: bind thread t of the OpenMP team to cpus[t] (returns how many were bound; 0 in the serial build);
+ * oracle_omp_unpin gives the calling thread its own affinity mask back. */
+int oracle_omp_pin(const int32_t* cpus, int n);
+void oracle_omp_unpin(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,12 +20,29 @@ def build_oracle():
     subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
 
 
-def load(omp=False):
-    name = "libvisfs_ba_oracle_omp.so" if omp else "libvisfs_ba_oracle.so"
+def cpu_has_avx512():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return all(x in fl for x in ("avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"))
+    except OSError:
+        pass
+    return False
+
+
+def load(omp=False, v4=False):
+    """v4: the AVX-512 / FMA-contracting build — bench.py's cpu_baseline leg only, never the checker."""
+    name = "libvisfs_ba_oracle" + ("_omp" if omp else "") + ("_v4" if v4 else "") + ".so"
     path = os.path.join(ORACLE_DIR, name)
     if not os.path.exists(path):
         build_oracle()
     lib = C.CDLL(path)
+    lib.oracle_omp_pin.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    lib.oracle_omp_pin.restype = C.c_int
+    lib.oracle_omp_unpin.argtypes = []
+    lib.oracle_omp_unpin.restype = None
     lib.oracle_pose_from_Rt.argtypes = [_pd, _pd, _pd]
     lib.oracle_pose_to_Rt.argtypes = [_pd, _pd, _pd]
     lib.oracle_pose_update.argtypes = [_pd, _pd]

@@ -509,3 +509,57 @@ def test_banded_solver_keeps_the_checker_s_accuracy_on_ill_conditioned_systems(o
         eg = rel_err(xg, np.linalg.solve(Sg, s.fetch(abi.BUF_BS)))
         assert eg <= 10.0 * max(eo, 1e-13), (seed, lam, eo, eg)
     s.close(); o.close()
+
+
+def _fault_free_direct_reference(w, iterations=10):
+    from visfs_amd import backend
+    s0 = backend.Solver(abi.default_params(iterations=iterations, solver=0))
+    wb0 = abi.WindowBuffers(w)
+    rc0, rb0 = s0.solve_window(wb0)
+    s0.close()
+    return rc0, rb0, wb0
+
+
+@pytest.mark.parametrize("shape", ["one_wave", "four_wave"])
+def test_a_timed_out_persistent_pcg_is_solved_again_on_the_direct_solver(olib, monkeypatch, shape):
+    """the reference's linear solver cannot fail for lack of residency (Optimizer.cpp:76-91); Optimizer/Solver=2's
+    persistent PCG can, when another process keeps part of the GPU busy.  The hand-off time-out is forced (VISFS_BA_FAULT_PCG_TIMEOUT=1:
+    block row 0 withholds its first hand-off, every wait gives up after 2^10 polls): the call must still return a solution — the window
+    re-run from its uploaded estimates on the direct solver, i.e. exactly what an Optimizer/Solver=0 handle computes — and say so."""
+    from visfs_amd import backend
+    w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11) if shape == "one_wave" else synth.make_window("custom", n_kf=100, n_lm=3000, n_obs=24000, seed=21)
+    rc0, rb0, wb0 = _fault_free_direct_reference(w)
+    assert rc0 == abi.OK and rb0.struct.solver_fallback == 0
+    monkeypatch.setenv("VISFS_BA_FAULT_PCG_TIMEOUT", "1")
+    prm = abi.default_params(iterations=10, solver=2)
+    s = backend.Solver(prm)
+    wb = abi.WindowBuffers(w)
+    rc, rb = s.solve_window(wb)
+    assert rc == abi.OK and rb.struct.solver_fallback == 1
+    assert np.array_equal(rb.pose_Twr_out, rb0.pose_Twr_out) and rb.outliers() == rb0.outliers()
+    assert np.array_equal(wb.point_xyz, wb0.point_xyz, equal_nan=True)
+    # GRAPH layer: the first optimise after an upload (or a reset) can be re-run; one that continues from earlier results cannot
+    gb = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))[0]
+    s.upload(gb)
+    rc1, st1 = s.optimize()
+    assert rc1 == abi.OK and st1.solver_fallback == 1 and st1.pcg_iterations == 0
+    st2 = abi.Stats()
+    rc2 = s.lib.visfs_ba_optimize(s.h, C.byref(st2))
+    assert rc2 == abi.ERR_DEVICE                                     # not from the uploaded estimates: nothing to re-run from
+    s.reset()
+    rc3, st3 = s.optimize()
+    assert rc3 == abi.OK and st3.solver_fallback == 1
+    s.close()
+
+
+def test_timed_out_members_of_a_batch_fall_back_one_by_one(olib, monkeypatch):
+    from visfs_amd import backend
+    ws = [synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11 + i) for i in range(3)]
+    refs = [_fault_free_direct_reference(w) for w in ws]
+    monkeypatch.setenv("VISFS_BA_FAULT_PCG_TIMEOUT", "1")
+    s = backend.Solver(abi.default_params(iterations=10, solver=2))
+    rbs = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    for rb, (rc0, rb0, _) in zip(rbs, refs):
+        assert rb.struct.status == rc0 == abi.OK and rb.struct.solver_fallback == 1
+        assert np.array_equal(rb.pose_Twr_out, rb0.pose_Twr_out) and rb.outliers() == rb0.outliers()
+    s.close()

@@ -1,15 +1,11 @@
 set -o pipefail
 O=gpurun_out; mkdir -p $O
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/r04_c_tests.log 2>&1; echo "tests rc=$?" >> $O/r04_c_tests.log
-tail -8 $O/r04_c_tests.log
-for CFG in "--solver 0" "--solver 0 --config C4 --iterations 10 --steps 6 --warmup 2" "--framework 1" "--config C5 --windows-per-gpu 8 --solver 0 --steps 10 --warmup 2"; do
-  timeout -k 10 300 python bench.py $CFG --no-cpu-baseline >> $O/r04_c_bench.log 2>> $O/r04_c_bench.err
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_workloads.py -m gpu -x -q -k "timed_out or fall_back or failed_upload or fused_speculative or c5_share" > $O/r04_d_tests.log 2>&1; echo "tests rc=$?" >> $O/r04_d_tests.log
+tail -12 $O/r04_d_tests.log
+timeout -k 10 400 python bench.py > $O/r04_d_bench.json 2> $O/r04_d_bench.err; echo "bench rc=$?"
 python - <<'PY'
 import json
-for ln in open('gpurun_out/r04_c_bench.log'):
-    if not ln.startswith('{'): continue
-    d=json.loads(ln); r=d.get('roofline') or {}
-    print(d['config']['workload'][:60], '| value', d['value'], '|', r.get('kernel_symbol'), r.get('avg_launch_us'))
+d=json.loads([l for l in open('gpurun_out/r04_d_bench.json') if l.startswith('{')][0])
+print('value', d['value'], 'per_frame', d.get('per_frame_call'), '\nconfig5', d.get('config5'))
+print(json.dumps(d['cpu_baseline'], indent=1))
 PY
-python tools/stage_precision.py 559 > $O/r04_c_stage_precision.log 2>&1; cat $O/r04_c_stage_precision.log | cut -c1-400

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_TRACE = 64
 
 # status codes (include/visfs_ba.h)
@@ -77,7 +77,7 @@ class Result(C.Structure):
                 ("outlier_feature", _pu64), ("outlier_pose", _pu64),
                 ("iterations_run", C.c_int32 * 2), ("chi2_initial", C.c_double),
                 ("chi2_phase1", C.c_double), ("chi2_final", C.c_double),
-                ("warn_mono_skipped", C.c_int32), ("reserved", C.c_int32)]
+                ("warn_mono_skipped", C.c_int32), ("solver_fallback", C.c_int32)]
 
 
 class Graph(C.Structure):
@@ -113,7 +113,8 @@ class Stats(C.Structure):
                 ("chi2_initial", C.c_double), ("chi2_phase1", C.c_double), ("chi2_final", C.c_double),
                 ("n_trace", C.c_int32), ("trace_lambda", C.c_double * MAX_TRACE),
                 ("trace_chi2", C.c_double * MAX_TRACE),
-                ("n_active_edges", C.c_int32 * 2), ("pcg_iterations_phase", C.c_int32 * 2)]
+                ("n_active_edges", C.c_int32 * 2), ("pcg_iterations_phase", C.c_int32 * 2),
+                ("solver_fallback", C.c_int32), ("reserved", C.c_int32)]
 
 
 def _ptr(a, ctype):

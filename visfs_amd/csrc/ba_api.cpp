@@ -105,6 +105,11 @@ struct Workspace {
     bool fused_decide = true;                      // gated units: k_backsub carries the LM decision (VISFS_BA_DECIDE_FUSED=0: k_decide, A/B runs and tests)
     int extra_units[2] = { 0, 0 };                 // rejected trials per phase of the previous solve: units enqueued on top of `half`
     bool small_solve = false;                      // reduced system <= 64 x 64: k_small_solve replaces k_schur_finalize + solver
+    bool pristine = false;                         // the estimates are the uploaded ones (upload / reset, no optimise since): a solve can be re-run from its start
+    bool direct_ready = false;                     // the structures of the direct solver exist although Optimizer/Solver=2: the fallback of a timed-out persistent PCG
+    int solver_now = -1;                           // >= 0: the linear solver of the run in progress when it is not Optimizer/Solver (the fallback run: 0)
+    int fallbacks = 0;                             // solves of this workspace that were re-run on the direct solver
+    bool fell_back_last = false;                   // ... the last one was (batch members: read when their statistics are filled)
     // VISFS_BA_GRAPH=1 (measurement): the up-front launch sequence of a solve captured once per resident graph and replayed
     hipGraphExec_t graph_exec = nullptr;
     int graph_units[2] = { -1, -1 };
@@ -625,7 +630,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     // factorisation in one workgroup (k_band_chol) when the band is narrow enough, the dense blocked Cholesky otherwise (VISFS_BA_BAND=0 forces it)
     int band_B = -1, band_rows = 0, band_lds = 0;
     std::vector<int32_t> band_code;
-    if (prm.solver != 2 && Npf >= 1) {
+    // (Optimizer/Solver=2 windows get the plan too: it is what a solve falls back to when the persistent PCG's hand-off times out — a GPU
+    // kept busy by another process —, so that the call still returns a solution as the reference's solver always does, Optimizer.cpp:76-91)
+    if (Npf >= 1) {
         int Bw = 0;
         for (int b = 0; b < n_blk; ++b) Bw = std::max(Bw, blk_j[b] - blk_i[b]);
         const char* e = std::getenv("VISFS_BA_BAND");
@@ -654,6 +661,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     const int n_parts = std::max(n_lin_a + 1, n_eval);
     const size_t n6 = (size_t)6 * Npf;
     const size_t chol_np = std::max<size_t>(32, (n6 + 31) / 32 * 32);
+    const bool small_solve_fits_npf = Npf >= 1 && n6 <= (size_t)SM_MAX_N6;
     const size_t n_hist = (size_t)std::max(index_blocks(No), 1) * std::max(Npf, 1);
 
     // ---- the INDEX section (block-level structure of S, small) and the mutable section: one device arena, the index part staged in
@@ -729,7 +737,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.dl_part = A.take<double>(ceres && prm.trust_region == 1 ? (size_t)n_parts * 4 : 1);
         g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.s2p = A.take<double>(std::max<size_t>(n6, 1));
-        const bool dense_chol = prm.solver != 2 && band_B < 0;
+        const bool dense_chol = band_B < 0 && (prm.solver != 2 || (!small_solve_fits_npf && chol_np <= 2048));   // (PCG windows: the fallback's scratch, up to 67 MB)
         g.dense = A.take<double>(dense_chol ? chol_np * chol_np : 1);
         g.chol_f = A.take<double>(dense_chol ? chol_np * chol_np : 1);
         g.band_L = A.take<double>(band_B >= 0 && band_rows < Npf ? (size_t)Npf * (band_B + 1) * 36 : 1);
@@ -819,6 +827,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
               dg.grid.max_x = gr->grid->max_x; dg.grid.max_y = gr->grid->max_y; }
     dg.debug = 0;
     { const char* e = std::getenv("VISFS_BA_STAMP_WG"); dg.stamp_wg = e ? std::atoi(e) : 0; }
+    { const char* e = std::getenv("VISFS_BA_FAULT_PCG_TIMEOUT"); dg.fault_pcg = (e && e[0] == '1') ? 1 : 0; }      // test hook: force the time-out path once per solve
     w.g = dg;
     // opt-in (VISFS_BA_FUSED=1): one CU's fp64 rate makes the fused kernel slower than the multi-kernel path per window
     // (DESIGN.md §4); it pays only when many small windows run side by side
@@ -841,6 +850,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     if (w.batch_member) { const char* e = std::getenv("VISFS_BA_BATCH_SPEC"); if (!w.spec_fused || !(e && e[0] == '1')) { w.spec = false; w.spec_fused = false; } }
     // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
     { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
+    w.direct_ready = prm.solver == 2 && !ceres && Npf >= 1 && !w.small_solve && (band_B >= 0 || chol_np <= 2048);
+    w.solver_now = -1;
     w.n_pairs = npairs; w.device_bytes = total_bytes + pbytes;
     w.free_pose = free_pose; w.blk_i = blk_i; w.blk_j = blk_j; w.pose_free = pose_free;
     w.odo_i.assign(gr->odo_from, gr->odo_from + Ne); w.odo_j.assign(gr->odo_to, gr->odo_to + Ne);
@@ -857,6 +868,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     if (timing) { HIP_TRY(h, hipStreamSynchronize(w.stream)); lap("h2d+sync"); }
     w.upload_in_flight = true;
     w.loaded = true;
+    w.pristine = true;
     return VISFS_BA_OK;
 }
 
@@ -907,14 +919,15 @@ int ws_read_state(visfs_ba_handle* h, Workspace& w) {
 // w.spec ("speculative linearise"): only the first unit of a phase linearises up front; every unit ENDS with the launch that
 // linearises its trial state beside the LM decision (k_linearize spec = 1), so k_decide and its launch leave the critical path.
 void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
+    const int solver = w.solver_now >= 0 ? w.solver_now : h->prm.solver;
     if (!w.spec || first) { ProfScope p(w, VISFS_BA_K_LINEARIZE, w.g.Ne == 0 && w.g.Nz == 0); launch_linearize(w.g, w.stream); }
     if (w.g.ceres) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_ceres_lin_finalize(w.g, w.stream); }
     else if (first) { ProfScope p(w, VISFS_BA_K_LIN_FINALIZE, true); launch_lin_finalize(w.g, 0, w.stream); }
     { ProfScope p(w, VISFS_BA_K_SCHUR, true); if (w.spec_fused && !first) launch_schur_partial_roleb(w.g, w.stream); else launch_schur_partial(w.g, w.stream); }
-    if (w.small_solve) { ProfScope p(w, h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, h->prm.solver, w.stream); }
+    if (w.small_solve) { ProfScope p(w, solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, solver, w.stream); }
     else {
         { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
-        if (h->prm.solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
+        if (solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }
     if (w.g.dogleg) {
@@ -1026,19 +1039,22 @@ int batch_members_per_launch(visfs_ba_handle* h, const std::vector<Workspace*>& 
 // Optimizer.cpp:261-318 on the resident graph.
 // fresh_upload: the caller has just uploaded this window and nothing has touched it since (the window layer) — the upload's own k_reset has
 // left exactly the state the reset below would produce.
-int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const bool fresh_upload = false) {
+// fallback_run: the re-run of a solve whose persistent PCG timed out, on the direct solver (w.solver_now = 0): the caller has restored the
+// uploaded estimates and re-armed the LM state; no hipGraph (the captured sequence is the PCG one).
+int ws_optimize_run(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const bool fresh_upload, const bool fallback_run) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     HIP_TRY(h, hipSetDevice(h->device));          // a process may hold handles on several GPUs
+    const int solver = w.solver_now >= 0 ? w.solver_now : h->prm.solver;
     // g2o branch: optimize(iterations / 2) twice (Optimizer.cpp:265,311); Ceres branch: one Solve with max_num_iterations = iterations (:521)
     const int half = w.g.ceres ? h->prm.iterations : h->prm.iterations / 2;
     PcgLease pcg_lease;                                                                         // persistent PCG: co-residency budget of the device
-    if (h->prm.solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lease.acquire(h->device, pcg_wave_cost(dims_of(w.g), 1));
+    if (solver == 2 && !w.small_solve && !w.fused && !w.g.pcg_cu) pcg_lease.acquire(h->device, pcg_wave_cost(dims_of(w.g), 1));
     // a fresh optimizer per call (Optimizer.cpp:75): all edges level 0, LM state re-armed, estimates kept
-    const bool reset_launched = !(fresh_upload && w.solves_since_upload == 0);
+    const bool reset_launched = !fallback_run && !(fresh_upload && w.solves_since_upload == 0);
     if (reset_launched) { ProfScope p(w, VISFS_BA_K_RESET); launch_reset(w.g, half, h->prm.trust_region == 1, 0, w.stream); }
     if (w.fused) {
         // small window: both phases, the outlier pass and the final evaluation in one launch of one workgroup
-        { ProfScope p(w, VISFS_BA_K_SMALL); launch_small_optimize(w.g, h->prm.solver, half, w.stream); }
+        { ProfScope p(w, VISFS_BA_K_SMALL); launch_small_optimize(w.g, solver, half, w.stream); }
         HIP_TRY(h, hipGetLastError());
         int rcs = ws_read_state(h, w);
         if (rcs != VISFS_BA_OK) return rcs;
@@ -1070,7 +1086,7 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const b
     const int n0 = half + w.extra_units[0], n1 = half2 > 0 ? half2 + w.extra_units[1] : 0;
     w.solves_since_upload += 1;
     bool replayed = false;
-    if (graph_mode != 0 && !w.prof_mask && !w.graph_failed && (graph_mode == 1 || w.solves_since_upload >= 2)) {
+    if (graph_mode != 0 && !fallback_run && !w.prof_mask && !w.graph_failed && (graph_mode == 1 || w.solves_since_upload >= 2)) {
         if (!w.graph_exec || w.graph_units[0] != n0 || w.graph_units[1] != n1) {
             if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
             // Any failure between begin and end must still END the capture (the stream is unusable otherwise), drop the partial graph and
@@ -1126,11 +1142,38 @@ int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const b
         w.active[VISFS_BA_K_LIN_FINALIZE] += (st.iterations_run[0] > 0) + (st.iterations_run[1] > 0);
         w.active[VISFS_BA_K_SCHUR] += st.n_active[1]; w.active[VISFS_BA_K_SCHUR_FINALIZE] += st.n_active[1];
         if (!w.spec && !w.fused_decide) w.active[VISFS_BA_K_DECIDE] += st.n_active[1];
-        w.active[h->prm.solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT] += st.n_active[1];
+        w.active[solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT] += st.n_active[1];
         w.active[VISFS_BA_K_BACKSUB] += st.n_active[3];
         w.active[VISFS_BA_K_PHASE_END] += 2; if (reset_launched) w.active[VISFS_BA_K_RESET] += 1;
     }
     return w.h_state->status;
+}
+
+// A solve that cannot be lost to residency.  The persistent PCG needs every workgroup of its grid resident at once;
+// when another process keeps part of the GPU busy its hand-off waits give up (LmState::pcg_timeout) and the state machine stops with
+// VISFS_BA_ERR_DEVICE.  The reference's linear solver cannot fail that way (Optimizer.cpp:76-91), so the solve is re-run HERE, in the same
+// call, from the estimates it started from, on the non-persistent direct solver (k_band_chol, or the dense blocked Cholesky for a wide band)
+// — an exact solve of the same damped systems where PCG stops at its tolerance: the result is a valid localOptimize result, not bit-equal to
+// the PCG one.  Only a solve that started from the uploaded estimates can be re-run (the window layer always does; the GRAPH layer after an
+// upload or visfs_ba_graph_reset); visfs_ba_stats::solver_fallback / visfs_ba_result::solver_fallback report it.
+int ws_optimize(visfs_ba_handle* h, Workspace& w, visfs_ba_stats* stats, const bool fresh_upload = false) {
+    const bool pristine = w.pristine;
+    w.pristine = false;
+    w.solver_now = -1;
+    int rc = ws_optimize_run(h, w, stats, fresh_upload, false);
+    if (stats) stats->solver_fallback = 0;
+    if (rc != VISFS_BA_ERR_DEVICE || !w.loaded || !w.h_state || !w.h_state->pcg_timeout) return rc;
+    if (!(pristine && w.direct_ready && h->prm.solver == 2)) return rc;
+    w.solver_now = 0;
+    w.fallbacks += 1;
+    // the uploaded estimates back, all edges level 0, LM state re-armed (k_reset also clears pcg_timeout)
+    launch_reset(w.g, w.g.ceres ? h->prm.iterations : h->prm.iterations / 2, h->prm.trust_region == 1, 1, w.stream);
+    if (hipGetLastError() != hipSuccess) { w.solver_now = -1; return rc; }
+    rc = ws_optimize_run(h, w, stats, false, true);
+    w.solver_now = -1;
+    if (stats) stats->solver_fallback = 1;
+    if (rc != VISFS_BA_ERR_DEVICE) h->err.clear();
+    return rc;
 }
 
 // state_fresh: w.h_state already holds the LM state of the finished run (ws_optimize / batch_optimize read it): no extra round trip.
@@ -1387,7 +1430,7 @@ static const char* framework_refusal(const visfs_ba_params& prm) {
 // input).  pool: host threads for the O(N_obs) passes (nullptr: the calling thread alone).
 int prepare_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, visfs_ba_result* r, PackedWindow& pk, WorkerPool* pool = nullptr) {
     const visfs_ba_params& prm = h->prm;
-    r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0;
+    r->n_poses_out = 0; r->n_outliers = 0; r->warn_mono_skipped = 0; r->solver_fallback = 0;
     r->iterations_run[0] = r->iterations_run[1] = 0;
     r->chi2_initial = r->chi2_phase1 = r->chi2_final = 0.0;
     if (const char* why = framework_refusal(prm)) { h->err = why; r->status = VISFS_BA_ERR_UNSUPPORTED; return 0; }
@@ -1450,6 +1493,7 @@ int finish_window(visfs_ba_handle* h, Workspace& w, const visfs_ba_window* win, 
     if (rc == VISFS_BA_ERR_DEVICE || rc == VISFS_BA_ERR_NOT_LOADED) return r->status = rc;
     const int Np = win->n_poses, Nl = win->n_points;
     r->status = rc;
+    r->solver_fallback = st.solver_fallback;
     r->iterations_run[0] = st.iterations_run[0]; r->iterations_run[1] = st.iterations_run[1];
     r->chi2_initial = st.chi2_initial; r->chi2_phase1 = st.chi2_phase1; r->chi2_final = st.chi2_final;
     if (rc != VISFS_BA_OK && rc != VISFS_BA_ERR_HUGE_CHI2_2) return rc;
@@ -1585,6 +1629,8 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
     }
     std::vector<DeviceGraph>& hg = bs.host_graphs;
     hg.resize(B);
+    std::vector<char> pristine(B, 0);
+    for (int b = 0; b < B; ++b) { Workspace& w = *ws[members[b]]; pristine[b] = w.pristine ? 1 : 0; w.pristine = false; }
     LaunchDims d = dims_of(ws[members[0]]->g);
     bool fused = true, small_solve = true, fused_decide = true, spec_fused = true;
     for (int b = 0; b < B; ++b) {
@@ -1623,7 +1669,8 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         int top_up = 0;
         for (int b = 0; b < B; ++b) {
             const LmState& st = bs.h_lm[b];
-            if (st.status == VISFS_BA_ERR_DEVICE) { h->err = "a device-side hand-off (persistent PCG / LM decision) timed out"; return VISFS_BA_ERR_DEVICE; }
+            // (a member whose hand-off timed out has stopped — status 8, every later launch a no-op for it —; the others go on, it is dealt
+            // with below)
             if (st.ended >= 2 || st.status != 0) continue;
             all_finished = false;
             if (!st.done) top_up = std::max(top_up, std::max(1, st.max_iter - st.phase_iter));
@@ -1632,8 +1679,27 @@ int batch_optimize(visfs_ba_handle* h, BatchScratch& bs, const std::vector<Works
         if (guard > 16 * h->prm.iterations + 32) { h->err = "LM state machine did not terminate"; return VISFS_BA_ERR_DEVICE; }
         units(top_up, false); phase_end(0); units(half2, true); phase_end(1);
     }
-    for (int b = 0; b < B; ++b) *ws[members[b]]->h_state = bs.h_lm[b];
-    return VISFS_BA_OK;
+    int worst = VISFS_BA_OK;
+    pcg_lease.release();
+    for (int b = 0; b < B; ++b) {
+        Workspace& w = *ws[members[b]];
+        *w.h_state = bs.h_lm[b];
+        const bool was_pristine = pristine[b];
+        w.fell_back_last = false;
+        if (bs.h_lm[b].status != VISFS_BA_ERR_DEVICE) continue;
+        // this member's persistent PCG (or decision hand-off) timed out: solve it again, alone, on the direct solver (see ws_optimize)
+        int rc = VISFS_BA_ERR_DEVICE;
+        if (bs.h_lm[b].pcg_timeout && was_pristine && w.direct_ready && h->prm.solver == 2) {
+            HIP_TRY(h, hipStreamSynchronize(stream));
+            w.solver_now = 0; w.fallbacks += 1;
+            launch_reset(w.g, half, h->prm.trust_region == 1, 1, w.stream);
+            rc = hipGetLastError() == hipSuccess ? ws_optimize_run(h, w, nullptr, false, true) : (int)VISFS_BA_ERR_DEVICE;
+            w.solver_now = -1;
+            w.fell_back_last = rc != VISFS_BA_ERR_DEVICE;
+        }
+        if (rc == VISFS_BA_ERR_DEVICE) { h->err = "a device-side hand-off (persistent PCG / LM decision) timed out"; worst = VISFS_BA_ERR_DEVICE; }
+    }
+    return worst;
 }
 
 // One group of windows that share launches.  Groups of 8 and more members (PCG kernels k_pcg1 or k_pcg_cu) are cut into two halves
@@ -1809,6 +1875,7 @@ int visfs_ba_graph_reset(visfs_ba_handle* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     launch_reset(h->ws.g, h->ws.g.ceres ? h->prm.iterations : h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
     HIP_TRY(h, hipGetLastError());
+    h->ws.pristine = true;
     return VISFS_BA_OK;
 }
 
@@ -1888,6 +1955,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
                 for (int i : members) {
                     if (rc != VISFS_BA_OK) { rcs[i] = rc; worst = VISFS_BA_ERR_DEVICE; continue; }
                     fill_stats(*h->batch[i]->h_state, &stats[i]);
+                    stats[i].solver_fallback = h->batch[i]->fell_back_last ? 1 : 0;
                     rcs[i] = h->batch[i]->h_state->status;
                 }
             }
@@ -1956,6 +2024,7 @@ int visfs_ba_batch_reset(visfs_ba_handle* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->n_batch > 0) launch_reset_batch(h->scratch.d_all, h->n_batch, h->scratch.all_dims, h->prm.framework == 1 ? h->prm.iterations : h->prm.iterations / 2, h->prm.trust_region == 1, 1, h->ws.stream);
     HIP_TRY(h, hipGetLastError());
+    for (int i = 0; i < h->n_batch; ++i) h->batch[i]->pristine = true;
     return VISFS_BA_OK;
 }
 
@@ -1982,7 +2051,7 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
                 const int rc = batch_optimize_group(h, members);
                 if (rc != VISFS_BA_OK) return rc;
                 for (int i : members) {
-                    if (stats) fill_stats(*h->batch[i]->h_state, &stats[i]);
+                    if (stats) { fill_stats(*h->batch[i]->h_state, &stats[i]); stats[i].solver_fallback = h->batch[i]->fell_back_last ? 1 : 0; }
                     if (h->batch[i]->h_state->status != VISFS_BA_OK) worst = h->batch[i]->h_state->status;
                 }
             }

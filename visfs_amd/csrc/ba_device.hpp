@@ -231,6 +231,8 @@ struct DeviceGraph {
     unsigned long long* stamps;  // [128] diagnostic build (-DVISFS_BA_STAMPS) only: real-time stamps of one PCG workgroup
     int32_t stamp_wg;
     int32_t debug;
+    int32_t fault_pcg;      // test hook (VISFS_BA_FAULT_PCG_TIMEOUT=1 at upload): block row 0 of the persistent PCG withholds its first hand-off and every wait
+                            // gives up after 2^10 instead of 2^22 polls — the path a GPU kept busy by another process takes (LmState::pcg_timeout)
 };
 
 // A wave-uniform pointer, pinned to scalar registers (the batched kernels read their graph from HBM with vector loads; without

@@ -1646,6 +1646,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     dn = sP[0]; d0 = sP[1];
     int iter = 0;
     bool timeout = false;
+    const unsigned spin_limit = g.fault_pcg ? (1u << 10) : (1u << 22);
 #ifdef VISFS_BA_STAMPS
 #define PCG_STAMP(slot) do { if (tid == 0 && blockIdx.x == (unsigned)g.stamp_wg && (slot) < 126) g.stamps[(slot)] = wall_clock64(); } while (0)
     PCG_STAMP(0);
@@ -1685,7 +1686,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
         // ---- publish: thread 12 li + 2 r + h carries half h of q[i0 + li][r] (sum of the four waves' partials, fixed order)
         const unsigned epoch = (unsigned)iter + 1u;
         unsigned long long* gr = g.granules + (size_t)(iter & 1) * (2 * n6);
-        if (tid < 12 * (i1 - i0)) {
+        if (tid < 12 * (i1 - i0) && !(g.fault_pcg && blockIdx.x == 0 && iter == 0)) {
             const int li = tid / 12, r6 = (tid % 12) >> 1;
             const double* qp = sQ + li * 32;
             const double qv = ((qp[r6] + qp[8 + r6]) + qp[16 + r6]) + qp[24 + r6];
@@ -1714,7 +1715,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
                 }
                 if (__all(ok)) break;                                  // per wave; the workgroup meets at the barrier below
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) { timeout = true; break; }
+                if (++spins > spin_limit) { timeout = true; break; }
             }
             if (!timeout) {
 #pragma unroll
@@ -1904,6 +1905,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     }
     int iter = 0;
     bool timeout = false;
+    const unsigned spin_limit = g.fault_pcg ? (1u << 10) : (1u << 22);
     bool xcd_local = false;                            // GV == 3: every row of this window runs on one XCD (decided after iteration 0)
     PCG1_STAMP(0);
     while (true) {
@@ -1922,7 +1924,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
         const unsigned epoch = (unsigned)iter + 1u;
         unsigned long long* gr = g.granules + (size_t)(iter & 1) * (2 * n6);
         PCG1_STAMP(1 + 4 * iter);
-        if (len >= 1) {
+        if (len >= 1 && !(g.fault_pcg && i0 == 0 && iter == 0)) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(y[0]);
             unsigned long long* o = gr + 2 * (6 * i0 + off);
             const unsigned long long g0 = ((unsigned long long)epoch << 32) | (bits & 0xffffffffull), g1 = ((unsigned long long)epoch << 32) | (bits >> 32);
@@ -1949,7 +1951,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
                     }
                     if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) { timeout = true; break; }
+                    if (++spins > spin_limit) { timeout = true; break; }
                 }
             } else {
                 // 16-byte write-through-coherent loads (sc1: served past this CU's L1) through a buffer descriptor over the granule array
@@ -1980,13 +1982,13 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
                             for (int k = 0; k < 6; ++k) a[k] = b[k];
                             break;
                         }
-                        if (++spins > (1u << 22)) { timeout = true; break; }
+                        if (++spins > spin_limit) { timeout = true; break; }
                     }
                 } else {
                     while (true) {
                         if (__all(tags_ok(a))) break;
                         __builtin_amdgcn_s_sleep(1); sweep(a);
-                        if (++spins > (1u << 22)) { timeout = true; break; }
+                        if (++spins > spin_limit) { timeout = true; break; }
                     }
                 }
 #pragma unroll
@@ -2004,7 +2006,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
                     if (own) xw = ld_granule(xp);
                     if (__all(!own || (xw >> 32) == 1ull)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) { timeout = true; break; }
+                    if (++spins > spin_limit) { timeout = true; break; }
                 }
                 if (timeout) break;
                 const unsigned x0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xw);      // row 0's XCD
