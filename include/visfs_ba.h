@@ -324,6 +324,10 @@ typedef struct visfs_ba_graph_info {
                                    * 2 the fused speculative unit (k_backsub also carries the decision and the landmark-major half of the
                                    *   trial's linearisation; the pose-major half rides behind the next k_schur_partial): what the kernel
                                    *   classes of the profile hooks contain depends on it */
+    int32_t schur_runs;           /* ABI 7: > 0: the Schur complement is formed by k_schur_runs, that many workgroups each owning a run of
+                                   * schur_run_landmarks consecutive landmarks (tiles staged in LDS); 0: the pair-list gather (k_schur_partial,
+                                   * n_schur_chunks wavefronts) */
+    int32_t schur_run_landmarks;
 } visfs_ba_graph_info;
 /* GRAPH layer for a batch of independent windows (BASELINE config 5): n graphs resident side by side; one optimise call runs
  * them through ONE sequence of launches (blockIdx.y = window, each window gated by its own LM state).  Needs

@@ -648,7 +648,7 @@ def test_schur_chunk_passes_agree_to_rounding(olib, monkeypatch):
     w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11)
     ref = None
     for passes in ("1", "2", "3"):
-        info, rc, st, out = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SCH_PASSES=passes), iterations=10, solver=2)
+        info, rc, st, out = _solve_in_mode(monkeypatch, w, dict(VISFS_BA_SCH_PASSES=passes, VISFS_BA_SCHUR_RUNS="0"), iterations=10, solver=2)   # (the pair-list gather)
         assert rc == abi.OK
         if ref is None:
             ref = (info, st, out)

@@ -563,3 +563,86 @@ def test_timed_out_members_of_a_batch_fall_back_one_by_one(olib, monkeypatch):
         assert rb.struct.status == rc0 == abi.OK and rb.struct.solver_fallback == 1
         assert np.array_equal(rb.pose_Twr_out, rb0.pose_Twr_out) and rb.outliers() == rb0.outliers()
     s.close()
+
+
+def _solve_graph(monkeypatch, w, env, **prm_kw):
+    from visfs_amd import backend
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    prm = abi.default_params(**prm_kw)
+    s = backend.Solver(prm)
+    gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s.upload(gb)
+    info = s.describe()
+    rc, st = s.optimize()
+    out = s.download()
+    s.close()
+    return info, rc, st, out
+
+
+@pytest.mark.parametrize("case", ["K30", "C2", "C3", "RAGGED30", "HARD", "S0", "CERES", "LASER"])
+def test_schur_by_runs_of_landmarks_equals_the_pair_gather_to_rounding(olib, monkeypatch, case):
+    """Round 4: k_schur_runs stages every tile core, Q = N D and camera-frame point in LDS once per damped solve and
+    accumulates the blocks of a run of landmarks in registers; the pair-list gather rebuilds both tiles and the landmark inverse per pair.
+    Per pair the operands are the same values — only the association of the sums differs: identical LM trajectories (iteration and PCG
+    counts, outlier sets), results equal to rounding."""
+    from helpers import hard_window, ragged_window
+    kw = dict(iterations=10, solver=2)
+    if case == "K30":
+        w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11)
+    elif case == "RAGGED30":
+        w = ragged_window(seed=9, n_kf=30, n_lm=900, n_obs=7200, odo=True, drop=0.3)
+    elif case == "HARD":
+        w = hard_window()
+    elif case == "S0":
+        w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11); kw["solver"] = 0
+    elif case == "CERES":
+        w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11); kw["framework"] = 1
+    elif case == "LASER":
+        w = synth.make_laser_window(n_kf=16, with_visual=True, n_points=400)
+    else:
+        w = synth.make_window(case); kw["iterations"] = 20
+    i0, rc0, st0, out0 = _solve_graph(monkeypatch, w, dict(VISFS_BA_SCHUR_RUNS="0"), **kw)
+    i1, rc1, st1, out1 = _solve_graph(monkeypatch, w, dict(VISFS_BA_SCHUR_RUNS="1"), **kw)
+    assert i0["schur_runs"] == 0 and i0["n_schur_chunks"] > 0
+    assert i1["schur_runs"] > 0 and i1["n_schur_chunks"] == 0
+    assert rc0 == rc1 == abi.OK
+    assert list(st0.iterations_run) == list(st1.iterations_run) and list(st0.trials_run) == list(st1.trials_run)
+    assert st0.pcg_iterations == st1.pcg_iterations and st0.n_outliers == st1.n_outliers
+    assert abs(st0.chi2_final - st1.chi2_final) <= 1e-10 * st0.chi2_final
+    assert np.abs(out0[0] - out1[0]).max() < 1e-10 and rel_err(out1[1], out0[1]) < 1e-9
+    assert np.array_equal(out0[2], out1[2])
+
+
+def test_windows_the_run_kernel_does_not_fit_keep_the_gather(olib, monkeypatch):
+    """Landmark ids that do not grow with time (here: reversed against the tracks' first key-frames AND interleaved) give runs whose
+    pose span exceeds the kernel's 64 poses; small reduced systems are k_small_solve's.  Both keep the pair-list gather; parity unchanged."""
+    w = synth.make_window("custom", n_kf=160, n_lm=3000, n_obs=24000, seed=21)
+    # interleave the landmarks of the two halves of the trajectory: every run of consecutive landmarks now spans the whole window
+    ids = np.asarray(w["point_ids"]).copy()
+    n = len(ids)
+    perm = np.empty(n, np.int64); perm[0::2] = np.arange((n + 1) // 2); perm[1::2] = np.arange((n + 1) // 2, n)
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)                      # old landmark index -> new position
+    w2 = dict(w)
+    w2["point_xyz"] = np.asarray(w["point_xyz"])[perm].copy(); w2["point_fixed"] = np.asarray(w["point_fixed"])[perm].copy()
+    feat_old = np.searchsorted(ids, np.asarray(w["ref_feature"]))
+    new_feat = ids[inv[feat_old]]
+    order = np.lexsort((np.asarray(w["ref_pose"]), new_feat))
+    for k in ("ref_pose", "ref_u", "ref_v", "ref_depth"):
+        w2[k] = np.asarray(w[k])[order]
+    w2["ref_feature"] = new_feat[order]
+    if "gross" in w2:
+        w2["gross"] = np.asarray(w["gross"])[order]
+    monkeypatch.setenv("VISFS_BA_SCHUR_RUNS", "1")                              # (opt-in: the gather is the default, profiles/r04_schur_lds_tiles.log)
+    o, s, gb = make_pair(olib, w2, iterations=10, solver=2)
+    d = s.describe()
+    assert d["schur_runs"] == 0 and d["n_schur_chunks"] > 0
+    check_optimize(o, s, pose_tol=1e-9)
+    s.close(); o.close()
+    o, s, gb = make_pair(olib, synth.make_window("PROD"), iterations=10, solver=2)
+    assert s.describe()["schur_runs"] == 0
+    s.close(); o.close()
+    o, s, gb = make_pair(olib, w, iterations=10, solver=2)                       # the same window with its ids in time order: runs
+    assert s.describe()["schur_runs"] > 0
+    check_optimize(o, s, pose_tol=1e-9)
+    s.close(); o.close()

@@ -99,7 +99,8 @@ class GraphInfo(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_free_poses", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
                 ("n_odo", C.c_int32), ("n_blk", C.c_int32), ("n_pairs", C.c_int64), ("lanes_per_landmark", C.c_int32),
                 ("n_schur_chunks", C.c_int32), ("device_bytes", C.c_int64), ("fused_path", C.c_int32), ("solver_kernel", C.c_int32),
-                ("band_blocks", C.c_int32), ("graph_replayed", C.c_int32), ("unit_form", C.c_int32)]
+                ("band_blocks", C.c_int32), ("graph_replayed", C.c_int32), ("unit_form", C.c_int32),
+                ("schur_runs", C.c_int32), ("schur_run_landmarks", C.c_int32)]
 
 
 class Profile(C.Structure):

@@ -46,18 +46,25 @@ struct Arena {
 
 // Host scratch of the window layer that survives from call to call (a fresh std::vector of this size is an mmap, a page fault per
 // 4 KiB on first touch and an munmap, every frame — and page faults from several threads at once serialise in the kernel).
+// What the run-based Schur kernel (k_schur_runs) needs to know about 8 consecutive landmarks: how many observations they have and
+// which poses (index space of the window, fixed ones included) those touch.
+struct RunGroup { int32_t cnt = 0; int32_t lo = 0x7fffffff, hi = -1; };
+constexpr int RUN_GROUP = 8;
 struct alignas(128) SummaryPart {          // (one per thread, updated per observation: no two may share a cache line)
     std::vector<int32_t> cnt, run, pc, track;
+    std::vector<RunGroup> grp;
     int64_t pairs = 0; int ok = 0; bool any_run = false, used = false; const char* bad = nullptr;
     int npf = 0; int cur = -1; bool cur_fixed = false;
     int first = -1, last = -1, c = 0; bool gap = false;         // the current landmark's free poses: a contiguous run unless `gap`
-    void begin(int Npf) {
+    void begin(int Npf, int Nl) {
         used = true; npf = Npf; cnt.assign(Npf + 1, 0); run.assign((size_t)Npf * Npf, 0); pc.clear(); track.clear();
+        grp.assign((size_t)(Nl + RUN_GROUP - 1) / RUN_GROUP + 1, RunGroup());
         pairs = 0; ok = 0; any_run = false; bad = nullptr; cur = -1; first = last = -1; c = 0; gap = false;
     }
     // observations arrive landmark by landmark (a landmark never straddles two accumulators), poses ascending inside a landmark
-    inline void add(int landmark, bool landmark_fixed, int a /* free index of the pose, -1: fixed */) {
+    inline void add(int landmark, bool landmark_fixed, int a /* free index of the pose, -1: fixed */, int pose /* its index in the window */) {
         if (landmark != cur) { flush(); cur = landmark; cur_fixed = landmark_fixed; }
+        { RunGroup& G = grp[(size_t)landmark / RUN_GROUP]; G.cnt++; G.lo = std::min(G.lo, pose); G.hi = std::max(G.hi, pose); }
         ok += !(a < 0 && landmark_fixed);
         if (a < 0) return;
         cnt[a + 1]++;
@@ -311,6 +318,7 @@ struct GraphSummary {
     int64_t pairs_seen = 0;
     int n_edges_ok = 0;
     const char* bad = nullptr;
+    std::vector<RunGroup> grp;         // per RUN_GROUP consecutive landmarks
 };
 // One pass over the observations (landmark-major), shared out over the pool at landmark boundaries.
 // A landmark seen by the free poses {a_1 < ... < a_k} adds one pair to every block (a_i, a_j), i <= j.  Tracks are runs of consecutive
@@ -332,6 +340,13 @@ void merge_summary(std::vector<SummaryPart>& part, const int NT, const int Npf, 
         S.pairs_seen += P.pairs; S.n_edges_ok += P.ok; any_run = any_run || P.any_run;
     }
     for (int a = 0; a < Npf; ++a) S.cnt[a + 1] += S.cnt[a];
+    S.grp.clear();
+    for (int t = 0; t < NT; ++t) {
+        const SummaryPart& P = part[t];
+        if (!P.used) continue;
+        if (S.grp.size() < P.grp.size()) S.grp.resize(P.grp.size());
+        for (size_t q = 0; q < P.grp.size(); ++q) { RunGroup& G = S.grp[q]; G.cnt += P.grp[q].cnt; G.lo = std::min(G.lo, P.grp[q].lo); G.hi = std::max(G.hi, P.grp[q].hi); }
+    }
     if (any_run) {
         // in place: run[a][b] <- sum_{s <= a, e >= b} run[s][e]
         for (int a = 0; a < Npf; ++a)
@@ -364,7 +379,7 @@ void summarize_graph(const visfs_ba_graph* gr, const int32_t* pose_free, const i
     for (int t = 0; t < NT; ++t) part[t].used = false;
     auto body = [&](int t, int slot) {
         SummaryPart& P = part[slot];
-        if (!P.used) P.begin(Npf);
+        if (!P.used) P.begin(Npf, Nl);
         if (P.bad) return;
         for (int k = cut[t]; k < cut[t + 1]; ++k) {
             const int l = gr->obs_point[k], cp = gr->obs_pose[k];
@@ -372,7 +387,7 @@ void summarize_graph(const visfs_ba_graph* gr, const int32_t* pose_free, const i
                 if (l < 0 || l >= Nl || cp < 0 || cp >= Np) { P.bad = "observation index out of range"; return; }
                 if (k > 0 && (l < gr->obs_point[k - 1] || (l == gr->obs_point[k - 1] && cp <= gr->obs_pose[k - 1]))) { P.bad = "observations must be sorted by (point, pose) and unique"; return; }
             }
-            P.add(l, gr->point_fixed[l] != 0, pose_free[cp]);
+            P.add(l, gr->point_fixed[l] != 0, pose_free[cp], cp);
         }
         P.flush();
     };
@@ -563,6 +578,89 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         for (int b = 0; b < n_blk; ++b) { const int r = blk_i[b]; row_col[at[r]] = blk_j[b]; row_blk[at[r]] = 2 * b; at[r]++; }
     }
 
+    // ---- Schur complement by RUNS OF LANDMARKS (k_schur_runs, ba_kernels.hip): the plan.  A workgroup owns run_lr x run_m consecutive
+    // landmarks; run_lr is the largest of 64 / 32 / 16 / 8 whose sub-batches never hold more than RUN_MAX_TILES observations (their tiles are
+    // staged in LDS); a run's blocks are those of its pose span [lo, lo + W) — from the structure summary, which has seen every observation's
+    // landmark and pose.  Windows it does not fit (a span above RUN_MAX_W poses: landmarks whose ids do not grow with time; reduced systems
+    // that k_small_solve serves; VISFS_BA_SCHUR_RUNS=0) keep the pair-list gather.  A property of the window alone.
+    struct RunPlan { int LR = 0, M = 1, n = 0, cap = 0, wmax = 0; size_t lds = 0; int64_t total = 0; std::vector<int4> desc; std::vector<int32_t> first, last, k0; } rp;
+    {
+        // Measured (profiles/r04_schur_lds_tiles.log): a third of the gather's VALU instructions per pair, but every workgroup is a chain
+        // of barrier-separated phases (descriptors, global loads, D_l / R_i, tiles, accumulate, three reduction passes: 12 us stamped at C2)
+        // at two to three waves per SIMD — 15.7 us per launch against the gather's 8.7 at C2, 34 against 29.5 at the 200-key-frame window,
+        // 16 resident windows 78.6 k against 79.0 k it/s at best.  The gather stays the default; VISFS_BA_SCHUR_RUNS=1 selects this kernel
+        // (tests, A/B runs).
+        const char* e = std::getenv("VISFS_BA_SCHUR_RUNS");
+        const bool want = e && e[0] == '1';
+        const int ng = (Nl + RUN_GROUP - 1) / RUN_GROUP;
+        if (want && Npf >= 1 && No > 0 && Nl > 0 && (size_t)6 * Npf > (size_t)SM_MAX_N6 && (int)sum.grp.size() >= ng && Np < 65536) {
+            // (first choice: sub-batches of at most 176 tiles — 30 KB of LDS, three workgroups and more per CU; else whatever fits at all)
+            for (int limit : { 176, RUN_MAX_TILES }) {
+                for (int LR : { 64, 32, 16, 8 }) {
+                    const int gper = LR / RUN_GROUP;
+                    int maxc = 0;
+                    for (int g0 = 0; g0 < ng; g0 += gper) { int c = 0; for (int q = g0; q < std::min(ng, g0 + gper); ++q) c += sum.grp[q].cnt; maxc = std::max(maxc, c); }
+                    if (maxc <= limit) { rp.LR = LR; rp.cap = maxc; break; }
+                }
+                if (rp.LR) break;
+            }
+            { const char* el = std::getenv("VISFS_BA_RUN_LR"); const int q = el ? std::atoi(el) : 0;                    // tuning override (never above what fits)
+              if (rp.LR && (q == 8 || q == 16 || q == 32 || q == 64) && q < rp.LR) { rp.LR = q; rp.cap = 0; const int gper = q / RUN_GROUP;
+                  for (int g0 = 0; g0 < ng; g0 += gper) { int c = 0; for (int qq = g0; qq < std::min(ng, g0 + gper); ++qq) c += sum.grp[qq].cnt; rp.cap = std::max(rp.cap, c); } } }
+            if (rp.LR) {
+                // sub-batches per workgroup: one, until the window has so many landmarks that a partial per run and block costs more traffic
+                // than the workgroups it keeps busy (a 200-key-frame window: ~940 runs of 32 landmarks at M = 1)
+                rp.M = std::max(1, 32 / rp.LR);                 // at least 32 landmarks per workgroup: a partial per run and block is traffic
+                while ((Nl + rp.LR * rp.M - 1) / (rp.LR * rp.M) > 1024 && rp.M < 16) rp.M *= 2;
+                { const char* em = std::getenv("VISFS_BA_RUN_M"); const int q = em ? std::atoi(em) : 0; if (q >= 1 && q <= 16) rp.M = q; }
+                const int per = rp.LR * rp.M, gper = per / RUN_GROUP;
+                rp.n = (Nl + per - 1) / per;
+                rp.desc.assign(rp.n, make_int4(0, 0, 0, 0));
+                bool ok = rp.n < (1 << 20);
+                int nbmax = 0;
+                for (int r = 0; r < rp.n && ok; ++r) {
+                    int lo = 0x7fffffff, hi = -1;
+                    for (int q = r * gper; q < std::min(ng, (r + 1) * gper); ++q) if (sum.grp[q].cnt > 0) { lo = std::min(lo, sum.grp[q].lo); hi = std::max(hi, sum.grp[q].hi); }
+                    const int W = hi >= lo ? hi - lo + 1 : 0;
+                    if (W > RUN_MAX_W) { ok = false; break; }
+                    rp.desc[r] = make_int4(W ? lo : 0, W, (int)rp.total, 0);
+                    rp.total += (int64_t)W * (W + 1) / 2;
+                    rp.wmax = std::max(rp.wmax, W); nbmax = std::max(nbmax, W * (W + 1) / 2);
+                    if (rp.total > 0x3fffffff) ok = false;
+                }
+                if (ok) {
+                    // per stored block of S: the range of runs whose span holds both of its poses (k_schur_finalize walks it)
+                    rp.first.assign(n_blk, 0x7fffffff); rp.last.assign(n_blk, -1);
+                    for (int r = 0; r < rp.n; ++r) {
+                        const int lo = rp.desc[r].x, W = rp.desc[r].y;
+                        for (int li = 0; li < W; ++li) {
+                            const int a = pose_free[lo + li];
+                            if (a < 0) continue;
+                            for (int lj = li; lj < W; ++lj) {
+                                const int b2 = pose_free[lo + lj];
+                                if (b2 < 0) continue;
+                                const int bk = blk_of[(size_t)a * Npf + b2];
+                                if (bk >= 0) { rp.first[bk] = std::min(rp.first[bk], r); rp.last[bk] = std::max(rp.last[bk], r); }
+                            }
+                        }
+                    }
+                    for (int b = 0; b < n_blk && ok; ++b) if (rp.last[b] >= 0 && rp.last[b] - rp.first[b] + 1 > 4095) ok = false;
+                }
+                if (!ok) { rp = RunPlan(); }
+                else {
+                    rp.lds = (((size_t)std::max(rp.cap, (256 * 14 + RUN_TILE - 1) / RUN_TILE) * RUN_TILE + 9 * (size_t)rp.LR + 9 * (size_t)rp.wmax) * 8 + (((size_t)rp.LR * rp.wmax + 3) & ~size_t(3)) * 2 + (size_t)nbmax * 2 + 15) & ~size_t(15);
+                    // first observation of every sub-batch of run_lr landmarks (observations are landmark-major: a prefix sum of the groups' counts)
+                    const int nsub = rp.n * rp.M, gl = rp.LR / RUN_GROUP;
+                    rp.k0.assign((size_t)nsub + 1, 0);
+                    int acc = 0;
+                    for (int sb = 0; sb < nsub; ++sb) { rp.k0[sb] = acc; for (int q = sb * gl; q < std::min(ng, (sb + 1) * gl); ++q) acc += sum.grp[q].cnt; }
+                    rp.k0[nsub] = acc;
+                    if (acc != No) rp = RunPlan();                 // (cannot happen: every observation was counted once)
+                }
+            }
+        }
+    }
+    const bool run_path = rp.n > 0;
     // Schur chunks: <= SCH_CHUNK co-observation pairs of one block per wavefront
     // A lane may take several pairs of its chunk (64 per pass) and add them serially before the wave's reduce-scatter.  Measured
     // (profiles/r01_v8_schur_passes.log): two passes win 4-5 % on a lone mid-size window (C2: half the waves, half the partials
@@ -575,9 +673,10 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     { const char* e = std::getenv("VISFS_BA_SCH_PASSES"); if (e) { const int q = std::atoi(e); if (q >= 1 && q <= 8) sch_passes = q; } }
     const int sch_chunk = SCH_CHUNK * sch_passes;
     std::vector<int32_t> blk_chunk_ptr(n_blk + 1, 0), sch_blk, sch_ptr;
-    sch_blk.reserve((size_t)(npairs / sch_chunk) + n_blk + 1); sch_ptr.reserve((size_t)(npairs / sch_chunk) + n_blk + 1);
+    if (!run_path) { sch_blk.reserve((size_t)(npairs / sch_chunk) + n_blk + 1); sch_ptr.reserve((size_t)(npairs / sch_chunk) + n_blk + 1); }
     for (int b = 0; b < n_blk; ++b) {
         blk_chunk_ptr[b] = (int32_t)sch_blk.size();
+        if (run_path) continue;                             // (no pair lists, no chunks: the runs replace them)
         for (int e = blk_ptr[b]; e < blk_ptr[b + 1]; e += sch_chunk) { sch_blk.push_back(b); sch_ptr.push_back(e); }
     }
     blk_chunk_ptr[n_blk] = (int32_t)sch_blk.size();
@@ -591,6 +690,11 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         const int a = blk_i[b];
         const bool dg = (a == blk_j[b]);
         blk_desc[2 * b] = make_int4(blk_chunk_ptr[b], blk_chunk_ptr[b + 1], dg ? pose_odo_ptr[a] : blk_odo_ptr[b], dg ? pose_odo_ptr[a + 1] : blk_odo_ptr[b + 1]);
+        if (run_path) {
+            const int cnt_r = rp.last[b] >= 0 ? rp.last[b] - rp.first[b] + 1 : 0;
+            blk_desc[2 * b].x = (int)((unsigned)(cnt_r ? rp.first[b] : 0) | ((unsigned)cnt_r << 20));
+            blk_desc[2 * b].y = (int)((unsigned)free_pose[a] | ((unsigned)free_pose[blk_j[b]] << 16));
+        }
         blk_desc[2 * b + 1] = make_int4(a, blk_j[b], pose_chunk_ptr[a], pose_chunk_ptr[a + 1]);
     }
     if (prm.solver == 2 && Npf > MAX_PCG_FREE_POSES) { h->err = "Optimizer/Solver=2 (PCG) supports at most 1024 free poses; use the direct solver"; return VISFS_BA_ERR_UNSUPPORTED; }
@@ -686,6 +790,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
         g.pcg1_code = pcg1 ? A.take<int32_t>((size_t)Npf * Npf) : nullptr;
         g.band_code = band_B >= 0 ? A.take<int32_t>(band_code.size()) : nullptr;
+        g.run_desc = run_path ? A.take<int4>(rp.desc.size()) : nullptr;
+        g.run_k0 = run_path ? A.take<int32_t>(rp.k0.size()) : nullptr;
     };
     Arena sizing{ nullptr, 0, 0 };
     layout(sizing, hg);
@@ -728,7 +834,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.bs = A.take<double>(std::max<size_t>(n6, 1));
         g.Minv = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.x = A.take<double>(std::max<size_t>(n6, 1));
-        g.sch_part = A.take<double>((size_t)std::max(n_sch, 1) * 42);
+        g.sch_part = A.take<double>((size_t)std::max<int64_t>(std::max<int64_t>(n_sch, rp.total), 1) * 42);
         g.granules = A.take<unsigned long long>(std::max<size_t>(4 * n6 + Npf, 1));        // + one placement word per block row (k_pcg1)
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
@@ -748,7 +854,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         // ---- from here on: arrays that are written in full before anything reads them — not part of the upload's clearing pass (a third
         // of the arena at C2: the stage hooks' H_pl tiles and residuals exist for every window but are only written under `debug`)
         zero_end = (A.used + 255) & ~size_t(255);
-        g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(npairs, 1));      // every slot filled on the device (k_build_pairs: the counts are the summary's)
+        g.blk_pairs = A.take<int4>((size_t)std::max<int64_t>(run_path ? 0 : npairs, 1));      // every slot filled on the device (k_build_pairs: the counts are the summary's)
         g.pose_lm = A.take<int32_t>(std::max(n_pose_obs, 1));                   // every slot filled by k_index_scatter
         g.pose_rec = A.take<DeviceGraph::PoseRec>(std::max(n_pose_obs, 1));     // likewise
         g.obs_err = A.take<double>((size_t)std::max(No, 1) * 3);               // debug: every observation, active or not (k_linearize)
@@ -797,6 +903,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
         if (pcg1) std::memcpy(const_cast<int32_t*>(hg.pcg1_code), pcg1_code.data(), pcg1_code.size() * 4);
         if (band_B >= 0) std::memcpy(const_cast<int32_t*>(hg.band_code), band_code.data(), band_code.size() * 4);
+        if (run_path) { std::memcpy(const_cast<int4*>(hg.run_desc), rp.desc.data(), rp.desc.size() * sizeof(int4)); std::memcpy(const_cast<int32_t*>(hg.run_k0), rp.k0.data(), rp.k0.size() * 4); }
     }
     lap("stage fill");
     // device pointers: same offsets
@@ -808,6 +915,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_pose_obs = n_pose_obs;
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
+    dg.n_runs = rp.n; dg.run_lr = rp.LR; dg.run_m = rp.M; dg.run_cap = rp.cap; dg.run_wmax = rp.wmax; dg.run_lds_bytes = (int32_t)rp.lds;
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
@@ -1320,7 +1428,7 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
         struct LapGuard { TaskLap* l; std::chrono::steady_clock::time_point z; ~LapGuard() { if (l) l->t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - z).count(); } } lap_guard{ nullptr, tr0 };
         if (timing) { task_lap[t].slot = slot; task_lap[t].t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); lap_guard.l = &task_lap[t]; }
         SummaryPart* SP = ps ? &(*ps->part)[slot] : nullptr;
-        if (SP && !SP->used) SP->begin(ps->Npf);
+        if (SP && !SP->used) SP->begin(ps->Npf, w->n_points);
         Part& P = part[t];
         int no = cut[t], mono = 0, last_p = -1, last_c = -1;
         // references arrive in nested-map order, so the id looked up is almost always at (or right after) the previous hit
@@ -1372,7 +1480,7 @@ int pack_window_impl(const visfs_ba_window* w, const PackOut& o, visfs_ba_graph*
                 if (o.obs_ref) o.obs_ref[no] = k;
                 ++no;
             }
-            if (fast_sum && !(dbg & 2)) for (int q = no0; q < no; ++q) SP->add(p, pfixed, ps->pose_free[o.obs_pose[q]]);
+            if (fast_sum && !(dbg & 2)) for (int q = no0; q < no; ++q) SP->add(p, pfixed, ps->pose_free[o.obs_pose[q]], o.obs_pose[q]);
         }
         if (SP) SP->flush();
         P.no = no - cut[t]; P.mono = mono; P.last_p = last_p; P.last_c = last_c;
@@ -1941,7 +2049,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
             const bool batchable = batching && (h->prm.framework == 0 || ws.small_solve || band) && (h->prm.solver == 2 || ws.small_solve || ws.fused || band) && ws.g.Np <= MAX_STAGED_POSES && ws.g.Npf <= MAX_PCG_ONE_ROW_POSES;
             if (!batchable) { singles.push_back(i); continue; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
-            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0, ws.spec_fused ? 1 : 0 }].push_back(i);
+            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0, (ws.spec_fused ? 1 : 0) | (ws.g.n_runs > 0 ? 2 : 0) }].push_back(i);
         }
         std::vector<visfs_ba_stats> stats(n);
         int worst = VISFS_BA_OK;
@@ -2040,7 +2148,7 @@ int visfs_ba_batch_optimize(visfs_ba_handle* h, visfs_ba_stats* stats) {
             if (!(h->prm.solver == 2 || ws.small_solve || ws.fused || band)) { h->err = "batched launches need Optimizer/Solver=2, a banded reduced system (direct solver) or reduced systems <= 64 x 64"; return VISFS_BA_ERR_UNSUPPORTED; }
             if (ws.g.Np > MAX_STAGED_POSES || ws.g.Npf > MAX_PCG_ONE_ROW_POSES) { h->err = "windows of more than 840 poses / 256 free poses cannot share launches: solve them one by one"; return VISFS_BA_ERR_UNSUPPORTED; }
             const int cls = band ? 4 : ws.g.pcg_cu ? 3 : ws.g.Npf <= 64 ? 0 : ws.g.Npf <= 128 ? 1 : 2;
-            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0, ws.spec_fused ? 1 : 0 }].push_back(i);
+            groups[{ ws.g.group, cls, ws.small_solve ? 1 : 0, ws.fused ? 1 : 0, (ws.spec_fused ? 1 : 0) | (ws.g.n_runs > 0 ? 2 : 0) }].push_back(i);
         }
         int worst = VISFS_BA_OK;
         for (auto& kv : groups) {
@@ -2071,6 +2179,7 @@ int visfs_ba_graph_describe(visfs_ba_handle* h, visfs_ba_graph_info* out) {
     if (!w.loaded) { h->err = "no graph resident"; return VISFS_BA_ERR_NOT_LOADED; }
     out->n_poses = w.g.Np; out->n_free_poses = w.g.Npf; out->n_points = w.g.Nl; out->n_obs = w.g.No; out->n_odo = w.g.Ne;
     out->n_blk = w.g.n_blk; out->n_pairs = w.n_pairs; out->lanes_per_landmark = w.g.group; out->n_schur_chunks = w.g.n_sch;
+    out->schur_runs = w.g.n_runs; out->schur_run_landmarks = w.g.run_lr * w.g.run_m;
     out->device_bytes = (int64_t)w.device_bytes;
     out->fused_path = w.fused ? 1 : 0;
     out->band_blocks = (h->prm.solver != 2 && !w.small_solve) ? w.g.band_B : -1;

@@ -30,6 +30,9 @@ constexpr int MAX_STAGED_POSES = 840; // poses staged as R|t in LDS (12 doubles 
                                       // larger windows take the kernels that read the poses from HBM (PoseSrc<false>)
 constexpr int MAX_PCG_ONE_ROW_POSES = 256; // persistent PCG with one workgroup per block row: all co-resident (256 CUs, >= 1 workgroup each)
 constexpr int MAX_PCG_FREE_POSES = 1024;   // beyond 256 free poses a workgroup owns several block rows (<= 256 workgroups) and an owner thread up to 4 blocks
+constexpr int RUN_MAX_W = 64;        // k_schur_runs: widest pose span of a run of landmarks (slot table [landmarks][span], 16-bit entries)
+constexpr int RUN_MAX_TILES = 416;   // ... observations of one sub-batch (21 doubles of LDS each: two workgroups per CU)
+constexpr int RUN_TILE = 21;         // ... doubles per staged tile: Q = N D (9), N (9), Pc (3)
 constexpr int SCH_CHUNK = 64;         // co-observation pairs per Schur wavefront and pass (DeviceGraph::sch_chunk = 64 x passes)
 // fused single-workgroup path (k_small_optimize): limits of a "small" window
 constexpr int SM_MAX_POSES = 16;      // R|t of every pose twice in LDS
@@ -127,6 +130,12 @@ struct DeviceGraph {
     int32_t n_lin_a;        // workgroups of the landmark-major role
     int32_t n_edges_ok;     // stereo edges whose two ends are not both fixed (the active set before the outlier pass)
     int32_t group;          // lanes per landmark (4/8/16/32/64)
+    // Schur complement by RUNS OF LANDMARKS (k_schur_runs, round 4): n_runs > 0 selects it, 0 keeps the pair-list gather (k_schur_partial)
+    int32_t n_runs;         // workgroups: run r covers landmarks [r * run_lr * run_m, ...), run_m sub-batches of run_lr landmarks each
+    int32_t run_lr, run_m;
+    int32_t run_cap;        // tile slots in LDS (>= the observations of any sub-batch)
+    int32_t run_wmax;       // widest pose span of a run (<= RUN_MAX_W)
+    int32_t run_lds_bytes;
     double fx, fy, cx, cy, bf;
     double inv_pixel_var, inv_odo_cov, huber_delta;
     // Optimizer/Framework=1 (Ceres branch, Optimizer.cpp:366-593): the residual is info * e with info = I / var, so the objective carries
@@ -177,7 +186,12 @@ struct DeviceGraph {
     const int32_t* blk_chunk_ptr; // [n_blk+1] Schur chunks of each block
     const int4* sch_desc;       // [n_sch] (first pair, last pair + 1, pose index of i, pose index of j): ONE load gives a wave all it needs
     const int4* blk_desc;       // [n_blk][2]: (first Schur chunk, last + 1, first odometry entry, last + 1) — entries of blk_odo for an
-                                //   off-diagonal block, of pose_odo for a diagonal one — and (i, j, first pose-major chunk of i, last + 1)
+                                //   off-diagonal block, of pose_odo for a diagonal one — and (i, j, first pose-major chunk of i, last + 1).
+                                //   n_runs > 0: the first two are (first run | number of runs << 20, pose index of i | pose index of j << 16):
+                                //   the runs whose pose span can hold this block
+    const int32_t* run_k0;      // [n_runs * run_m + 1] first observation of every sub-batch of landmarks (the last entry: No)
+    const int4* run_desc;       // [n_runs] (lowest pose index of the run's observations, pose span W, first slot of its W (W + 1) / 2 block
+                                //   partials in sch_part, 0)
     const int32_t* blk_odo_ptr; // [n_blk+1]
     const int32_t* blk_odo;     // [..] edge*2 + transposed
     const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)

@@ -401,7 +401,7 @@ __device__ __forceinline__ void lin_landmark(const DeviceGraph& g, const LinBuf&
         double2* seed = reinterpret_cast<double2*>(L.obs_pcw + 4 * (size_t)k);
         seed[0] = make_double2(pc.x, pc.y);
         seed[1] = make_double2(pc.z, wo_tile);
-        if (VISFS_BA_POSE_SEEDS) {
+        if (VISFS_BA_POSE_SEEDS && g.n_runs == 0) {   // (k_schur_runs reads the landmark-major seeds)
             const int pp = g.obs_ppos[k];             // the pose-major copy the Schur gather reads (coalesced there)
             if (pp >= 0) {
                 double2* ps = reinterpret_cast<double2*>(L.pose_pcw + 4 * (size_t)pp);
@@ -1330,6 +1330,33 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     schur_chunk<MULTI>(g, L, ch, lane, lambda, pose, dsc, e < dsc.y ? g.blk_pairs[e] : make_int4(0, 0, 0, 0));
 }
 
+// The pose-major role of the linearisation as a workgroup behind a Schur launch (ROLEB): chunk c of a pose's observations.
+template <class Src>
+__device__ __forceinline__ void roleb_chunk(const DeviceGraph& g, const LmState* st, const int c, double* redb) {
+    if (c >= g.n_chunks) return;
+    // chunk -> pose, range, record: none of it depends on the LM state — in flight before the gate
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int a = g.chunk_pose[c];
+    const int begin = g.chunk_ptr[c], end = g.chunk_ptr[c + 1];
+    const bool mine = begin + tid < end;
+    DeviceGraph::PoseRec rec;
+    rec.k = 0; rec.l_ok = -1; rec.u = rec.v = rec.ur = 0.0;
+    if (mine) rec = g.pose_rec[begin + tid];
+    const int ipose = g.free_pose[a];
+    if (!st->lin_b_pending || !(st->mode & MODE_TRIAL)) return;
+    const int sel = st->sel;
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
+    double acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+    if (mine) pose_obs_terms_rec(g, rec, pose_to_Rt(g.pose[sel] + POSE_STRIDE * ipose), g.pt[sel], intr_of(g), g.inv_pixel_var, g.huber_delta, acc);
+    int off = 0, len = 27;
+    ReduceScatter<27, 32>::run(acc, lane, off, len);
+    if (len >= 1) redb[wave * 27 + off] = acc[0];
+    __syncthreads();
+    if (tid < 27) L.hpp_part[27 * (size_t)c + tid] = redb[tid] + redb[27 + tid] + redb[54 + tid] + redb[81 + tid];
+}
+
 // ROLEB (single window, fused speculative unit): the workgroups behind this window's share of the chunk list are the pose-major role of
 // the linearisation the previous unit's k_backsub<LINA> left half done (LmState::lin_b_pending): upper triangle of Jx^T (rho' Omega) Jx
 // and -Jx^T (rho' Omega) e per chunk of a pose's observations, at the committed estimate, into the current set's hpp_part — read by
@@ -1345,29 +1372,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
         const int first_b = (((g.n_sch + 3) / 4) + 7) / 8 * 8;
         if ((int)blockIdx.x >= first_b) {
             __shared__ double redb[4 * 27];
-            const int c = (int)blockIdx.x - first_b;
-            if (c >= g.n_chunks) return;
-            // chunk -> pose, range, record: none of it depends on the LM state — in flight before the gate
-            const int tid = threadIdx.x, wave = tid >> 6;
-            const int a = g.chunk_pose[c];
-            const int begin = g.chunk_ptr[c], end = g.chunk_ptr[c + 1];
-            const bool mine = begin + tid < end;
-            DeviceGraph::PoseRec rec;
-            rec.k = 0; rec.l_ok = -1; rec.u = rec.v = rec.ur = 0.0;
-            if (mine) rec = g.pose_rec[begin + tid];
-            const int ipose = g.free_pose[a];
-            if (!st->lin_b_pending || !(st->mode & MODE_TRIAL)) return;
-            const int sel = st->sel;
-            const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
-            double acc[27];
-#pragma unroll
-            for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-            if (mine) pose_obs_terms_rec(g, rec, pose_to_Rt(g.pose[sel] + POSE_STRIDE * ipose), g.pt[sel], intr_of(g), g.inv_pixel_var, g.huber_delta, acc);
-            int off = 0, len = 27;
-            ReduceScatter<27, 32>::run(acc, lane, off, len);
-            if (len >= 1) redb[wave * 27 + off] = acc[0];
-            __syncthreads();
-            if (tid < 27) L.hpp_part[27 * (size_t)c + tid] = redb[tid] + redb[27 + tid] + redb[54 + tid] + redb[81 + tid];
+            roleb_chunk<Src>(g, st, (int)blockIdx.x - first_b, redb);
             return;
         }
     }
@@ -1389,6 +1394,242 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     if (!(st->mode & MODE_TRIAL)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     schur_chunk<MULTI, CERES>(g, L, ch, lane, st->lambda, g.pose[st->sel], dsc, pr);
+}
+
+// ================================================================= K5, round 4: Schur complement by RUNS OF LANDMARKS
+// The pair-list gather above rebuilds both 3x3 tile cores and inverts the landmark block for EVERY co-observation pair (at track
+// length 10 a tile is rebuilt 11 times, a landmark's D^-1 formed 55 times per damped solve) and pays a 42-value cross-lane reduction per
+// 64 pairs: 581 VALU instructions per wavefront for ~162 useful multiply-adds per pair (profiles/r03_v4_sq_C4R_counters.json); it is the
+// arithmetic-bound kernel of the 200-key-frame window and of batched launches.  k_schur_runs turns the loop inside out:
+//   * a workgroup owns a RUN of consecutive landmarks (run_lr x run_m of them; landmark ids grow with time, so a run's observations lie
+//     in a short span of W poses — the host knows every run's span from the structure summary and picks run_lr so that a sub-batch's
+//     observations fit the LDS);
+//   * phase 1, one lane per observation: the tile core N (tile_core), the landmark's damped inverse D, Q = N D and the camera-frame
+//     point go to LDS ONCE — these are the "LDS-staged Jacobian tiles" — and the (landmark, pose) -> tile slot table is filled;
+//   * phase 2, one lane per (block of the run's span, part): the lane walks the landmarks of its part and ACCUMULATES
+//     W_a D W_b^T = [P, P Xb^T; Xa P, Xa P Xb^T], P = Q_a N_b^T, in registers — 81 multiply-adds per pair on operands read from LDS,
+//     no tile rebuild, no inverse, no cross-lane traffic;
+//   * the parts of a block are added in part order through LDS and the run writes ONE partial per block of its span (sch_part, at
+//     run_desc.z); k_schur_finalize adds the partials of the runs whose span holds the block, in run order.
+// Every sum has a fixed order that depends on the window alone: results are reproducible and independent of any batch.  Per pair the
+// operands are the values the gather forms (same functions), only the association of the sums differs.
+constexpr unsigned short RUN_NONE = 0xffffu;
+constexpr int RUN_RED = 14;                // sums per item and pass of the reduction over the parts (42 = 3 x 14)
+// Global-load chain of a workgroup: run_desc / run_k0 / the LM state (level 1) -> EVERYTHING else (level 2): the seeds and indices of the
+// thread's (up to two) observations, H_ll and b_l of the sub-batch's landmarks (consecutive ids: addresses follow from the run number), the
+// poses of the run's span.  D_l and R_i are formed once per landmark / pose into LDS, the tiles from those.
+#ifndef VISFS_BA_RUN_WAVES
+#define VISFS_BA_RUN_WAVES 3           // waves per SIMD the kernel is compiled for (A/B builds)
+#endif
+// barrier that waits for this wave's LDS traffic only (__syncthreads() also drains the global stores of the partials)
+#define RUN_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <class Src, bool CERES = false, bool ROLEB = false>
+__global__ __launch_bounds__(256, VISFS_BA_RUN_WAVES) void k_schur_runs(const Src src) {
+    const DeviceGraph& g = graph_of(src);
+    const LmState* st = g.st;
+    extern __shared__ __attribute__((aligned(16))) double run_lds[];
+    const int tid = threadIdx.x;
+    const int nwg = (g.n_runs + 7) / 8 * 8;                  // this window's share of the launch
+    if (ROLEB) {
+        if ((int)blockIdx.x >= nwg) { roleb_chunk<Src>(g, st, (int)blockIdx.x - nwg, run_lds); return; }
+    }
+    const int bx = (int)blockIdx.x;
+    if (bx >= nwg) return;
+    // XCD-aware: consecutive runs (neighbouring poses, the same Hll / seeds lines) on one XCD's L2, as the gather does
+    const int per_xcd = nwg >> 3;
+    const int r = (bx & 7) * per_xcd + (bx >> 3);
+    if (r >= g.n_runs) return;
+#ifdef VISFS_BA_STAMPS
+#define RUN_STAMP(slot) do { if (tid == 0 && r == g.stamp_wg) g.stamps[96 + (slot)] = wall_clock64(); } while (0)
+#else
+#define RUN_STAMP(slot) do { } while (0)
+#endif
+    RUN_STAMP(0);
+    const int LR = g.run_lr, M = g.run_m;
+    const int4 rd = g.run_desc[r];                            // (lowest pose index, span W, first partial slot, -) — before the gate
+    int k_next = g.run_k0[r * M];                             // first observation of the first sub-batch
+    const int L0 = r * LR * M, L1 = min(g.Nl, L0 + LR * M);
+    if (!(st->mode & MODE_TRIAL)) return;
+    const int ipmin = rd.x, W = rd.y;
+    const int nb = W * (W + 1) / 2;
+    if (nb == 0) return;                                     // a run without observations: no partial slot, nothing reads one
+    const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
+    const double lambda = st->lambda;
+    const double* __restrict__ pose = g.pose[st->sel];
+    const Intrinsics K = intr_of(g);
+    // ---- LDS: tiles (reused for the reduction over the parts), b_l / D_l of the sub-batch, R of the span's poses, slot table, (i, j) of the local blocks
+    const int cap = max(g.run_cap, (256 * RUN_RED + RUN_TILE - 1) / RUN_TILE);
+    double* tiles = run_lds;                                                  // [cap][21]
+    double* sbl = tiles + (size_t)cap * RUN_TILE;                             // [LR][3]
+    double* sD = sbl + 3 * LR;                                                // [LR][6]  (D[0] = NaN: no usable inverse)
+    double* sR = sD + 6 * LR;                                                 // [run_wmax][9]
+    unsigned short* slot = reinterpret_cast<unsigned short*>(sR + 9 * g.run_wmax);   // [LR][W]
+    unsigned short* bij = slot + ((LR * g.run_wmax + 3) & ~3);                // [nb] i | j << 8
+    for (int t = tid; t < nb; t += 256) {
+        int i = 0, off = 0;
+        while (t >= off + (W - i)) { off += W - i; ++i; }
+        bij[t] = (unsigned short)(i | ((i + t - off) << 8));
+    }
+    if (tid >= 64 && tid < 64 + W) {                          // R of pose ipmin + (tid - 64), wave 1
+        const Rt T = pose_to_Rt(pose + POSE_STRIDE * (ipmin + tid - 64));
+        double* o = sR + 9 * (tid - 64);
+        o[0] = T.R.m00; o[1] = T.R.m01; o[2] = T.R.m02; o[3] = T.R.m10; o[4] = T.R.m11; o[5] = T.R.m12; o[6] = T.R.m20; o[7] = T.R.m21; o[8] = T.R.m22;
+    }
+    // blocks of the span in rounds of 256 items; one round whenever the span has <= 22 poses (then P parts share a block)
+    for (int blk0 = 0; blk0 < nb; blk0 += 256) {
+        const int nbr = min(256, nb - blk0);
+        const int P = nb <= 256 ? max(1, 256 / nb) : 1;
+        const int blk = tid / P, part = tid - blk * P;
+        const bool item = blk < nbr;
+        __syncthreads();                                     // bij, sR complete (first round); the previous round's reduction has left the tiles region
+        RUN_STAMP(1);
+        int bi = 0, bj = 0;
+        bool live = false, diag = false;
+        if (item) {
+            const unsigned v = bij[blk0 + blk];
+            bi = (int)(v & 0xffu); bj = (int)(v >> 8);
+            live = g.pose_free[ipmin + bi] >= 0 && g.pose_free[ipmin + bj] >= 0;
+            diag = bi == bj;
+        }
+        double G[36], gb[6];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) G[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) gb[q] = 0.0;
+        if (blk0 > 0) k_next = g.run_k0[r * M];
+        for (int m = 0; m < M; ++m) {
+            const int Lb0 = L0 + m * LR, Lb1 = min(L1, Lb0 + LR);
+            if (Lb0 >= Lb1) break;
+            const int nl = Lb1 - Lb0;
+            const int k0 = k_next;
+            k_next = g.run_k0[r * M + m + 1];
+            const int nt = k_next - k0;
+            // ---- phase 1a: every global load of the sub-batch, none depending on another
+            double2 s0[2], s1[2];
+            int ol[2], oi[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tid + 256 * u;
+                s0[u] = make_double2(0.0, 0.0); s1[u] = make_double2(0.0, 0.0); ol[u] = Lb0; oi[u] = ipmin;
+                if (t < nt) {
+                    const double2* seed = reinterpret_cast<const double2*>(L.obs_pcw + 4 * (size_t)(k0 + t));
+                    s0[u] = seed[0]; s1[u] = seed[1];
+                    ol[u] = g.obs_pt[k0 + t]; oi[u] = g.obs_pose[k0 + t];
+                }
+            }
+            double Hh[6] = { 1.0, 0.0, 0.0, 1.0, 0.0, 1.0 };
+            if (tid < nl) {
+                const double* H = L.Hll + 6 * (size_t)(Lb0 + tid);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Hh[q] = H[q];
+            }
+            __syncthreads();                                 // the previous sub-batch's readers are done with tiles / slot / sbl / sD
+            RUN_STAMP(2);
+            for (int t = tid; t < nl * W; t += 256) slot[t] = RUN_NONE;
+            for (int t = tid; t < 3 * nl; t += 256) sbl[t] = L.bl[3 * (size_t)Lb0 + t];
+            if (tid < nl) {
+                const int l = Lb0 + tid;
+                double a0 = lambda, a1 = lambda, a2 = lambda;
+                if (CERES) { a0 = damp_of(g, lambda, Hh[0], g.s2l, 3 * (size_t)l); a1 = damp_of(g, lambda, Hh[3], g.s2l, 3 * (size_t)l + 1); a2 = damp_of(g, lambda, Hh[5], g.s2l, 3 * (size_t)l + 2); }
+                const double h[6] = { Hh[0] + a0, Hh[1], Hh[2], Hh[3] + a1, Hh[4], Hh[5] + a2 };
+                double D[6];
+                sym3_inverse(h, D);
+                // (a singular damped block — Gauss-Newton, lambda = 0, a landmark without active edges — drops out as in the gather)
+                const bool okD = (D[0] == D[0]) && (fabs(D[0]) <= DBL_MAX) && (D[3] == D[3]) && (fabs(D[3]) <= DBL_MAX) && (D[5] == D[5]) && (fabs(D[5]) <= DBL_MAX);
+                double* o = sD + 6 * tid;
+                o[0] = okD ? D[0] : __builtin_nan(""); o[1] = D[1]; o[2] = D[2]; o[3] = D[3]; o[4] = D[4]; o[5] = D[5];
+            }
+            __syncthreads();
+            RUN_STAMP(3);
+            // ---- phase 1b: the tiles of this thread's observations, from registers and LDS
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = tid + 256 * u;
+                if (t >= nt || s1[u].y == 0.0) continue;      // no tile: inactive edge, fixed pose or fixed landmark
+                const double* D = sD + 6 * (ol[u] - Lb0);
+                const double D0 = D[0];
+                if (!(D0 == D0)) continue;
+                const double* Rr = sR + 9 * (oi[u] - ipmin);
+                const Mat3 R{ Rr[0], Rr[1], Rr[2], Rr[3], Rr[4], Rr[5], Rr[6], Rr[7], Rr[8] };
+                const Vec3 pc{ s0[u].x, s0[u].y, s1[u].x };
+                double N[9];
+                tile_core(R, pc, s1[u].y, K, N);
+                double* o = tiles + (size_t)t * RUN_TILE;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {                // Q = N D
+                    o[3 * rr + 0] = N[3 * rr] * D0 + N[3 * rr + 1] * D[1] + N[3 * rr + 2] * D[2];
+                    o[3 * rr + 1] = N[3 * rr] * D[1] + N[3 * rr + 1] * D[3] + N[3 * rr + 2] * D[4];
+                    o[3 * rr + 2] = N[3 * rr] * D[2] + N[3 * rr + 1] * D[4] + N[3 * rr + 2] * D[5];
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) o[9 + q] = N[q];
+                o[18] = pc.x; o[19] = pc.y; o[20] = pc.z;
+                slot[(ol[u] - Lb0) * W + (oi[u] - ipmin)] = (unsigned short)t;
+            }
+            __syncthreads();
+            RUN_STAMP(4);
+            // ---- phase 2: this item's block over the landmarks of its part
+            if (live) {
+                for (int ll = part; ll < nl; ll += P) {
+                    const unsigned sa = slot[ll * W + bi], sb = slot[ll * W + bj];
+                    if (sa == RUN_NONE || sb == RUN_NONE) continue;
+                    const double* ta = tiles + (size_t)sa * RUN_TILE;
+                    const double* tb = tiles + (size_t)sb * RUN_TILE;
+                    double Q[9], Nb[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) { Q[q] = ta[q]; Nb[q] = tb[9 + q]; }
+                    const Vec3 pa{ ta[18], ta[19], ta[20] }, pb{ tb[18], tb[19], tb[20] };
+                    double T[18];
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        const double p0 = Q[3 * rr] * Nb[0] + Q[3 * rr + 1] * Nb[1] + Q[3 * rr + 2] * Nb[2];       // P = Q Nb^T
+                        const double p1 = Q[3 * rr] * Nb[3] + Q[3 * rr + 1] * Nb[4] + Q[3 * rr + 2] * Nb[5];
+                        const double p2 = Q[3 * rr] * Nb[6] + Q[3 * rr + 1] * Nb[7] + Q[3 * rr + 2] * Nb[8];
+                        T[6 * rr + 0] = p0; T[6 * rr + 1] = p1; T[6 * rr + 2] = p2;
+                        T[6 * rr + 3] = pb.y * p2 - pb.z * p1; T[6 * rr + 4] = pb.z * p0 - pb.x * p2; T[6 * rr + 5] = pb.x * p1 - pb.y * p0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) G[q] += T[q];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {               // bottom half: Pc_a crossed with the columns of the top half, two fused multiply-adds each
+                        const double t0 = T[c], t1 = T[6 + c], t2 = T[12 + c];
+                        G[18 + c] = fma(-pa.z, t1, fma(pa.y, t2, G[18 + c]));
+                        G[24 + c] = fma(-pa.x, t2, fma(pa.z, t0, G[24 + c]));
+                        G[30 + c] = fma(-pa.y, t0, fma(pa.x, t1, G[30 + c]));
+                    }
+                    if (diag) {
+                        const double B0 = sbl[3 * ll], B1 = sbl[3 * ll + 1], B2 = sbl[3 * ll + 2];
+                        const double v0 = Q[0] * B0 + Q[1] * B1 + Q[2] * B2, v1 = Q[3] * B0 + Q[4] * B1 + Q[5] * B2, v2 = Q[6] * B0 + Q[7] * B1 + Q[8] * B2;
+                        gb[0] += v0; gb[1] += v1; gb[2] += v2;
+                        gb[3] += pa.y * v2 - pa.z * v1; gb[4] += pa.z * v0 - pa.x * v2; gb[5] += pa.x * v1 - pa.y * v0;
+                    }
+                }
+            }
+        }
+        // ---- the parts of a block added in part order: the 42 sums of an item go through the tiles region in three thirds of 14 (entry
+        // e of the partial: 0..35 the block row-major, 36..41 b_s); LDS-only barriers — the global stores of a third stay in flight
+        double* out = g.sch_part + 42 * ((size_t)rd.z + blk0);
+        RUN_STAMP(5);
+#pragma unroll
+        for (int third = 0; third < 3; ++third) {
+            RUN_SYNC();
+            RUN_STAMP(6 + 2 * third);
+            if (item) {
+                double* o = tiles + (size_t)tid * RUN_RED;
+#pragma unroll
+                for (int q = 0; q < RUN_RED; ++q) { const int e = RUN_RED * third + q; o[q] = e < 36 ? G[e < 36 ? e : 0] : gb[e >= 36 ? e - 36 : 0]; }
+            }
+            RUN_SYNC();
+            for (int t = tid; t < RUN_RED * nbr; t += 256) {
+                const int b2 = t / RUN_RED, q = t - RUN_RED * b2;
+                const double* src2 = tiles + (size_t)(b2 * P) * RUN_RED + q;
+                double v = src2[0];
+                for (int pp = 1; pp < P; ++pp) v += src2[RUN_RED * pp];
+                out[42 * (size_t)b2 + RUN_RED * third + q] = v;
+            }
+            RUN_STAMP(7 + 2 * third);
+        }
+    }
 }
 
 // k_schur_finalize: one wavefront per stored block:
@@ -1419,7 +1660,46 @@ __device__ __forceinline__ double gauss_jordan_6x6(const double val, const int l
 // One wavefront, one stored block of S: shared by k_schur_finalize and the fused small-window kernel.
 // (bd, be = blk_desc[2 b], blk_desc[2 b + 1] come from the caller: they do not depend on the LM state, so a kernel can have them in
 // flight while its gate is still being read)
-__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be) {
+// k_schur_runs' partials of one block: the runs whose pose span holds the block, in run order, dealt over the `nw` waves of the caller
+// (wave w takes the hits whose ordinal is w mod nw and adds them in ascending order; the caller adds the waves' sums in wave order).
+// bdx = first candidate run | count << 20, bdy = pose index of i | pose index of j << 16 (blk_desc).  Lane = run for the descriptors (one
+// coalesced load per 64 runs); a hit's partial slot is broadcast with a readlane; eight loads in flight.
+__device__ __forceinline__ double run_partial_sum(const DeviceGraph& g, const int bdx, const int bdy, const int lane, const int wave, const int nw) {
+    const int r0 = bdx & 0xfffff, r1 = r0 + (int)((unsigned)bdx >> 20);
+    const int pi = bdy & 0xffff, pj = (int)((unsigned)bdy >> 16);
+    double part = 0.0;
+    int ord = 0, n = 0;
+    int s8[8];
+    auto flush = [&]() {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = (u < n && lane < 42) ? g.sch_part[42 * (size_t)s8[u] + lane] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u < n) part += v8[u];
+        n = 0;
+    };
+    for (int base = r0; base < r1; base += 64) {
+        const int rr = base + lane;
+        const int4 rd = rr < r1 ? g.run_desc[rr] : make_int4(0, 0, 0, 0);
+        const int li = pi - rd.x, lj = pj - rd.x;
+        const bool hit = rr < r1 && li >= 0 && lj < rd.y;
+        const int idx = rd.z + li * rd.y - (li * (li - 1)) / 2 + (lj - li);
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int bit = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int sidx = __builtin_amdgcn_readlane(idx, bit);
+            if ((ord++ % nw) != wave) continue;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u == n) s8[u] = sidx;
+            if (++n == 8) flush();
+        }
+    }
+    if (n > 0) flush();
+    return part;
+}
+
+__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be, const double part_in = 0.0) {
     {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass.
         // CONTRACT with the persistent PCG (k_pcg / k_pcg1) that follows: (1) EVERY block's wave runs this loop — the words are dealt
         // over all n_blk waves (stride n_blk * 64), so a kernel that calls schur_block for a subset of the blocks clears only a
@@ -1437,8 +1717,10 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     const int i = be.x, j = be.y;
     const bool diag = (i == j);
     const int r = lane / 6, c = lane % 6;    // meaningful for lane < 36
-    double part = 0.0;
-    if (lane < 42) {
+    double part = part_in;
+    if (g.n_runs > 0) {
+        // (k_schur_runs' partials: summed by run_partial_sum on the four waves of the block's workgroup, handed in)
+    } else if (lane < 42) {
         // (unroll 8 measured slower than 4: a C2 block has ~5 two-pass chunks, most of them would run in the remainder loop)
 #pragma unroll 4
         for (int ch = bd.x; ch < bd.y; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
@@ -1477,21 +1759,32 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
 }
 
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
+    // (the fused small-window kernel: pair-list gather only)
     schur_block(g, L, st, b, lane, g.blk_desc[2 * b], g.blk_desc[2 * b + 1]);     // (first chunk, last + 1, first odometry entry, last + 1), (i, j, first pose-major chunk of i, last + 1)
 }
 
-template <class Src>
+// RUNS (the Schur complement came from k_schur_runs): one WORKGROUP per stored block — a block collects one partial per run whose span
+// holds it (tens, where the gather left a handful of chunk partials), so the four waves each add a quarter of them and wave 0 finishes.
+template <class Src, bool RUNS = false>
 __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = g.st;
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = RUNS ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     if (b >= g.n_blk) return;
     // the block descriptors first, the gate after: one cold-L2 round trip instead of two at the head of the kernel
     const int4 bd = g.blk_desc[2 * b], be = g.blk_desc[2 * b + 1];
     if (!(st->mode & MODE_TRIAL)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
-    schur_block(g, L, st, b, lane, bd, be);
+    if (RUNS) {
+        __shared__ double sp[4 * 42];
+        const double mine = run_partial_sum(g, bd.x, bd.y, lane, wave, 4);
+        if (lane < 42) sp[42 * wave + lane] = mine;
+        __syncthreads();
+        if (wave != 0) return;
+        const double part = lane < 42 ? ((sp[lane] + sp[42 + lane]) + sp[84 + lane]) + sp[126 + lane] : 0.0;
+        schur_block(g, L, st, b, lane, bd, be, part);
+    } else schur_block(g, L, st, b, lane, bd, be);
 }
 
 // ================================================================= K6: block-Jacobi PCG on S, persistent
@@ -3931,8 +4224,10 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.chunks = g.n_chunks;
     d.backsub_blocks = g.n_lin_a + 1;
     d.sch_wgs = g.n_sch > 0 ? (((g.n_sch + 3) / 4) + 7) / 8 * 8 : 0;
+    d.run_wgs = g.n_runs > 0 ? (g.n_runs + 7) / 8 * 8 : 0;
+    d.run_lds = g.n_runs > 0 ? g.run_lds_bytes : 0;
     d.sch_multi = g.sch_chunk > 64 ? 1 : 0;
-    d.fin_wgs = (g.n_blk + 3) / 4;
+    d.fin_wgs = g.n_runs > 0 ? g.n_blk : (g.n_blk + 3) / 4;
     d.pcg_rows = g.Npf;
     d.pcg_lds = g.pcg_lds_bytes;
     d.eval_blocks = (g.No + 255) / 256 + 1;
@@ -3949,6 +4244,7 @@ LaunchDims dims_of(const DeviceGraph& g) {
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     LaunchDims d = a;
     d.np = std::max(a.np, b.np); d.lin_blocks = std::max(a.lin_blocks, b.lin_blocks); d.chunks = std::max(a.chunks, b.chunks); d.backsub_blocks = std::max(a.backsub_blocks, b.backsub_blocks);
+    d.run_wgs = std::max(a.run_wgs, b.run_wgs); d.run_lds = std::max(a.run_lds, b.run_lds);   // (a launch serves run-path windows or gather windows, never both)
     d.sch_wgs = std::max(a.sch_wgs, b.sch_wgs); d.fin_wgs = std::max(a.fin_wgs, b.fin_wgs); d.pcg_rows = std::max(a.pcg_rows, b.pcg_rows);
     d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
     d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
@@ -4022,6 +4318,12 @@ static void launch_ceres_lin_finalize_src(const Src& src, int B, hipStream_t s) 
 }
 template <class Src>
 static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    if (d.run_wgs > 0) {                                                   // Schur complement by runs of landmarks
+        const size_t lds = (size_t)d.run_lds;
+        if (d.ceres) { ensure_lds(k_schur_runs<Src, true>, lds); TIMED_LAUNCH((k_schur_runs<Src, true>), dim3(d.run_wgs, B), dim3(256), lds, s, src); }
+        else { ensure_lds(k_schur_runs<Src, false>, lds); TIMED_LAUNCH((k_schur_runs<Src, false>), dim3(d.run_wgs, B), dim3(256), lds, s, src); }
+        return;
+    }
     if (d.sch_wgs <= 0) return;
     if (d.ceres) {                                                         // Optimizer/Framework=1: the damping is per variable (damp_of)
         if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src, true>), dim3(d.sch_wgs, B), dim3(256), 0, s, src);
@@ -4033,7 +4335,8 @@ static void launch_schur_partial_src(const Src& src, const LaunchDims& d, int B,
 }
 template <class Src>
 static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    TIMED_LAUNCH((k_schur_finalize<Src>), dim3(d.fin_wgs, B), dim3(256), 0, s, src);
+    if (d.run_wgs > 0) TIMED_LAUNCH((k_schur_finalize<Src, true>), dim3(d.fin_wgs, B), dim3(256), 0, s, src);     // one workgroup per block
+    else TIMED_LAUNCH((k_schur_finalize<Src>), dim3(d.fin_wgs, B), dim3(256), 0, s, src);
 }
 template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
@@ -4087,7 +4390,7 @@ void launch_build_index(const DeviceGraph& g, int32_t* hist, hipStream_t s) {
 }
 int index_blocks(int No) { return (No + IDX_T - 1) / IDX_T; }
 void launch_build_pairs(const DeviceGraph& g, hipStream_t s) {
-    if (g.n_blk <= 0) return;
+    if (g.n_blk <= 0 || g.n_runs > 0) return;             // (the run-based Schur kernel needs no pair lists)
     hipLaunchKernelGGL(k_build_pairs, dim3((g.n_blk + 3) / 4), dim3(256), 0, s, g);
 }
 void launch_linearize(const DeviceGraph& g, hipStream_t s) { launch_linearize_src(One{ g }, dims_of(g), 1, 0, s); }
@@ -4122,6 +4425,12 @@ static void launch_backsub_lin_src(const Src& src, const LaunchDims& d, int B, h
 }
 template <class Src>
 static void launch_schur_partial_roleb_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
+    if (d.run_wgs > 0) {
+        const size_t lds = (size_t)d.run_lds;
+        ensure_lds(k_schur_runs<Src, false, true>, lds);
+        TIMED_LAUNCH((k_schur_runs<Src, false, true>), dim3(d.run_wgs + d.chunks, B), dim3(256), lds, s, src);
+        return;
+    }
     const int grid = d.sch_wgs + d.chunks;                    // (a window's role-B workgroups start right behind ITS share of the chunk list)
     if (grid <= 0) return;
     if (d.sch_multi) TIMED_LAUNCH((k_schur_partial<true, Src, false, true>), dim3(grid, B), dim3(256), 0, s, src);
