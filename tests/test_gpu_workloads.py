@@ -646,3 +646,47 @@ def test_windows_the_run_kernel_does_not_fit_keep_the_gather(olib, monkeypatch):
     assert s.describe()["schur_runs"] > 0
     check_optimize(o, s, pose_tol=1e-9)
     s.close(); o.close()
+
+
+@pytest.mark.parametrize("case", ["C1", "PROD", "K30", "K30_S0", "K30_CERES", "C2"])
+def test_per_frame_launch_sequence_is_replayed_across_uploads_and_changes_no_byte(olib, monkeypatch, case):
+    """Round 4: visfs_ba_solve_window runs its launches through the kernels that read the window from a fixed device
+    address, on grids rounded up to size classes; the sequence captured at the second frame of a class is REPLAYED for the following frames
+    although every frame uploads a new window (other measurements, a few references more or less).  Every frame's result must be the bytes
+    of the by-value path (VISFS_BA_FRAME_GRAPH=0), and the later frames must really have been replays."""
+    from visfs_amd import backend
+    from helpers import drop_refs
+    kw = dict(iterations=10, solver=2)
+    if case == "K30_S0":
+        kw["solver"] = 0
+    if case == "K30_CERES":
+        kw["framework"] = 1
+    if case == "C2":
+        kw["iterations"] = 20
+
+    def frame(i):
+        if case in ("C1", "PROD", "C2"):
+            w = synth.make_window(case, window_index=i)
+        else:
+            w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=100 + i)
+        if i % 3 == 1:                                       # a few references fewer: other sizes, (mostly) the same class
+            rng = np.random.default_rng(i)
+            w = drop_refs(w, rng.random(len(w["ref_feature"])) > 0.01)
+        return w
+    n_frames = 7
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("VISFS_BA_FRAME_GRAPH", mode)
+        s = backend.Solver(abi.default_params(**kw))
+        res = []
+        for i in range(n_frames):
+            wb = abi.WindowBuffers(frame(i))
+            rc, rb = s.solve_window(wb)
+            res.append((rc, rb.pose_Twr_out.copy(), rb.outliers(), wb.point_xyz.copy(), list(rb.struct.iterations_run), rb.struct.chi2_final, s.describe()["graph_replayed"]))
+        outs[mode] = res
+        s.close()
+    for a, b in zip(outs["0"], outs["2"]):
+        assert a[0] == b[0] == abi.OK
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3], equal_nan=True) and a[4] == b[4] and a[5] == b[5]
+    assert not any(r[6] for r in outs["0"])                  # the by-value path never replays a per-frame call
+    assert sum(r[6] for r in outs["2"]) >= n_frames - 4      # two frames at most per class before the replays start (two classes show up)

@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace visfs_ba {
 
@@ -215,11 +216,16 @@ __device__ __forceinline__ Intrinsics intr_of(const DeviceGraph& g) { return Int
 // Many: independent windows solved side by side — blockIdx.y selects the window from an array in HBM,
 // every window is gated by its own LmState, so the same launch serves windows at different points of their LM loops.
 struct One { DeviceGraph g; static constexpr bool batched = false; };
-struct Many { const DeviceGraph* gs; static constexpr bool batched = true; };
+// st1 (a launch that serves ONE window whose LM state sits at a fixed address — the per-frame path, whose captured launch sequence is
+// replayed across uploads): the gate of every kernel is then read through a pointer that travels in the kernel arguments, in parallel
+// with the first fields of the graph, instead of behind them; nullptr for batches.
+struct Many { const DeviceGraph* gs; LmState* st1; static constexpr bool batched = true; };
 // host side of the launchers: the by-value graph of a single window (a batch never reaches the callers of this: see staged())
 inline const DeviceGraph& graph_of_host(const One& s) { return s.g; }
 inline const DeviceGraph& graph_of_host(const Many&) { static const DeviceGraph none{}; return none; }
 __device__ __forceinline__ const DeviceGraph& graph_of(const One& s) { return s.g; }
+__device__ __forceinline__ LmState* state_of(const One&, const DeviceGraph& g) { return g.st; }
+__device__ __forceinline__ LmState* state_of(const Many& s, const DeviceGraph& g) { return s.st1 ? s.st1 : g.st; }
 // The graph array of a batch is written by the host before the launches and never by a kernel: reading it through the constant
 // address space lets the compiler fetch the members with scalar loads into SGPRs (as it does for the by-value graph of One)
 // instead of keeping vector-loaded copies live in VGPRs.
@@ -706,7 +712,7 @@ template <int G, class Src, bool SPEC, bool STG = true>
 __global__ __launch_bounds__(256) void k_linearize(const Src src) {
     constexpr bool spec = SPEC;
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sRt = smem;                       // [Np][12] (STG)
     double* red = smem + (STG ? 12 * g.Np : 0);   // [4 * 27]
@@ -856,7 +862,7 @@ template <class Src>
 __global__ __launch_bounds__(256) void k_odo_linearize(const Src src, const int spec_arg) {
     const bool spec = !Src::batched && spec_arg;
     const DeviceGraph& g = graph_of(src);
-    const LmState* st = g.st;
+    const LmState* st = state_of(src, g);
     int sel, ls;
     if (spec) { if (!st->spec_go) return; sel = st->spec_src; ls = st->spec_dst; }
     else { if (!(st->mode & MODE_LIN)) return; sel = st->sel; ls = st->lin_sel; }
@@ -934,7 +940,7 @@ int ceres_script_host(const int max_iter, const double cost0, const double x_nor
 template <class Src>
 __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int force) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (!(st->mode & MODE_LIN)) return;
     if (!force && st->phase_iter != 0) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(1024) void k_lin_finalize(const Src src, const int 
 template <class Src>
 __global__ __launch_bounds__(1024) void k_ceres_lin_finalize(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (!(st->mode & MODE_LIN)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     __shared__ double red[48];
@@ -1364,7 +1370,7 @@ __device__ __forceinline__ void roleb_chunk(const DeviceGraph& g, const LmState*
 template <bool MULTI, class Src, bool CERES = false, bool ROLEB = false>
 __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    const LmState* st = g.st;
+    const LmState* st = state_of(src, g);
     const int lane = threadIdx.x & 63;
     // (role B sits BEHIND the gather in dispatch order: in front of it — measured — it delays the chunk workgroups, which are the launch's
     // critical path, and costs C2 4 %; behind it the launch is 1.5 us longer than the plain gather)
@@ -1426,7 +1432,7 @@ constexpr int RUN_RED = 14;                // sums per item and pass of the redu
 template <class Src, bool CERES = false, bool ROLEB = false>
 __global__ __launch_bounds__(256, VISFS_BA_RUN_WAVES) void k_schur_runs(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    const LmState* st = g.st;
+    const LmState* st = state_of(src, g);
     extern __shared__ __attribute__((aligned(16))) double run_lds[];
     const int tid = threadIdx.x;
     const int nwg = (g.n_runs + 7) / 8 * 8;                  // this window's share of the launch
@@ -1768,7 +1774,7 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
 template <class Src, bool RUNS = false>
 __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = RUNS ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     if (b >= g.n_blk) return;
@@ -1828,7 +1834,7 @@ __global__ __launch_bounds__(256) void k_pcg(const Src src) {
     static_assert(!MREG || BPL == 1, "Minv in registers: one block per owner");
     static_assert(!MULTIROW || WIDE, "several rows per workgroup only in the WIDE form");
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (!(st->mode & MODE_TRIAL)) return;
     const int R = MULTIROW ? g.pcg_rows_per_wg : 1;   // block rows of S per workgroup
     if ((int)blockIdx.x * R >= g.Npf) return;         // a batched launch is sized for the largest window
@@ -2145,7 +2151,7 @@ struct ReduceScatterUp<N, 64> {
 template <class Src, int GV>
 __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (GV == 3 && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
     if (!(st->mode & MODE_TRIAL)) return;
     const int i0 = GV == 3 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -2372,7 +2378,7 @@ constexpr int CU_MAX_N6 = 16 * CU_RPW; // 336 scalar rows = 56 free poses in 16 
 template <class Src>
 __global__ __launch_bounds__(1024) void k_pcg_cu(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (!(st->mode & MODE_TRIAL)) return;
     __shared__ __attribute__((aligned(16))) double sd[CU_MAX_N6 + 8], sr[CU_MAX_N6 + 8];
     __shared__ __attribute__((aligned(16))) double sM[CU_MAX_N6 * 6];      // Minv rows
@@ -2881,7 +2887,7 @@ __device__ __forceinline__ void band_apply_dinv(const double* __restrict__ X, co
 template <class Src>
 __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (!(st->mode & MODE_TRIAL)) return;
     extern __shared__ __attribute__((aligned(16))) double band_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -3313,7 +3319,7 @@ __global__ __launch_bounds__(256, (DEC && Src::batched) ? (LINA ? (ODOSPEC ? 2 :
         if (dw == -2) return;
     }
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
 #ifdef VISFS_BA_STAMPS
 #define BS_STAMP(slot) do { if (LINA && threadIdx.x == 0 && blockIdx.x == (unsigned)g.stamp_wg) g.stamps[32 + (slot)] = wall_clock64(); } while (0)
 #else
@@ -3429,7 +3435,7 @@ __global__ __launch_bounds__(256, (DEC && Src::batched) ? (LINA ? (ODOSPEC ? 2 :
 template <class Src>
 __global__ __launch_bounds__(256) void k_dogleg_mid(const Src src) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     __shared__ double red[4];
     if (!(st->mode & MODE_TRIAL) || st->solver_failed || st->pcg_timeout) return;
     const int tid = threadIdx.x;
@@ -3463,7 +3469,7 @@ template <class Src>
 __global__ __launch_bounds__(256) void k_decide(const Src src) {
     const DeviceGraph& g = graph_of(src);
     __shared__ double red[4];
-    decide_role(g, g.st, red, false);
+    decide_role(g, state_of(src, g), red, false);
 }
 
 // ================================================================= K10: per-edge chi2, outlier marking
@@ -3471,7 +3477,7 @@ __global__ __launch_bounds__(256) void k_decide(const Src src) {
 template <class Src, bool STG = true>
 __global__ __launch_bounds__(256) void k_eval(const Src src, const int mark, const int phase_just_done) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (st->status != 0) return;
     // the host may enqueue a phase end before it knows that the phase is over (one state read per solve): act only then
     if (phase_just_done >= 0 && (!st->done || st->ended != phase_just_done)) return;
@@ -3559,7 +3565,7 @@ template <class Src>
 __global__ __launch_bounds__(256) void k_phase_end(const Src src, const int phase_just_done, const int next_max_iter) {
     const DeviceGraph& g = graph_of(src);
     const int nparts = (g.No + 255) / 256 + 1;          // partials written by k_eval
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     if (st->status != 0) return;
     if (!st->done || st->ended != phase_just_done) return;      // (same gate as k_eval, which does not modify the state)
     __shared__ double red[4];
@@ -3584,7 +3590,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
     }
     for (int t = gid; t < g.No; t += stride) { g.obs_level[t] = 0; g.obs_outlier[t] = 0; g.obs_chi2_out[t] = 0.0; }
     if (gid == 0) {
-        LmState* st = g.st;
+        LmState* st = state_of(src, g);
         st->lambda = 0.0; st->ni = 2.0; st->current_chi = 0.0; st->temp_chi = 0.0; st->rho = 0.0; st->scale = 0.0; st->max_diag = 0.0;
         st->pcg_res_in = -1.0; st->pcg_residual = -1.0;
         st->chi2_initial = 0.0; st->chi2_phase1 = 0.0; st->chi2_final = 0.0;
@@ -3891,7 +3897,7 @@ __device__ __forceinline__ void sm_solve(const DeviceGraph& g, LmState* st, cons
 template <class Src>
 __global__ __launch_bounds__(512) void k_small_solve(const Src src, const int solver) {
     const DeviceGraph& g = graph_of(src);
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!(st->mode & MODE_TRIAL)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
@@ -4009,7 +4015,7 @@ template <class Src>
 __global__ __launch_bounds__(SM_T) void k_small_optimize(const Src src, const int solver, const int half) {
     const DeviceGraph& g = graph_of(src);
     const LinBuf L = lin_of(g, 0);            // one workgroup, stages in order: no second linearisation set needed
-    LmState* st = g.st;
+    LmState* st = state_of(src, g);
     __shared__ double sRt[SM_MAX_POSES * 12];              // R|t of the estimate
     __shared__ double sRtT[SM_MAX_POSES * 12];             // ... of the trial state
     __shared__ double sA[SM_MAX_N6 * SM_LD];               // dense reduced camera matrix / its Cholesky factor
@@ -4255,6 +4261,30 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.dogleg = a.dogleg & b.dogleg;                    // ... and one trust-region strategy
     return d;
 }
+// Launch geometry rounded up to SIZE CLASSES (steps of at most 12.5 %): a launch sequence captured for one window of a sliding map then
+// serves the next frames too — their windows differ by a few observations, and every kernel that reads its graph from HBM (Many) lets the
+// surplus workgroups of a grid sized for a larger window return at once (the batched launches rely on the same property).
+static inline int size_class(const int x) {
+    if (x <= 8) return x;
+    const int e = 31 - __builtin_clz((unsigned)x), step = 1 << (e - 3);
+    return (x + step - 1) / step * step;
+}
+LaunchDims dims_class(const LaunchDims& a) {
+    LaunchDims d = a;
+    d.np = a.np <= MAX_STAGED_POSES ? std::min(size_class(a.np), MAX_STAGED_POSES) : size_class(a.np);   // (a class never changes the staged / unstaged choice)
+    d.chunks = size_class(a.chunks); d.lin_blocks = std::max(size_class(a.lin_blocks), size_class(a.backsub_blocks - 1) + d.chunks);
+    d.backsub_blocks = size_class(a.backsub_blocks);
+    d.sch_wgs = (size_class(a.sch_wgs) + 7) / 8 * 8; d.run_wgs = (size_class(a.run_wgs) + 7) / 8 * 8; d.run_lds = a.run_lds;
+    d.fin_wgs = size_class(a.fin_wgs); d.pcg_rows = size_class(a.pcg_rows);
+    if (a.pcg_rows <= 64) d.pcg_rows = std::min(d.pcg_rows, 64);                   // (the k_pcg / k_pcg1 variant follows the row count)
+    else if (a.pcg_rows <= MAX_PCG_ONE_ROW_POSES) d.pcg_rows = std::min(d.pcg_rows, MAX_PCG_ONE_ROW_POSES);
+    d.pcg_lds = a.pcg_lds > 0 ? std::min(size_class(a.pcg_lds), 160 * 1024) : 0;
+    d.eval_blocks = size_class(a.eval_blocks); d.reset_blocks = size_class(a.reset_blocks);
+    d.band_lds = a.band_lds > 0 ? std::min((size_class(a.band_lds) + 15) / 16 * 16, (int)BAND_LDS_BUDGET) : 0;
+    return d;
+}
+bool dims_equal(const LaunchDims& a, const LaunchDims& b) { return std::memcmp(&a, &b, sizeof(LaunchDims)) == 0; }
+
 // dynamic LDS of the kernels that stage every pose of the window as R|t (12 doubles each); windows beyond MAX_STAGED_POSES use the
 // instantiations that read the poses from HBM instead (STG = false) and need only the reduction scratch
 static inline bool staged(const LaunchDims& d) { return d.np <= MAX_STAGED_POSES; }
@@ -4525,8 +4555,8 @@ static void launch_backsub_dogleg_many(const Many& src, const LaunchDims& d, int
         default: launch_backsub_dogleg_many_t<64>(src, d, B, pass, s); break;
     }
 }
-void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, bool spec_fused, hipStream_t s) {
-    const Many src{ gs };
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, bool spec_fused, hipStream_t s, LmState* st1) {
+    const Many src{ gs, st1 };
     // spec_fused (round 4): the members run the fused speculative unit of a window on its own — k_linearize only in the first unit of a
     // phase, the Schur gather with the pending pose-major role behind it, the back-substitution with the LM decision and the landmark-major
     // role of the trial's linearisation on board: 4 launches per unit instead of 6 (3 instead of 5 with k_small_solve)
@@ -4557,8 +4587,8 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
     launch_backsub_src(src, d, B, 0, fused_decide ? 1 : 0, s);
     if (!fused_decide) hipLaunchKernelGGL((k_decide<Many>), dim3(1, B), dim3(256), 0, s, src);
 }
-void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s) {
-    launch_phase_end_src(Many{ gs }, d, B, phase_just_done, mark, next_max_iter, s);
+void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s, LmState* st1) {
+    launch_phase_end_src(Many{ gs, st1 }, d, B, phase_just_done, mark, next_max_iter, s);
 }
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s) {
     hipLaunchKernelGGL((k_small_optimize<Many>), dim3(1, B), dim3(SM_T), 0, s, Many{ gs }, solver, half);

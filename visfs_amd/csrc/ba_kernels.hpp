@@ -48,8 +48,11 @@ bool small_path_fits(const DeviceGraph& g);                          // the wind
 void launch_small_optimize(const DeviceGraph& g, int solver, int half, hipStream_t s);   // both phases + outlier pass in one launch
 // batches of independent windows: gs = B DeviceGraphs in HBM, blockIdx.y = window
 void launch_reset_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int max_iter, int gauss_newton, int restore, hipStream_t s);
-void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, bool spec_fused, hipStream_t s);
-void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s);
+// st1 (B == 1 only): the window's LM state at a fixed address, handed to the kernels beside the graph pointer (see Many::st1)
+void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool first, bool small_solve, int solver, bool fused_decide, bool spec_fused, hipStream_t s, LmState* st1 = nullptr);
+void launch_phase_end_batch(const DeviceGraph* gs, int B, const LaunchDims& d, int phase_just_done, int mark, int next_max_iter, hipStream_t s, LmState* st1 = nullptr);
+LaunchDims dims_class(const LaunchDims& d);                           // launch geometry rounded up to size classes (per-frame launch sequences replayed across uploads)
+bool dims_equal(const LaunchDims& a, const LaunchDims& b);
 void launch_small_optimize_batch(const DeviceGraph* gs, int B, int solver, int half, hipStream_t s);
 void launch_gather_lm(const DeviceGraph* gs, int B, LmState* out, hipStream_t s);
 void launch_stage_arm(const DeviceGraph& g, double lambda, int mode, hipStream_t s);
