@@ -690,3 +690,30 @@ def test_per_frame_launch_sequence_is_replayed_across_uploads_and_changes_no_byt
         assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3], equal_nan=True) and a[4] == b[4] and a[5] == b[5]
     assert not any(r[6] for r in outs["0"])                  # the by-value path never replays a per-frame call
     assert sum(r[6] for r in outs["2"]) >= n_frames - 4      # two frames at most per class before the replays start (two classes show up)
+
+
+@pytest.mark.parametrize("case", ["K30", "C3S", "HARD"])
+def test_finalisation_on_board_the_pcg_launch_changes_no_byte(olib, monkeypatch, case):
+    """VERDICT r03 item 9 (closed by measurement, profiles/r04_fin_pcg_fusion_ab.log): k_schur_finalize as the prologue of the one-wave PCG
+    launch (VISFS_BA_FIN_PCG=1: write-through stores + drain + flag, sc1 reloads, unit-tagged hand-off words) performs the same arithmetic:
+    every output, counter and trace entry equals the two-launch form, rejected trials and odometry included — also across repeated solves
+    of one resident graph (the tags count the units of a call, k_reset zeroes the flags)."""
+    from helpers import hard_window
+    from test_gpu_parity import _stats_tuple
+    w = synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11) if case == "K30" else hard_window() if case == "HARD" else synth.make_window("C3", n_kf=20, n_lm=500, n_obs=4000)
+    kw = dict(iterations=20, solver=2)
+    _, rc0, st0, out0 = _solve_graph(monkeypatch, w, dict(VISFS_BA_FIN_PCG="0"), **kw)
+    _, rc1, st1, out1 = _solve_graph(monkeypatch, w, dict(VISFS_BA_FIN_PCG="1"), **kw)
+    assert rc0 == rc1 == abi.OK
+    assert _stats_tuple(st0) == _stats_tuple(st1)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out0, out1))
+    from visfs_amd import backend
+    prm = abi.default_params(**kw)
+    s = backend.Solver(prm)
+    gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s.upload(gb)
+    for _ in range(3):
+        s.reset(); rc, st = s.optimize()
+        assert rc == abi.OK and _stats_tuple(st) == _stats_tuple(st0)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(s.download(), out0))
+    s.close()

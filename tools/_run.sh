@@ -1,20 +1,22 @@
 set -o pipefail
-O=$PWD/gpurun_out; mkdir -p $O; export PYTHONPATH=$PWD TMPDIR=/tmp; ROOT=$PWD
-cd /tmp
-for M in 0 2; do
-  export VISFS_BA_FRAME_GRAPH=$M
-  for CFG in C2 PROD; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/r04_l_stats_${CFG}_m$M" -o f -- python3 "$ROOT/tools/frame_loop.py" $CFG 40 > "$O/r04_l_${CFG}_m$M.log" 2>/dev/null
-  done
-done
-cd $ROOT
-for M in 0 2; do for CFG in C2 PROD; do echo "== $CFG mode $M: $(cat $O/r04_l_${CFG}_m$M.log)"; python3 - $O/r04_l_stats_${CFG}_m$M/f_kernel_stats.csv <<'PY'
-import csv,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-print(f"   total kernel time {tot/1e3/43:.1f} us per call")
-for r in rows[:9]:
-    n=r['Name'].replace('visfs_ba::','').replace('void ','')
-    print(f"  {int(r['Calls']):5d} {float(r['AverageNs'])/1e3:8.2f} us  {float(r['Percentage']):5.1f}%  {n[:100]}")
-PY
-done; done
+O=gpurun_out; mkdir -p $O; export PYTHONPATH=$PWD
+timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "optimize_parity or stage_parity or repeated or batch or fused_spec or decision or timed" > $O/r04_n_tests.log 2>&1; echo "tests rc=$?" >> $O/r04_n_tests.log
+tail -6 $O/r04_n_tests.log
+grep -q "rc=0" $O/r04_n_tests.log || exit 1
+rm -f $O/r04_n_ab.log
+run_set() {
+  timeout -k 10 200 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --config5 off >> $O/r04_n_ab.log 2>&1
+  timeout -k 10 200 python bench.py --config C3 --steps 40 --warmup 5 --no-cpu-baseline --config5 off >> $O/r04_n_ab.log 2>&1
+  timeout -k 10 200 python bench.py --config C5 --windows-per-gpu 8 --steps 10 --warmup 2 --no-cpu-baseline --config5 off >> $O/r04_n_ab.log 2>&1
+  timeout -k 10 200 python bench.py --config C5 --windows-per-gpu 16 --steps 10 --warmup 2 --no-cpu-baseline --config5 off >> $O/r04_n_ab.log 2>&1
+}
+echo "== fused finalize + pcg1 (default)" >> $O/r04_n_ab.log; run_set
+echo "== VISFS_BA_FIN_PCG=0" >> $O/r04_n_ab.log; VISFS_BA_FIN_PCG=0 run_set
+echo "== fused again" >> $O/r04_n_ab.log; run_set
+grep -h '"value"\|^==' $O/r04_n_ab.log | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('=='): print(ln.strip()); continue
+    d = json.loads(ln); r = d.get('roofline') or {}
+    print(' ', d['config']['workload'][:4], d['config']['windows_per_gpu'], 'value', d['value'], 'per_frame', (d.get('per_frame_call') or {}).get('ms_per_call'), 'dom', r.get('kernel'), r.get('avg_launch_us'), {k: round(v) for k, v in d['kernel_us_per_step_calibration'].items()})
+"

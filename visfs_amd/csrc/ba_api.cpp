@@ -855,6 +855,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.dxl = A.take<double>((size_t)std::max(Nl, 1) * 3);
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.trial_gran = A.take<unsigned long long>((size_t)n_parts * 4);
+        g.fin_flag = A.take<uint32_t>((size_t)std::max(n_blk, 1));
         g.aux_part = A.take<double>((size_t)n_parts);
         g.dl_part = A.take<double>(ceres && prm.trust_region == 1 ? (size_t)n_parts * 4 : 1);
         g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
@@ -931,6 +932,12 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     dg.Np = Np; dg.Nl = Nl; dg.No = No; dg.Ne = Ne; dg.Npf = Npf;
     dg.n_pose_obs = n_pose_obs;
     dg.n_chunks = n_chunks; dg.n_blk = n_blk; dg.n_lin_a = n_lin_a; dg.group = group; dg.n_edges_ok = n_edges_ok;
+    // The finalisation of S as the prologue of the one-wave PCG launch (k_pcg1<FIN>; VERDICT r03 item 9's "drop the k_schur_finalize launch").
+    // MEASURED (profiles/r04_fin_pcg_fusion_ab.log): bit-identical, and no faster — the fused launch takes 27.0 us where the two launches take
+    // 5.65 + 20.9 (the in-launch hand-off, a drain + flag + sc1 reload, costs what the kernel boundary cost; the finalising waves run at
+    // k_pcg1's one wave per SIMD); C2 19.8-20.0 k against 20.2 k it/s, 16 resident windows 65 k against 80 k.  Opt-in: VISFS_BA_FIN_PCG=1.
+    { const char* e = std::getenv("VISFS_BA_FIN_PCG"); const char* gv = std::getenv("VISFS_BA_PCG_GATHER");
+      dg.fin_pcg = (pcg1 && !pcg_cu && !small_solve_fits_npf && (e && e[0] == '1') && !(gv && std::atoi(gv) != 1)) ? 1 : 0; }
     dg.n_runs = rp.n; dg.run_lr = rp.LR; dg.run_m = rp.M; dg.run_cap = rp.cap; dg.run_wmax = rp.wmax; dg.run_lds_bytes = (int32_t)rp.lds;
     dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
@@ -1053,7 +1060,8 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     { ProfScope p(w, VISFS_BA_K_SCHUR, true); if (w.spec_fused && !first) launch_schur_partial_roleb(w.g, w.stream); else launch_schur_partial(w.g, w.stream); }
     if (w.small_solve) { ProfScope p(w, solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, solver, w.stream); }
     else {
-        { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
+        const bool fin_on_board = solver == 2 && w.g.fin_pcg && w.g.pcg1_code != nullptr && !w.g.pcg_cu;       // k_pcg1<FIN>: the finalisation rides on the PCG launch
+        if (!fin_on_board) { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
         if (solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }
@@ -2352,7 +2360,7 @@ int visfs_ba_stage_trial(visfs_ba_handle* h, double lambda, double* trial_chi2, 
     launch_schur_partial(w.g, w.stream);
     if (w.small_solve) launch_small_solve(w.g, h->prm.solver, w.stream);
     else {
-        launch_schur_finalize(w.g, w.stream);
+        if (!(h->prm.solver == 2 && w.g.fin_pcg && w.g.pcg1_code != nullptr && !w.g.pcg_cu)) launch_schur_finalize(w.g, w.stream);     // (else: on board the PCG launch)
         if (h->prm.solver == 2) launch_pcg(w.g, w.stream); else launch_direct(w.g, w.stream);
     }
     launch_backsub(w.g, w.stream);

@@ -226,6 +226,9 @@ struct DeviceGraph {
     double* x;                  // [Npf][6]   pose increment
     double* sch_part;           // [n_sch][42] per-chunk partial sums (36 block entries + 6 of b_s)
     unsigned long long* granules; // [2][2*6Npf] {epoch:32 | half of a double:32} hand-off words of the persistent PCG
+    uint32_t* fin_flag;         // [n_blk] fused finalisation + PCG launch (k_pcg1<FIN>): block b's S / b_s / Minv are complete when this holds the
+                                //   unit's tag (damped solves of this optimise call so far + 1); zeroed by k_reset
+    int32_t fin_pcg;            // 1: k_schur_finalize rides as the prologue of the k_pcg1 launch (one launch less per damped solve)
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
     // Optimizer/Framework=1: Jacobi scaling squared, fixed at iteration zero (k_ceres_lin_finalize): the damping of variable i is

@@ -1705,8 +1705,17 @@ __device__ __forceinline__ double run_partial_sum(const DeviceGraph& g, const in
     return part;
 }
 
-__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be, const double part_in = 0.0) {
-    {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass.
+// PUB (the finalisation as the prologue of the k_pcg1 launch, round 4): what the PCG waves of the SAME launch read — S, b_s, Minv — is
+// stored write-through (agent-scope relaxed atomic stores: sc1), the wave drains its stores and lane 0 publishes the unit's tag in
+// fin_flag[b] (cdna_hip_programming.md §6 Guideline 16, recipe R1); the granules are NOT zeroed here (the PCG waves may already be
+// publishing: k_reset zeroes them once per optimise call and the hand-off tags carry the unit).
+__device__ __forceinline__ void st_pub(double* p, const double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool PUB = false>
+__device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be, const double part_in = 0.0,
+                                            const unsigned pub_tag = 0u) {
+    if (!PUB) {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass.
         // CONTRACT with the persistent PCG (k_pcg / k_pcg1) that follows: (1) EVERY block's wave runs this loop — the words are dealt
         // over all n_blk waves (stride n_blk * 64), so a kernel that calls schur_block for a subset of the blocks clears only a
         // subset of the words; (2) the PCG relies on it: a hand-off tag is just the iteration number, so a word that keeps the
@@ -1738,7 +1747,11 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
                 const int code = g.blk_odo[n];
                 base += L.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
             }
-            g.S[36 * (size_t)b + lane] = base - part;
+            if (PUB) st_pub(g.S + 36 * (size_t)b + lane, base - part); else g.S[36 * (size_t)b + lane] = base - part;
+        }
+        if (PUB) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(g.fin_flag + b, pub_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -1749,24 +1762,29 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     double val = 0.0;
     if (lane < 36) {
         val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? damp_of(g, lambda, hv, g.s2p, 6 * (size_t)i + r) : 0.0) - part);
-        g.S[36 * (size_t)b + lane] = val;
+        if (PUB) st_pub(g.S + 36 * (size_t)b + lane, val); else g.S[36 * (size_t)b + lane] = val;
         g.Hpp[36 * (size_t)i + lane] = hv;
     } else if (lane < 42) {
         g.bp[6 * (size_t)i + (lane - 36)] = hv;
-        g.bs[6 * (size_t)i + (lane - 36)] = pin ? 0.0 : (hv - part);
+        const double bsv = pin ? 0.0 : (hv - part);
+        if (PUB) st_pub(g.bs + 6 * (size_t)i + (lane - 36), bsv); else g.bs[6 * (size_t)i + (lane - 36)] = bsv;
     }
     const double v = gauss_jordan_6x6(val, lane);
-    if (lane < 36) g.Minv[36 * (size_t)i + lane] = v;
+    if (lane < 36) { if (PUB) st_pub(g.Minv + 36 * (size_t)i + lane, v); else g.Minv[36 * (size_t)i + lane] = v; }
     if (b == 0 && lane == 0) {
         st->pcg_res_in = st->pcg_residual;
         st->n_active[1] += 1;
         if (st->mode & MODE_LIN) st->n_active[0] += 1;
     }
+    if (PUB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(g.fin_flag + b, pub_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
     // (the fused small-window kernel: pair-list gather only)
-    schur_block(g, L, st, b, lane, g.blk_desc[2 * b], g.blk_desc[2 * b + 1]);     // (first chunk, last + 1, first odometry entry, last + 1), (i, j, first pose-major chunk of i, last + 1)
+    schur_block<false>(g, L, st, b, lane, g.blk_desc[2 * b], g.blk_desc[2 * b + 1]);     // (first chunk, last + 1, first odometry entry, last + 1), (i, j, first pose-major chunk of i, last + 1)
 }
 
 // RUNS (the Schur complement came from k_schur_runs): one WORKGROUP per stored block — a block collects one partial per run whose span
@@ -1789,8 +1807,8 @@ __global__ __launch_bounds__(256) void k_schur_finalize(const Src src) {
         __syncthreads();
         if (wave != 0) return;
         const double part = lane < 42 ? ((sp[lane] + sp[42 + lane]) + sp[84 + lane]) + sp[126 + lane] : 0.0;
-        schur_block(g, L, st, b, lane, bd, be, part);
-    } else schur_block(g, L, st, b, lane, bd, be);
+        schur_block<false>(g, L, st, b, lane, bd, be, part);
+    } else schur_block<false>(g, L, st, b, lane, bd, be);
 }
 
 // ================================================================= K6: block-Jacobi PCG on S, persistent
@@ -2148,15 +2166,33 @@ struct ReduceScatterUp<N, 64> {
 // hardware — do the later iterations publish with PLAIN stores (kept in that XCD's L2, the coherence point of its CUs) and keep
 // reading with sc1 loads (past the L1, served by that L2): an L2 round trip instead of a fabric one per hand-off.  Otherwise they
 // stay on the write-through path.  Both paths move the same bits; the choice is identical in every wave (same gathered words).
-template <class Src, int GV>
+// FIN (round 4): the launch also carries the finalisation of the reduced system — k_schur_finalize as a prologue: workgroup (= wave) b of
+// n_blk first finalises stored block b (schur_block<PUB>: write-through stores, drain, flag), the first Npf of them then go on as the PCG
+// rows; lane a of row i0 waits for the flags of the two blocks it reads — S(i0, a) and the diagonal block of pose a (Minv_a, b_s a) — and
+// fetches them with sc1 loads (Guideline 16 R1: every load of handed-off bytes is sc1).  One launch and one kernel boundary less per
+// damped solve.  Finalise-only waves never wait, row waves wait for finalise waves (dispatched right behind them) and for each other as
+// before: the co-residency requirement is still "the Npf row waves of a window".  The q hand-off tags carry the unit (tag =
+// unit << 10 | iteration + 1) because nobody zeroes the granules between the units of one optimise call any more (k_reset does, once).
+template <class Src, int GV, bool FIN = false>
 __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
+    static_assert(!FIN || GV == 1, "the fused finalisation rides on the default gather variant");
     const DeviceGraph& g = graph_of(src);
     LmState* st = state_of(src, g);
     if (GV == 3 && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
+    const int lane = threadIdx.x;
+    unsigned unit_tag = 0u;
+    if (FIN) {
+        const int b = (int)blockIdx.x;
+        if (b >= g.n_blk) return;                     // a batched launch is sized for the largest window
+        const int4 bd = g.blk_desc[2 * b], be = g.blk_desc[2 * b + 1];
+        if (!(st->mode & MODE_TRIAL)) return;
+        unit_tag = (unsigned)(st->trials_run[0] + st->trials_run[1]) + 1u;
+        const LinSel<Src> lsel(g, st->lin_sel);
+        schur_block<true>(g, lsel.get(), st, b, lane, bd, be, 0.0, unit_tag);
+    }
     if (!(st->mode & MODE_TRIAL)) return;
     const int i0 = GV == 3 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (i0 >= g.Npf) return;                          // a batched launch is sized for the largest window
-    const int lane = threadIdx.x;
     const int Npf = g.Npf, n6 = 6 * Npf;
     const bool own = lane < Npf;
 #ifdef VISFS_BA_STAMPS
@@ -2167,8 +2203,49 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
 #endif
     // ---- set-up: S(i0, lane), Minv_lane, r = b_s; every load below is independent of the others
     const int code = own ? g.pcg1_code[i0 * Npf + lane] : -1;
+    const unsigned spin_limit = g.fault_pcg ? (1u << 10) : (1u << 22);
+    bool timeout = false;
     double Sr[36], mm[36], rr[6], dd[6], xx[6];
-    {
+    if (FIN) {
+        // wait for the two blocks this lane reads (finalised by other waves of this launch), then fetch them past the L1 (sc1)
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        const int dcode = own ? g.pcg1_code[lane * Npf + lane] : -1;          // the diagonal block of pose `lane`
+        const uint32_t* f1 = g.fin_flag + (code >= 0 ? (code >> 1) : 0);
+        const uint32_t* f2 = g.fin_flag + (dcode >= 0 ? (dcode >> 1) : 0);
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned a1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = (code < 0 || a1 == unit_tag) && (dcode < 0 || a2 == unit_tag);
+            if (__all(ok)) break;
+            if (spins > spin_limit) { timeout = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (timeout) { if (lane == 0) st->pcg_timeout = 1; return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");              // (no instruction: keeps the loads below behind the poll)
+        const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)g.S, 0, (int)(g.n_blk * 288), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc((void*)g.Minv, 0, (int)(Npf * 288), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)g.bs, 0, (int)(Npf * 48), 0x00020000);
+        const int oS = 288 * (code >= 0 ? (code >> 1) : 0), oM = 288 * (own ? lane : 0), oB = 48 * (own ? lane : 0);
+        v4u_t vs[18], vm[18], vb[3];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) { vs[q] = __builtin_amdgcn_raw_buffer_load_b128(rS, oS + 16 * q, 0, 16); vm[q] = __builtin_amdgcn_raw_buffer_load_b128(rM, oM + 16 * q, 0, 16); }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, oB + 16 * q, 0, 16);
+        double sv[36];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            sv[2 * q] = code >= 0 ? __hiloint2double((int)vs[q].y, (int)vs[q].x) : 0.0; sv[2 * q + 1] = code >= 0 ? __hiloint2double((int)vs[q].w, (int)vs[q].z) : 0.0;
+            mm[2 * q] = own ? __hiloint2double((int)vm[q].y, (int)vm[q].x) : 0.0; mm[2 * q + 1] = own ? __hiloint2double((int)vm[q].w, (int)vm[q].z) : 0.0;
+        }
+        const bool tr = (code & 1) != 0;              // the stored block is (lane, i0): use its transpose
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Sr[6 * r + c] = tr ? sv[6 * c + r] : sv[6 * r + c];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { rr[2 * q] = own ? __hiloint2double((int)vb[q].y, (int)vb[q].x) : 0.0; rr[2 * q + 1] = own ? __hiloint2double((int)vb[q].w, (int)vb[q].z) : 0.0; }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xx[c] = 0.0;
+    } else {
         const double2* Sb = reinterpret_cast<const double2*>(g.S + 36 * (size_t)(code >= 0 ? (code >> 1) : 0));
         const double2* Mb = reinterpret_cast<const double2*>(g.Minv + 36 * (size_t)(own ? lane : 0));
         double sv[36];
@@ -2199,12 +2276,12 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
     double dn = wave_sum(part);
     double d0 = 1e-6 * dn;
     {
-        const double res_in = st->pcg_res_in;
+        // (FIN: block 0's wave copies pcg_residual to pcg_res_in in this very launch — read the source, which nobody writes before every
+        // row has left its loop)
+        const double res_in = FIN ? st->pcg_residual : st->pcg_res_in;
         if (res_in > 0.0 && res_in > d0) d0 = res_in;
     }
     int iter = 0;
-    bool timeout = false;
-    const unsigned spin_limit = g.fault_pcg ? (1u << 10) : (1u << 22);
     bool xcd_local = false;                            // GV == 3: every row of this window runs on one XCD (decided after iteration 0)
     PCG1_STAMP(0);
     while (true) {
@@ -2220,7 +2297,7 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
         }
         int off = 0, len = 6;
         ReduceScatterUp<6, 1>::run(y, lane, off, len);
-        const unsigned epoch = (unsigned)iter + 1u;
+        const unsigned epoch = (FIN ? (unit_tag << 10) : 0u) + (unsigned)iter + 1u;
         unsigned long long* gr = g.granules + (size_t)(iter & 1) * (2 * n6);
         PCG1_STAMP(1 + 4 * iter);
         if (len >= 1 && !(g.fault_pcg && i0 == 0 && iter == 0)) {
@@ -3589,6 +3666,11 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         for (int t = gid; t < g.Nl * 3; t += stride) { const double v = g.pt0[t]; g.pt[0][t] = v; g.pt[1][t] = v; }
     }
     for (int t = gid; t < g.No; t += stride) { g.obs_level[t] = 0; g.obs_outlier[t] = 0; g.obs_chi2_out[t] = 0.0; }
+    if (g.fin_pcg) {
+        // the fused finalisation + PCG launch: its flags and hand-off words start every optimise call at zero (tags count the call's units)
+        for (int t = gid; t < g.n_blk; t += stride) g.fin_flag[t] = 0u;
+        for (int t = gid; t < 4 * 6 * g.Npf + g.Npf; t += stride) g.granules[t] = 0ull;
+    }
     if (gid == 0) {
         LmState* st = state_of(src, g);
         st->lambda = 0.0; st->ni = 2.0; st->current_chi = 0.0; st->temp_chi = 0.0; st->rho = 0.0; st->scale = 0.0; st->max_diag = 0.0;
@@ -4240,6 +4322,8 @@ LaunchDims dims_of(const DeviceGraph& g) {
     d.reset_blocks = std::min(std::max((g.No + 255) / 256, 1), 1024);
     d.has_odo = (g.Ne > 0 || g.Nz > 0) ? 1 : 0;
     d.pcg_one_wave = g.pcg1_code != nullptr ? 1 : 0;
+    d.fin_pcg = (g.fin_pcg && g.pcg1_code != nullptr) ? 1 : 0;
+    d.fin_pcg_wgs = g.n_blk;
     d.pcg_cu = g.pcg_cu;
     d.band = g.band_B >= 0 ? 1 : 0;                    // direct solver: every window of a launch on the banded factorisation (k_band_chol)
     d.band_lds = g.band_B >= 0 ? g.band_lds_bytes : 0;
@@ -4255,6 +4339,7 @@ LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b) {
     d.pcg_lds = std::max(a.pcg_lds, b.pcg_lds); d.eval_blocks = std::max(a.eval_blocks, b.eval_blocks); d.reset_blocks = std::max(a.reset_blocks, b.reset_blocks);
     d.has_odo = a.has_odo | b.has_odo; d.sch_multi = a.sch_multi | b.sch_multi;
     d.pcg_one_wave = a.pcg_one_wave & b.pcg_one_wave;
+    d.fin_pcg = a.fin_pcg & b.fin_pcg; d.fin_pcg_wgs = std::max(a.fin_pcg_wgs, b.fin_pcg_wgs);
     d.pcg_cu = a.pcg_cu & b.pcg_cu;
     d.band = a.band & b.band; d.band_lds = std::max(a.band_lds, b.band_lds);
     d.ceres = a.ceres & b.ceres;                       // (a handle has one framework: all windows of a launch agree)
@@ -4275,7 +4360,7 @@ LaunchDims dims_class(const LaunchDims& a) {
     d.chunks = size_class(a.chunks); d.lin_blocks = std::max(size_class(a.lin_blocks), size_class(a.backsub_blocks - 1) + d.chunks);
     d.backsub_blocks = size_class(a.backsub_blocks);
     d.sch_wgs = (size_class(a.sch_wgs) + 7) / 8 * 8; d.run_wgs = (size_class(a.run_wgs) + 7) / 8 * 8; d.run_lds = a.run_lds;
-    d.fin_wgs = size_class(a.fin_wgs); d.pcg_rows = size_class(a.pcg_rows);
+    d.fin_wgs = size_class(a.fin_wgs); d.pcg_rows = size_class(a.pcg_rows); d.fin_pcg_wgs = size_class(a.fin_pcg_wgs);
     if (a.pcg_rows <= 64) d.pcg_rows = std::min(d.pcg_rows, 64);                   // (the k_pcg / k_pcg1 variant follows the row count)
     else if (a.pcg_rows <= MAX_PCG_ONE_ROW_POSES) d.pcg_rows = std::min(d.pcg_rows, MAX_PCG_ONE_ROW_POSES);
     d.pcg_lds = a.pcg_lds > 0 ? std::min(size_class(a.pcg_lds), 160 * 1024) : 0;
@@ -4379,6 +4464,7 @@ static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream
         // them all onto one XCD (that is the intent); a batch on one XCD would not be (co-residency must not depend on placement)
         if (gv == 3 && !Src::batched) TIMED_LAUNCH((k_pcg1<One, 3>), dim3(8 * d.pcg_rows, B), dim3(64), 0, s, One{ graph_of_host(src) });
         else if (gv >= 2) TIMED_LAUNCH((k_pcg1<Src, 2>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
+        else if (gv == 1 && d.fin_pcg) TIMED_LAUNCH((k_pcg1<Src, 1, true>), dim3(d.fin_pcg_wgs, B), dim3(64), 0, s, src);     // finalisation on board
         else if (gv == 1) TIMED_LAUNCH((k_pcg1<Src, 1>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
         else TIMED_LAUNCH((k_pcg1<Src, 0>), dim3(d.pcg_rows, B), dim3(64), 0, s, src);
     }
@@ -4573,7 +4659,7 @@ void launch_unit_batch(const DeviceGraph* gs, int B, const LaunchDims& d, bool f
         ensure_lds(k_band_chol<Many>, (size_t)d.band_lds);
         hipLaunchKernelGGL((k_band_chol<Many>), dim3(1, B), dim3(BAND_T), (size_t)d.band_lds, s, src);
     }
-    else { launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
+    else { if (!(d.fin_pcg && d.pcg_one_wave && !d.pcg_cu)) launch_schur_finalize_src(src, d, B, s); launch_pcg_src(src, d, B, s); }
     if (d.dogleg) {
         // Optimizer/Framework=1 with the DOGLEG strategy: the two back-substitution passes around the point on the dogleg path, then the decision
         launch_backsub_dogleg_many(src, d, B, 1, s);

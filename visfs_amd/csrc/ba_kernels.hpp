@@ -9,7 +9,7 @@
 namespace visfs_ba {
 
 // Launch geometry of one window, or the element-wise maximum over a batch of windows (same lanes-per-landmark group).
-struct LaunchDims { int group, np, chunks, lin_blocks, backsub_blocks, run_wgs, run_lds, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave, pcg_cu, band, band_lds, ceres, dogleg; };
+struct LaunchDims { int group, np, chunks, lin_blocks, backsub_blocks, run_wgs, run_lds, sch_wgs, sch_multi, fin_wgs, pcg_rows, pcg_lds, eval_blocks, reset_blocks, has_odo, pcg_one_wave, pcg_cu, band, band_lds, ceres, dogleg, fin_pcg, fin_pcg_wgs; };
 LaunchDims dims_of(const DeviceGraph& g);
 LaunchDims dims_max(const LaunchDims& a, const LaunchDims& b);
 
