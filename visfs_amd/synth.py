@@ -29,6 +29,9 @@ CONFIGS = {
     "C5": dict(n_kf=50, n_lm=5000, n_obs=50000, odo=False, index=4),  # per window; 64 windows in the batch
     # production-sized window (Parameters.h:161,148: 6 signatures, <=300 features)
     "PROD": dict(n_kf=6, n_lm=300, n_obs=1500, odo=True, index=5),
+    # wide band (measurement only): tracks of 30 key-frames give the reduced camera matrix a block half-bandwidth of 29 — beyond what the
+    # banded factorisation holds in LDS, so Optimizer/Solver=0 takes the dense blocked Cholesky, the one place with an MFMA (fp64 SYRK)
+    "WB": dict(n_kf=60, n_lm=1200, n_obs=36000, odo=False, index=6),
 }
 BASE_SEED = 20261003
 
