@@ -17,7 +17,9 @@ for CFG in sys.argv[1:] or ["C2"]:
     st = out.view(np.uint64).astype(np.int64)
     ns = lambda a, b: int(st[a] - st[b]) * 10
     print(f"{CFG}: free poses {s.describe()['n_free_poses']}  load {ns(1, 0)} ns | factor loop {ns(110, 1)} | backward {ns(111, 110)} | epilogue {ns(112, 111)} | total {ns(112, 0)}")
+    # round 4 layout of the stamps of step k (< 16): [2 + 6k] thread 0 after the barrier of half 1, [3 + 6k] wave 0 after the next pivot's inverse,
+    # [5 + 6k] first helper thread after its trailing-update tasks, [4 + 6k] thread 0 after the barrier of half 2
     for k in range(1, 16, 2):
-        prev = 1 if k == 0 else 5 + 6 * (k - 1)
-        print(f"   step {k:2d}: A diag {ns(2 + 6 * k, prev):5d} rest {ns(3 + 6 * k, prev):5d} -> barrier {ns(4 + 6 * k, prev):5d} | B trsm+barrier {ns(5 + 6 * k, 4 + 6 * k):5d} | step {ns(5 + 6 * k, prev)}")
+        prev = 4 + 6 * (k - 1)
+        print(f"   step {k:2d}: half 1 (scale rows + barrier) {ns(2 + 6 * k, prev):5d} | half 2: wave 0 inverse {ns(3 + 6 * k, 2 + 6 * k):5d}, helpers' updates {ns(5 + 6 * k, 2 + 6 * k):5d}, to the barrier {ns(4 + 6 * k, 2 + 6 * k):5d} | step {ns(4 + 6 * k, prev)}")
     s.close()

@@ -2878,8 +2878,8 @@ constexpr int BAND_T = 256;
 constexpr int BAND_MAX_W = 22;                                  // (B + 1) <= 22: a (B + 2)-row ring of 6x6 blocks fits the LDS budget
 size_t band_lds_bytes(const int npf, const int B, const int rows) {
     const size_t W = (size_t)B + 1;
-    // ring + two unscaled columns + right-hand side + two D^-1 + G_{k+1,k} + flags, then the table of stored block ids and the pair table
-    return ((size_t)rows * W * 36 + 2 * W * 36 + 6 * (size_t)npf + 2 * 36 + 36 + 8) * sizeof(double) + ((size_t)npf * W * 4 + 15) / 16 * 16 + (((size_t)B * (B + 1)) + 15) / 16 * 16;
+    // ring + two column buffers (L of the current / previous column) + right-hand side + three pivot inverses + flags, then the table of stored block ids and the (m, j) table
+    return ((size_t)rows * W * 36 + 2 * W * 36 + 6 * (size_t)npf + 3 * 36 + 8) * sizeof(double) + ((size_t)npf * W * 4 + 15) / 16 * 16 + (((size_t)(B + 1) * (B + 2)) + 15) / 16 * 16;
 }
 // The plan for a reduced system of npf block rows with block half-bandwidth B: how many block rows stay in LDS (all of them when the
 // band fits), or false when even a (B + 2)-row window does not fit (wide bands: the dense blocked Cholesky takes those).
@@ -2983,13 +2983,12 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     const bool resident = RR >= Npf;
     const int rowsz = W * 36;
     double* ring = band_lds;                                   // [RR][W][36]
-    double* gk = ring + (size_t)RR * rowsz;                    // [2][W][36] the unscaled blocks G_ik of column k in half k & 1 (slot m = i - k)
-    double* cvec = gk + 2 * rowsz;                             // [6 Npf] right-hand side -> L^-1 b -> D^-1 L^-1 b -> x
-    double* dinv = cvec + 6 * Npf;                             // [2][36] X_k = C_k^-1 (D_k = C_k C_k^T) of the current / previous step
-    double* g1buf = dinv + 72;                                 // [36] G_{k+1,k}, read by every thread of step B while its slot is being overwritten
-    int* sflag = reinterpret_cast<int*>(g1buf + 36);           // (8 doubles reserved)
-    int* scode = reinterpret_cast<int*>(g1buf + 36 + 8);       // [Npf][W] stored block ids (DeviceGraph::band_code)
-    unsigned char* pij = reinterpret_cast<unsigned char*>(scode) + ((size_t)Npf * W * 4 + 15) / 16 * 16;   // [(B - 1) B / 2][2] (i, j), 2 <= j <= i <= B
+    double* lk = ring + (size_t)RR * rowsz;                    // [2][W][36] L_ik of column k in half k & 1 (slot m = i - k): the ring keeps the unscaled G_ik during step k
+    double* cvec = lk + 2 * rowsz;                             // [6 Npf] right-hand side -> L^-1 b -> D^-1 L^-1 b -> x
+    double* dinv = cvec + 6 * Npf;                             // [3][36] X_k = C_k^-1 (D_k = C_k C_k^T) at [k % 3]: step k reads X_k and X_{k-1} while X_{k+1} is written
+    int* sflag = reinterpret_cast<int*>(dinv + 108);           // (8 doubles reserved)
+    int* scode = reinterpret_cast<int*>(dinv + 108 + 8);       // [Npf][W] stored block ids (DeviceGraph::band_code)
+    unsigned char* pij = reinterpret_cast<unsigned char*>(scode) + ((size_t)Npf * W * 4 + 15) / 16 * 16;   // [B (B + 1) / 2 - 3][2] (m, j), 3 <= m <= B, 1 <= j <= m, by rows
     // ---- the first RR block rows of S: the lower block (I, I - d) is the transpose of the stored upper block (I - d, I).  The block
     // ids go to LDS first, so that the element loads below are independent of each other and many are in flight per thread.
     // (measured and dropped: letting the rows of a RESIDENT band enter progressively through the streaming path — the 7 us up-front
@@ -2998,9 +2997,9 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     for (int t = tid; t < Npf * W; t += BAND_T) scode[t] = g.band_code[t];
     for (int t = tid; t < 6 * Npf; t += BAND_T) cvec[t] = g.bs[t];
     if (tid == 0) sflag[0] = 0;
-    for (int p = tid; p < (B - 1) * B / 2; p += BAND_T) {
-        int i = 2; while ((i - 1) * i / 2 <= p) ++i;           // p = (i - 1) (i - 2) / 2 + (j - 2)
-        pij[2 * p] = (unsigned char)i; pij[2 * p + 1] = (unsigned char)(p - (i - 1) * (i - 2) / 2 + 2);
+    for (int p = tid; p < B * (B + 1) / 2 - 3; p += BAND_T) {
+        int m = 3; while (m * (m + 1) / 2 - 3 <= p) ++m;       // rows 3 .. m - 1 hold (m - 1) m / 2 - 3 entries
+        pij[2 * p] = (unsigned char)m; pij[2 * p + 1] = (unsigned char)(p - ((m - 1) * m / 2 - 3) + 1);
     }
     __syncthreads();
     {
@@ -3029,9 +3028,10 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     BAND_STAMP(1);
     // ring row of block row k + i (0 <= i <= B) when block row k sits in ring row kk
     auto ring_row = [&](const int kk, const int i) -> double* { int r = kk + i; r -= (r >= RR) ? RR : 0; return ring + (size_t)r * rowsz; };
-    // forward-substitution step s on one wavefront: c_i -= L_is c_s for the blocks below, then c_s <- D_s^-1 c_s
-    auto fwd_step = [&](const int s_, const int ks) {
-        const double* Di = dinv + 36 * (s_ & 1);
+    // forward-substitution step s on one wavefront: c_i -= L_is c_s for the blocks below (L_.s still sits in its column buffer), then c_s <- D_s^-1 c_s
+    auto fwd_step = [&](const int s_) {
+        const double* Di = dinv + 36 * (s_ % 3);
+        const double* Ls = lk + (size_t)(s_ & 1) * rowsz;
         double cs[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) cs[c] = cvec[6 * s_ + c];
@@ -3040,7 +3040,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
         if (lane < 6) { double zz[1]; band_apply_dinv<1>(Di, cs, lane, zz); z = zz[0]; }
         for (int e = lane; e < 6 * nb; e += 64) {
             const int m = e / 6 + 1, rr = e - 6 * (m - 1);
-            const double* L = ring_row(ks, m) + 36 * m + 6 * rr;
+            const double* L = Ls + 36 * m + 6 * rr;
             double acc = cvec[6 * (s_ + m) + rr];
 #pragma unroll
             for (int c = 0; c < 6; ++c) acc -= L[c] * cs[c];
@@ -3048,135 +3048,152 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
         }
         if (lane < 6) cvec[6 * s_ + lane] = z;
     };
-    // the part of the trailing update of column s that does not touch the next column: A_ij -= L_is G_js^T for 2 <= j <= i <= nb(s), on
-    // 3x3 tiles, by the threads of waves 1..3 (it runs beside the inverse of the NEXT diagonal block, which needs column s + 1 only)
-    auto syrk_rest = [&](const int s_, const int ks) {
-        const int nb = min(B, Npf - 1 - s_);
-        const int P = (nb - 1) * nb / 2;
-        const double* G = gk + (size_t)(s_ & 1) * rowsz;
-        for (int t = tid - 64; t < 4 * P; t += BAND_T - 64) {
-            const int p = t >> 2, ta = (t >> 1) & 1, tb = t & 1;
-            const int i = pij[2 * p], j = pij[2 * p + 1];
-            if ((i == j) & (tb > ta)) continue;                // a diagonal block: its upper 3x3 tile is never read
-            double* rowi = ring_row(ks, i);
-            const double* Li = rowi + 36 * i + 18 * ta;        // rows 3 ta .. of L_is
-            const double* Gj = G + 36 * j + 18 * tb;           // rows 3 tb .. of G_js
-            double* C = rowi + 36 * (i - j) + 18 * ta + 3 * tb;
-            double li[18], gj[18];
+    // Row rr of L_{k+m,k} = G_{k+m,k} D_k^-1, columns 3 hf .. (one of twelve lanes a block row); the whole row comes back in l[] (the partner
+    // lane t ^ 1 holds the other three columns).  store: the row goes to the column buffer (the ring keeps G until the next step: the
+    // updates read it) and, in the streaming form, to HBM.
+    auto scale_row = [&](const int k, const int kk, const int m, const int rr, const int hf, const double* __restrict__ X, double* __restrict__ Lcol, const bool store, double l[6]) {
+        const double* row = ring_row(kk, m) + 36 * m + 6 * rr;             // row rr of G_{k+m,k}
+        double a[6];
 #pragma unroll
-            for (int q = 0; q < 18; ++q) { li[q] = Li[q]; gj[q] = Gj[q]; }
+        for (int c = 0; c < 6; ++c) a[c] = row[c];
+        double o[3];
+        band_apply_dinv<3>(X, a, 3 * hf, o);
+        if (store) {
+            double* lo = Lcol + 36 * m + 6 * rr + 3 * hf;
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
+            for (int c = 0; c < 3; ++c) lo[c] = o[c];
+            if (!resident) {
+                double* h = g.band_L + (size_t)(k + m) * rowsz + 36 * m + 6 * rr + 3 * hf;
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    double acc = C[6 * rr + cc];
+                for (int c = 0; c < 3; ++c) h[c] = o[c];
+            }
+        }
 #pragma unroll
-                    for (int m = 0; m < 6; ++m) acc -= li[6 * rr + m] * gj[6 * cc + m];
-                    C[6 * rr + cc] = acc;
-                }
+        for (int c = 0; c < 3; ++c) { const double other = xor_lane<1>(o[c]); l[c] = hf ? other : o[c]; l[3 + c] = hf ? o[c] : other; }
+    };
+    // A_{k+m,k+j} -= L_{k+m,k} G_{k+j,k}^T: row rr, columns 3 hf .. of the block (twelve lanes a block; l = row rr of L_{k+m,k})
+    auto update_block = [&](const int kk, const int m, const int j, const int rr, const int hf, const double l[6]) {
+        const double* Gj = ring_row(kk, j) + 36 * j + 18 * hf;             // rows 3 hf .. of G_{k+j,k}
+        double* C = ring_row(kk, m) + 36 * (m - j) + 6 * rr + 3 * hf;
+        double gj[18], cv[3];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) gj[q] = Gj[q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cv[c] = C[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C[c] = cv[c] - (((l[0] * gj[6 * c] + l[1] * gj[6 * c + 1]) + (l[2] * gj[6 * c + 2] + l[3] * gj[6 * c + 3])) + (l[4] * gj[6 * c + 4] + l[5] * gj[6 * c + 5]));
+    };
+    // wave 0: X_k = C_k^-1 of the pivot block at ring row kr (every lane redundantly), published in dinv[k % 3]
+    auto invert_pivot = [&](const int k, const int kr) {
+        double inv[36];
+        const bool ok = band_chol6_inv(ring + (size_t)kr * rowsz, inv);
+        if (lane == 0) {
+            if (!ok) sflag[0] = 1;
+            double2* o2 = reinterpret_cast<double2*>(dinv + 36 * (k % 3));
+#pragma unroll
+            for (int q = 0; q < 18; ++q) o2[q] = make_double2(inv[2 * q], inv[2 * q + 1]);
         }
     };
-    int kk = 0, kp = 0;                                        // ring rows of block rows k and k - 1
+    // ---- the factor loop (round 4: the pivot's inverse no longer waits for the previous column's scaling).  At the top of step k the
+    // pivot X_k is published and every block of column k is final, still unscaled (G).
+    //   half 1: wave 0 scales block rows k + 1 and k + 2 and takes them out of the three blocks the NEXT pivot and the next step's first
+    //           rows depend on — (k+1,k+1), (k+2,k+1), (k+2,k+2), a twelve-lane group each —; the helper waves scale block rows k + 3 ..,
+    //           commit column k - 1's L into the ring (resident form: the backward pass reads it there) and move the entering block row
+    //           (streaming form);
+    //   half 2: wave 0 inverts pivot k + 1 (D_{k+1} is final: its last update was wave 0's own) WHILE the helpers apply the trailing
+    //           update of block rows k + 3 .. (one block a twelve-lane group, dealt evenly) and run the forward substitution of column k - 1.
+    // L of column k sits in a column buffer during step k (the ring keeps G: every update reads it) and moves to the ring a step later.
+    int kk = 0;                                                // ring row of block row k
     constexpr int NPEND = (BAND_MAX_W * 36 + (BAND_T - 64) - 1) / (BAND_T - 64);
     double pend[NPEND];                                        // streaming form: the block row of S on its way into the ring (waves 1..3)
     int pend_row = -1;
     int enter_row = nrows0 % RR;                               // ring row of the next block row of S to enter (streaming: the row of block row k - 1)
+    if (wave == 0) invert_pivot(0, 0);
+    BAND_SYNC();
     for (int k = 0; k < Npf; ++k) {
+        if (sflag[0]) { if (tid == 0) st->solver_failed = 1; return; }
         const int nb = min(B, Npf - 1 - k);
-        double* Dk = dinv + 36 * (k & 1);
-        double* rowk = ring + (size_t)kk * rowsz;
-        // ---- A: wave 0 inverts D_k (and sets G_{k+1,k} aside); beside it waves 1..3 run the part of the trailing update of column
-        // k - 1 that D_k does not depend on; the block row of S that enters the ring replaces row k - 1
+        const double* X = dinv + 36 * (k % 3);
+        double* Lcol = lk + (size_t)(k & 1) * rowsz;
+        // ---- half 1
         if (wave == 0) {
-            double g1 = 0.0;
-            if (nb > 0 && lane < 36) g1 = (ring_row(kk, 1) + 36)[lane];
-            double inv[36];
-            const bool ok = band_chol6_inv(rowk, inv);             // (inv: X = C_k^-1, lower triangular; D_k^-1 is applied as X^T X)
-            if (nb > 0 && lane < 36) g1buf[lane] = g1;
-            if (lane == 0) {
-                if (!ok) sflag[0] = 1;
-                double2* o2 = reinterpret_cast<double2*>(Dk);
-#pragma unroll
-                for (int q = 0; q < 18; ++q) o2[q] = make_double2(inv[2 * q], inv[2 * q + 1]);
+            // groups of twelve lanes: 0: row 1 -> block (1,1); 1: row 2 -> block (2,1); 2: row 2 once more (not stored) -> block (2,2)
+            const int grp = lane / 12, m = grp == 0 ? 1 : 2, j = grp == 2 ? 2 : 1;
+            if (grp < 3 && m <= nb) {
+                double l[6];
+                scale_row(k, kk, m, (lane % 12) >> 1, lane & 1, X, Lcol, grp < 2, l);
+                update_block(kk, m, j, (lane % 12) >> 1, lane & 1, l);
             }
-#ifdef VISFS_BA_STAMPS
-            if (lane == 0 && k < 16) sstamp[2 + 6 * k] = wall_clock64();
-#endif
-        } else if (k > 0) {
-            // the block row of S that entered the registers one step ago goes to its ring row (its loads have had a whole step to arrive),
-            // then the loads of the next one are issued: block row k - 1 + nrows0 (streaming form: into the ring row of block row k - 1)
-            if (pend_row >= 0) {
-                double* dst = ring + (size_t)pend_row * rowsz;
+        } else {
+            if (k > 0) {
+                // streaming form: the block row of S that entered the registers one step ago goes to its ring row, the loads of the next one are issued
+                if (pend_row >= 0) {
+                    double* dst = ring + (size_t)pend_row * rowsz;
 #pragma unroll
-                for (int u = 0; u < NPEND; ++u) { const int t = tid - 64 + (BAND_T - 64) * u; if (t < rowsz) dst[t] = pend[u]; }
-                pend_row = -1;
-            }
-            const int Inew = k - 1 + nrows0;
-            if (Inew < Npf) {
-                const int* code = scode + Inew * W;             // (from LDS: a block id fetched from HBM first would be a second dependent global round trip)
-#pragma unroll
-                for (int u = 0; u < NPEND; ++u) {
-                    const int t = tid - 64 + (BAND_T - 64) * u;
-                    pend[u] = 0.0;
-                    if (t < rowsz) { const int d = t / 36, q = t - 36 * d, b = code[d]; if (b >= 0) pend[u] = g.S[36 * (size_t)b + 6 * (q % 6) + q / 6]; }
+                    for (int u = 0; u < NPEND; ++u) { const int t = tid - 64 + (BAND_T - 64) * u; if (t < rowsz) dst[t] = pend[u]; }
+                    pend_row = -1;
                 }
-                pend_row = enter_row;
-                if (++enter_row == RR) enter_row = 0;
+                const int Inew = k - 1 + nrows0;
+                if (Inew < Npf) {
+                    const int* code = scode + Inew * W;             // (from LDS: a block id fetched from HBM first would be a second dependent global round trip)
+#pragma unroll
+                    for (int u = 0; u < NPEND; ++u) {
+                        const int t = tid - 64 + (BAND_T - 64) * u;
+                        pend[u] = 0.0;
+                        if (t < rowsz) { const int d = t / 36, q = t - 36 * d, b = code[d]; if (b >= 0) pend[u] = g.S[36 * (size_t)b + 6 * (q % 6) + q / 6]; }
+                    }
+                    pend_row = enter_row;
+                    if (++enter_row == RR) enter_row = 0;
+                }
+                // resident form: column k - 1's L (in its column buffer since the last step) goes to its place in the ring
+                if (resident) {
+                    const int nbp = min(B, Npf - k);               // blocks below the diagonal of column k - 1
+                    const double* Lp = lk + (size_t)((k - 1) & 1) * rowsz;
+                    int kp = kk - 1; if (kp < 0) kp = RR - 1;
+                    for (int t = tid - 64; t < 36 * nbp; t += BAND_T - 64) { const int m = t / 36 + 1; ring_row(kp, m)[t + 36] = Lp[t + 36]; }
+                }
             }
-            syrk_rest(k - 1, kp);
+            for (int t = tid - 64; t < 12 * (nb - 2); t += BAND_T - 64) {
+                double l[6];
+                scale_row(k, kk, 3 + t / 12, (t % 12) >> 1, t & 1, X, Lcol, true, l);
+            }
+        }
+        BAND_SYNC();
 #ifdef VISFS_BA_STAMPS
-            if (tid == 64 && k < 16) sstamp[3 + 6 * k] = wall_clock64();
+        if (tid == 0 && k < 16) sstamp[2 + 6 * k] = wall_clock64();
+#endif
+        // ---- half 2
+        if (wave == 0) {
+            if (k + 1 < Npf) { int k1 = kk + 1; if (k1 == RR) k1 = 0; invert_pivot(k + 1, k1); }
+#ifdef VISFS_BA_STAMPS
+            if (lane == 0 && k < 16) sstamp[3 + 6 * k] = wall_clock64();
+#endif
+        } else {
+            // the blocks (k + m, k + j), 3 <= m <= nb, 1 <= j <= m, a twelve-lane group each (the table lists them by rows: a prefix for short columns)
+            const int ntask = nb >= 3 ? nb * (nb + 1) / 2 - 3 : 0;
+            for (int t = tid - 64; t < 12 * ntask; t += BAND_T - 64) {
+                const int q = t / 12, u = t - 12 * q, rr = u >> 1, hf = u & 1;
+                const int m = pij[2 * q], j = pij[2 * q + 1];
+                const double* Lr = Lcol + 36 * m + 6 * rr;
+                double l[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) l[c] = Lr[c];
+                update_block(kk, m, j, rr, hf, l);
+            }
+            if (wave == 3 && k > 0) fwd_step(k - 1);
+#ifdef VISFS_BA_STAMPS
+            if (tid == 64 && k < 16) sstamp[5 + 6 * k] = wall_clock64();
 #endif
         }
         BAND_SYNC();
         if (k < 16) BAND_STAMP(4 + 6 * k);
-        if (sflag[0]) { if (tid == 0) st->solver_failed = 1; return; }
-        // ---- B: L_ik = G_ik D_k^-1, two threads per block row (three columns each), G_ik kept aside for the trailing update; the same
-        // threads then take L_ik G_{k+1,k}^T out of block (i, k + 1) — the one column the next diagonal block depends on
-        {
-            if (wave == 3 && k > 0) fwd_step(k - 1, kp);           // the forward substitution of the previous column rides on the idle wave
-            double* G = gk + (size_t)(k & 1) * rowsz;
-            for (int t = tid; t < 12 * nb; t += BAND_T) {
-                const int m = t / 12 + 1, u = t - 12 * (m - 1), rr = u >> 1, hf = u & 1;
-                double* rowi = ring_row(kk, m);
-                double* row = rowi + 36 * m + 6 * rr;
-                double* C = rowi + 36 * (m - 1) + 6 * rr + 3 * hf;    // block (k + m, k + 1), columns 3 hf ..
-                const double* g1r = g1buf + 18 * hf;                  // rows 3 hf .. of G_{k+1,k}
-                // every load first (one LDS round trip), static register indices throughout (hf only ever enters addresses and selects)
-                double a[6], g1[18], cv[3];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) a[c] = row[c];
-#pragma unroll
-                for (int q = 0; q < 18; ++q) g1[q] = g1r[q];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) cv[c] = C[c];
-                double o[3];
-                band_apply_dinv<3>(Dk, a, 3 * hf, o);                  // row rr of L_ik = G_ik D_k^-1, columns 3 hf ..: X^T (X g)
-                double* gr = G + 36 * m + 6 * rr + 3 * hf;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { gr[c] = hf ? a[3 + c] : a[c]; row[3 * hf + c] = o[c]; }   // (the partner lane has read the row: same wavefront, program order)
-                if (!resident) {
-                    double* h = g.band_L + (size_t)(k + m) * rowsz + 36 * m + 6 * rr + 3 * hf;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) h[c] = o[c];
-                }
-                // the whole row of L_ik: the partner lane (t ^ 1) holds the other three columns
-                double l[6];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { const double other = xor_lane<1>(o[c]); l[c] = hf ? other : o[c]; l[3 + c] = hf ? o[c] : other; }
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    C[c] = cv[c] - (((l[0] * g1[6 * c] + l[1] * g1[6 * c + 1]) + (l[2] * g1[6 * c + 2] + l[3] * g1[6 * c + 3])) + (l[4] * g1[6 * c + 4] + l[5] * g1[6 * c + 5]));
-            }
-        }
-        BAND_SYNC();
-        if (k < 16) BAND_STAMP(5 + 6 * k);
-        kp = kk;
         if (++kk == RR) kk = 0;
     }
+    if (sflag[0]) { if (tid == 0) st->solver_failed = 1; return; }
     BAND_STAMP(110);
     // ---- backward substitution, one wavefront (the other waves only help to bring chunks of the factor back from HBM)
-    if (wave == 0) fwd_step(Npf - 1, kp);                      // the last forward step: no blocks below
+    if (wave == 0) fwd_step(Npf - 1);                          // the last forward step: no blocks below
     __syncthreads();
     for (int k1 = Npf; k1 > 0;) {
         const int k0 = resident ? 0 : max(0, k1 - RR);
