@@ -242,7 +242,7 @@ struct DeviceGraph {
     double* dense;              // [chol_np][chol_np] scratch of the direct solver (n = 6 Npf padded to a multiple of 32)
     double* chol_y;             // [chol_np]
     double* chol_linv;          // [2][32][32] inverse of the diagonal block of panel p in half p & 1
-    double* band_L;             // [Npf][band_B + 1][36] the banded factor when it does not stay in LDS: block (I, I - d) at [I][d], d = 0: L_II^-1
+    double* band_L;             // [Npf][band_B + 1][36] the banded factor when it does not stay in LDS: block (I, I - d) at [I][d], d = 0: the packed Cholesky factor of the pivot block
 
     LmState* st;
     unsigned long long* stamps;  // [128] diagnostic build (-DVISFS_BA_STAMPS) only: real-time stamps of one PCG workgroup

@@ -2860,26 +2860,26 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const DeviceGraph g) {
 // Parameters.h:185, Optimizer.cpp:76-91).  In a sliding window a landmark is seen from a run of consecutive key-frames, so S is
 // block-BANDED: block (i, j) exists only for |i - j| <= B, B = longest track - 1 (C2 / C4: B = 9 of 49 / 199 block rows), and a
 // triangular factor keeps that band.  This kernel factors the band block column by block column inside one workgroup — no dense
-// matrix, no launch per panel — and solves in the same launch.  The factorisation is the BLOCK form S = L D L^T (6x6 blocks, L unit
-// lower, D block diagonal).  The pivot block D_k is Cholesky-factored (six dependent pivots) and D_k^-1 is applied through the inverse of
-// its triangular factor, X^T (X g) — backward stable where round 3's explicit closed-form inverse (two 3x3 adjugates: a shorter chain)
-// was not: see band_chol6_inv.
+// matrix, no launch per panel — and solves in the same launch.  The factorisation is the plain BLOCK CHOLESKY S = W W^T (6x6 blocks; the
+// diagonal block of W is the Cholesky factor C_k of the pivot block, the blocks below are W_ik = G_ik C_k^-T by a triangular solve per
+// row: nothing is ever inverted, so the factor is as accurate as a scalar Cholesky — see band_chol6 for the history).
 //   ring  [rows][B + 1][36]  LDS: block (I, I - d) of the lower band at [(I mod rows)][d]; rows == Npf when the whole band fits
-//                            (C2: 141 KB), else a sliding window of rows >= B + 2 block rows and the factor streams to band_L (HBM);
-//   step k:  A  wave 0: D_k = C C^T and X = C^-1 (every lane redundantly, operands by LDS broadcast: no cross-lane traffic), positive
-//               definiteness = positive pivots;  waves 1..3: the rest of the trailing update of column k - 1, hidden behind it;
-//            B  L_ik = G_ik D_k^-1 for the <= B blocks below (G = the updated, unscaled block; two threads per block row),
-//               G kept aside for step C;
-//            C  A_ij -= L_ik G_jk^T for k < j <= i <= k + B (a thread per 3x3 tile); the next block row of S enters the ring;
-//   then the backward substitution on one wavefront (right-looking: x_k final, z_j -= L_kj^T x_k) and K8 (pose oplus).
+//                            (C2: 136 KB), else a sliding window of rows >= B + 3 block rows and the factor streams to band_L (HBM);
+//   step k (pivot factor C_k published, column k final and unscaled):
+//     half 1  W_ik = G_ik C_k^-T in place, a lane per row (wave 0: block rows k + 1, k + 2, which it then takes out of the three blocks
+//             the next pivot and the next step's first rows depend on; helper waves: the rows below);  wave 3: forward substitution of
+//             column k - 1;
+//     half 2  wave 0: D_{k+1} = C C^T (every lane redundantly, operands by LDS broadcast: no cross-lane traffic; positive definiteness
+//             = positive pivots) WHILE the helpers apply A_ij -= W_ik W_jk^T for k + 3 <= i, k < j <= i (twelve lanes a block);
+//   then the backward substitution on one wavefront (right-looking: x_k = C_k^-T z_k, z_j -= W_kj^T x_k) and K8 (pose oplus).
 // Every sum has a fixed order: results are bitwise reproducible.  A non-positive or non-finite pivot sets LmState::solver_failed: g2o's
 // solver returns false and the LM trial is rejected.
 constexpr int BAND_T = 256;
 constexpr int BAND_MAX_W = 22;                                  // (B + 1) <= 22: a (B + 2)-row ring of 6x6 blocks fits the LDS budget
 size_t band_lds_bytes(const int npf, const int B, const int rows) {
     const size_t W = (size_t)B + 1;
-    // ring + two column buffers (L of the current / previous column) + right-hand side + three pivot inverses + flags, then the table of stored block ids and the (m, j) table
-    return ((size_t)rows * W * 36 + 2 * W * 36 + 6 * (size_t)npf + 3 * 36 + 8) * sizeof(double) + ((size_t)npf * W * 4 + 15) / 16 * 16 + (((size_t)(B + 1) * (B + 2)) + 15) / 16 * 16;
+    // ring + right-hand side + flags, then the table of stored block ids and the (m, j) table of the trailing update
+    return ((size_t)rows * W * 36 + 6 * (size_t)npf + 8) * sizeof(double) + ((size_t)npf * W * 4 + 15) / 16 * 16 + (((size_t)(B + 1) * (B + 2)) + 15) / 16 * 16;
 }
 // The plan for a reduced system of npf block rows with block half-bandwidth B: how many block rows stay in LDS (all of them when the
 // band fits), or false when even a (B + 2)-row window does not fit (wide bands: the dense blocked Cholesky takes those).
@@ -2897,67 +2897,65 @@ bool band_plan(const int npf, const int B, int* rows, int* lds_bytes) {
     return true;
 }
 
-// Round 4: Cholesky of the SPD 6x6 pivot block D = C C^T (row-major in LDS, lower triangle read) and the INVERSE OF ITS FACTOR, X = C^-1
-// (lower triangular; written row-major with explicit zeros above the diagonal).  D^-1 = X^T X is never formed: it is APPLIED as
-// X^T (X g).  Why: a pose that sees few landmarks (or a window without a fixed pose, Estimator.cpp:252) has a nearly singular pivot
-// block, and L_ik = G_ik D_k^-1 through ANY explicit inverse of D_k carries a relative error eps * cond(D_k) into the factor — the
-// closed-form inverse of round 3 (band_inv6: two 3x3 adjugates) lost the whole solution at cond(S) = 8e10 where the scalar Cholesky of
-// the checker keeps five digits (profiles/r03_stage_precision.log: 7.3e-1 vs 1.8e-5).  The two triangular products are backward stable
-// (error eps * cond(C) = eps * sqrt(cond(D))): the dense NumPy study of the variants is in profiles/r04_band_pivot_study.log.
-// Every lane computes the whole factor redundantly (operands arrive as LDS broadcasts: no cross-lane traffic); six dependent pivots,
-// each v_rsq_f64 + two Newton steps.  Returns false when a pivot is not positive (what a failed Cholesky is) or not finite.
+// Round 4: Cholesky of the SPD 6x6 pivot block D = C C^T.  The factor comes back PACKED
+// (tri6: row i holds C_i0 .. C_ii) with the RECIPROCAL 1 / C_jj on the diagonal: the triangular solves below multiply by it.
+// History: round 3 applied D^-1 through a closed-form inverse (two 3x3 adjugates) and lost the whole solution at cond(S) = 8e10 where
+// the scalar Cholesky of the checker keeps five digits (profiles/r03_stage_precision.log: 7.3e-1 vs 1.8e-5) — a pose that sees few
+// landmarks (or a window without a fixed pose, Estimator.cpp:252) has a nearly singular pivot block; round 4 first applied it as
+// X^T (X g), X = C^-1 (backward stable: profiles/r04_band_pivot_study.log), then dropped X altogether: computing it doubled the pivot's
+// dependent chain (~250 fp64 instructions on one wavefront per column), the chain IS the kernel's time, and the plain block Cholesky
+// needs only C.  Every lane computes the whole factor redundantly (operands arrive as LDS broadcasts: no cross-lane traffic); six
+// dependent pivots, each v_rsq_f64 + two Newton steps.  Returns false when a pivot is not positive (what a failed Cholesky is) or not finite.
 __device__ __forceinline__ constexpr int tri6(const int i, const int j) { return i * (i + 1) / 2 + j; }       // j <= i
-__device__ __forceinline__ bool band_chol6_inv(const double* __restrict__ D, double X[36]) {
-    double a[21], r[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) a[tri6(i, j)] = D[6 * i + j];
-    bool ok = true;
+// 1 / sqrt(x), x > 0, on the pivot chain: v_rsq_f64 seed (relative error < 2^-23) and ONE third-order step, y0 (1 + e / 2 + 3 e^2 / 8) with
+// e = 1 - x y0^2 (truncation 5 e^3 / 16 < 2^-68) — four dependent operations where fast_rsqrt's two Newton steps are six.
+__device__ __forceinline__ double band_rsqrt(const double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y0), y0, 1.0);
+    return __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
+}
+// `d` = the 21 values of the lower triangle, already in registers (row by row); `done(j)` is called as soon as column j of the factor is
+// final — the caller's stores of it then run behind the remaining pivots instead of after the last one (stamped: eleven 16-byte stores
+// of one lane after the chain cost 160-200 ns of a 560 ns half step).
+template <class Done>
+__device__ __forceinline__ bool band_chol6(double a[21], Done&& done) {
+    double plast = 0.0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const double p = a[tri6(j, j)];
-        ok = ok && (p > 0.0) && (p <= DBL_MAX);
-        r[j] = fast_rsqrt(p);
+        plast = p;
+        const double r = band_rsqrt(p);
+        a[tri6(j, j)] = r;
 #pragma unroll
-        for (int i = j; i < 6; ++i) a[tri6(i, j)] *= r[j];                       // column j of C (C_jj = p / sqrt(p))
+        for (int i = j + 1; i < 6; ++i) a[tri6(i, j)] *= r;                      // column j of C
+        done(j);
 #pragma unroll
         for (int i = j + 1; i < 6; ++i)
 #pragma unroll
             for (int k = j + 1; k <= i; ++k) a[tri6(i, k)] -= a[tri6(i, j)] * a[tri6(k, j)];
     }
-    // X = C^-1 by forward substitution, column by column: X_jj = 1 / C_jj = r_j, X_ij = -r_i sum_{m = j}^{i - 1} C_im X_mj
-#pragma unroll
-    for (int q = 0; q < 36; ++q) X[q] = 0.0;
+    // One test instead of six: a pivot that is negative, zero, infinite or NaN makes its reciprocal root NaN or infinite, the whole column
+    // below it (0 * inf and 0 * NaN included) NaN or infinite, and through a_5j^2 the LAST pivot NaN or -inf: the last pivot tells.
+    return (plast > 0.0) && (plast <= DBL_MAX);
+}
+// w C^T = g  (a row of W_ik = G_ik C_k^-T; also y = C^-1 c): w_j = (g_j - sum_{m < j} w_m C_jm) / C_jj
+__device__ __forceinline__ void band_trsv_fwd(const double c[21], const double g[6], double w[6]) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        X[6 * j + j] = r[j];
+        double v = g[j];
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int m = j; m < i; ++m) sacc += a[tri6(i, m)] * X[6 * m + j];
-            X[6 * i + j] = -r[i] * sacc;
-        }
+        for (int m = 0; m < j; ++m) v -= w[m] * c[tri6(j, m)];
+        w[j] = v * c[tri6(j, j)];
     }
-    return ok;
 }
-// y = D^-1 g = X^T (X g) for the six-vector g, entries [c0, c0 + NC) of the result (static indices: X comes as LDS broadcasts)
-template <int NC>
-__device__ __forceinline__ void band_apply_dinv(const double* __restrict__ X, const double g[6], const int c0, double out[NC]) {
-    double t[6];
+// x = C^-T z: x_j = (z_j - sum_{m > j} C_mj x_m) / C_jj
+__device__ __forceinline__ void band_trsv_bwd(const double c[21], const double z[6], double x[6]) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = X[6 * i] * g[0];
+    for (int j = 5; j >= 0; --j) {
+        double v = z[j];
 #pragma unroll
-        for (int j = 1; j <= i; ++j) v += X[6 * i + j] * g[j];
-        t[i] = v;
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        // (rows above the diagonal of column c0 + c hold exact zeros: six terms with static register indices whatever c0 is)
-        const double* col = X + c0 + c;
-        out[c] = ((col[0] * t[0] + col[6] * t[1]) + (col[12] * t[2] + col[18] * t[3])) + (col[24] * t[4] + col[30] * t[5]);
+        for (int m = 5; m > j; --m) v -= c[tri6(m, j)] * x[m];
+        x[j] = v * c[tri6(j, j)];
     }
 }
 
@@ -2976,6 +2974,9 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
 #define BAND_STAMP(slot) do { } while (0)
 #endif
     BAND_STAMP(0);
+#ifdef VISFS_BA_STAMPS
+    if (tid == 0) sstamp[120] = __builtin_readcyclecounter();      // shader clock: with the real-time stamps, the clock the kernel actually ran at
+#endif
     // Barrier of the factor loop: LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave — the
     // streaming form keeps loads of the entering block row and stores of the factor in flight across steps on purpose.
 #define BAND_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -2983,11 +2984,9 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     const bool resident = RR >= Npf;
     const int rowsz = W * 36;
     double* ring = band_lds;                                   // [RR][W][36]
-    double* lk = ring + (size_t)RR * rowsz;                    // [2][W][36] L_ik of column k in half k & 1 (slot m = i - k): the ring keeps the unscaled G_ik during step k
-    double* cvec = lk + 2 * rowsz;                             // [6 Npf] right-hand side -> L^-1 b -> D^-1 L^-1 b -> x
-    double* dinv = cvec + 6 * Npf;                             // [3][36] X_k = C_k^-1 (D_k = C_k C_k^T) at [k % 3]: step k reads X_k and X_{k-1} while X_{k+1} is written
-    int* sflag = reinterpret_cast<int*>(dinv + 108);           // (8 doubles reserved)
-    int* scode = reinterpret_cast<int*>(dinv + 108 + 8);       // [Npf][W] stored block ids (DeviceGraph::band_code)
+    double* cvec = ring + (size_t)RR * rowsz;                  // [6 Npf] right-hand side -> y (W y = b) -> x
+    int* sflag = reinterpret_cast<int*>(cvec + 6 * Npf);       // (8 doubles reserved)
+    int* scode = reinterpret_cast<int*>(cvec + 6 * Npf + 8);   // [Npf][W] stored block ids (DeviceGraph::band_code)
     unsigned char* pij = reinterpret_cast<unsigned char*>(scode) + ((size_t)Npf * W * 4 + 15) / 16 * 16;   // [B (B + 1) / 2 - 3][2] (m, j), 3 <= m <= B, 1 <= j <= m, by rows
     // ---- the first RR block rows of S: the lower block (I, I - d) is the transpose of the stored upper block (I - d, I).  The block
     // ids go to LDS first, so that the element loads below are independent of each other and many are in flight per thread.
@@ -3028,103 +3027,150 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     BAND_STAMP(1);
     // ring row of block row k + i (0 <= i <= B) when block row k sits in ring row kk
     auto ring_row = [&](const int kk, const int i) -> double* { int r = kk + i; r -= (r >= RR) ? RR : 0; return ring + (size_t)r * rowsz; };
-    // forward-substitution step s on one wavefront: c_i -= L_is c_s for the blocks below (L_.s still sits in its column buffer), then c_s <- D_s^-1 c_s
-    auto fwd_step = [&](const int s_) {
-        const double* Di = dinv + 36 * (s_ % 3);
-        const double* Ls = lk + (size_t)(s_ & 1) * rowsz;
-        double cs[6];
+    // the packed factor of a pivot block (21 values at the head of its diagonal slot), as LDS broadcasts
+    auto load_factor = [&](const double* __restrict__ slot, double c[21]) {
+#pragma unroll
+        for (int q = 0; q < 20; q += 2) { const double2 v = reinterpret_cast<const double2*>(slot)[q >> 1]; c[q] = v.x; c[q + 1] = v.y; }
+        c[20] = slot[20];
+    };
+    // forward-substitution step s on one wavefront (block row s in ring row sr): y_s = C_s^-1 c_s (every lane), c_i -= W_is y_s for the blocks below
+    auto fwd_step = [&](const int s_, const int sr) {
+        double cf[21], cs[6], y[6];
+        load_factor(ring + (size_t)sr * rowsz, cf);
 #pragma unroll
         for (int c = 0; c < 6; ++c) cs[c] = cvec[6 * s_ + c];
         const int nb = min(B, Npf - 1 - s_);
-        double z = 0.0;
-        if (lane < 6) { double zz[1]; band_apply_dinv<1>(Di, cs, lane, zz); z = zz[0]; }
-        for (int e = lane; e < 6 * nb; e += 64) {
-            const int m = e / 6 + 1, rr = e - 6 * (m - 1);
-            const double* L = Ls + 36 * m + 6 * rr;
-            double acc = cvec[6 * (s_ + m) + rr];
+        // the rows of W this lane multiplies (two at most: 6 B <= 126) are loaded before the triangular solve, not after it
+        double Lr[2][6], acc[2];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc -= L[c] * cs[c];
-            cvec[6 * (s_ + m) + rr] = acc;
-        }
-        if (lane < 6) cvec[6 * s_ + lane] = z;
-    };
-    // Row rr of L_{k+m,k} = G_{k+m,k} D_k^-1, columns 3 hf .. (one of twelve lanes a block row); the whole row comes back in l[] (the partner
-    // lane t ^ 1 holds the other three columns).  store: the row goes to the column buffer (the ring keeps G until the next step: the
-    // updates read it) and, in the streaming form, to HBM.
-    auto scale_row = [&](const int k, const int kk, const int m, const int rr, const int hf, const double* __restrict__ X, double* __restrict__ Lcol, const bool store, double l[6]) {
-        const double* row = ring_row(kk, m) + 36 * m + 6 * rr;             // row rr of G_{k+m,k}
-        double a[6];
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u;
+            if (e < 6 * nb) {
+                const int m = e / 6 + 1, rr = e - 6 * (m - 1);
+                const double* L = ring_row(sr, m) + 36 * m + 6 * rr;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) a[c] = row[c];
-        double o[3];
-        band_apply_dinv<3>(X, a, 3 * hf, o);
-        if (store) {
-            double* lo = Lcol + 36 * m + 6 * rr + 3 * hf;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) lo[c] = o[c];
-            if (!resident) {
-                double* h = g.band_L + (size_t)(k + m) * rowsz + 36 * m + 6 * rr + 3 * hf;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) h[c] = o[c];
+                for (int c = 0; c < 6; c += 2) { const double2 v = *reinterpret_cast<const double2*>(L + c); Lr[u][c] = v.x; Lr[u][c + 1] = v.y; }
+                acc[u] = cvec[6 * (s_ + m) + rr];
             }
         }
+        band_trsv_fwd(cf, cs, y);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const double other = xor_lane<1>(o[c]); l[c] = hf ? other : o[c]; l[3 + c] = hf ? o[c] : other; }
-    };
-    // A_{k+m,k+j} -= L_{k+m,k} G_{k+j,k}^T: row rr, columns 3 hf .. of the block (twelve lanes a block; l = row rr of L_{k+m,k})
-    auto update_block = [&](const int kk, const int m, const int j, const int rr, const int hf, const double l[6]) {
-        const double* Gj = ring_row(kk, j) + 36 * j + 18 * hf;             // rows 3 hf .. of G_{k+j,k}
-        double* C = ring_row(kk, m) + 36 * (m - j) + 6 * rr + 3 * hf;
-        double gj[18], cv[3];
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u;
+            if (e < 6 * nb) {
+                double a = acc[u];
 #pragma unroll
-        for (int q = 0; q < 18; ++q) gj[q] = Gj[q];
+                for (int c = 0; c < 6; ++c) a -= Lr[u][c] * y[c];
+                cvec[6 * s_ + 6 + e] = a;                      // (6 (s + m) + rr = 6 s + 6 + e)
+            }
+        }
+        if (lane < 6) {
+            double yl = y[0];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) cv[c] = C[c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            C[c] = cv[c] - (((l[0] * gj[6 * c] + l[1] * gj[6 * c + 1]) + (l[2] * gj[6 * c + 2] + l[3] * gj[6 * c + 3])) + (l[4] * gj[6 * c + 4] + l[5] * gj[6 * c + 5]));
-    };
-    // wave 0: X_k = C_k^-1 of the pivot block at ring row kr (every lane redundantly), published in dinv[k % 3]
-    auto invert_pivot = [&](const int k, const int kr) {
-        double inv[36];
-        const bool ok = band_chol6_inv(ring + (size_t)kr * rowsz, inv);
-        if (lane == 0) {
-            if (!ok) sflag[0] = 1;
-            double2* o2 = reinterpret_cast<double2*>(dinv + 36 * (k % 3));
-#pragma unroll
-            for (int q = 0; q < 18; ++q) o2[q] = make_double2(inv[2 * q], inv[2 * q + 1]);
+            for (int c = 1; c < 6; ++c) yl = lane == c ? y[c] : yl;
+            cvec[6 * s_ + lane] = yl;
         }
     };
-    // ---- the factor loop (round 4: the pivot's inverse no longer waits for the previous column's scaling).  At the top of step k the
-    // pivot X_k is published and every block of column k is final, still unscaled (G).
-    //   half 1: wave 0 scales block rows k + 1 and k + 2 and takes them out of the three blocks the NEXT pivot and the next step's first
-    //           rows depend on — (k+1,k+1), (k+2,k+1), (k+2,k+2), a twelve-lane group each —; the helper waves scale block rows k + 3 ..,
-    //           commit column k - 1's L into the ring (resident form: the backward pass reads it there) and move the entering block row
-    //           (streaming form);
-    //   half 2: wave 0 inverts pivot k + 1 (D_{k+1} is final: its last update was wave 0's own) WHILE the helpers apply the trailing
-    //           update of block rows k + 3 .. (one block a twelve-lane group, dealt evenly) and run the forward substitution of column k - 1.
-    // L of column k sits in a column buffer during step k (the ring keeps G: every update reads it) and moves to the ring a step later.
+    // Row rr of W_{k+m,k} = G_{k+m,k} C_k^-T, in place (two lanes a row, each solves the whole row and writes three columns); in the
+    // streaming form the row also goes to HBM
+    auto trsm_row = [&](const int k, const int kk, const int m, const int rr, const int hf, const double cf[21]) {
+        double* row = ring_row(kk, m) + 36 * m + 6 * rr;
+        double a[6], w[6];
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) { const double2 v = *reinterpret_cast<const double2*>(row + c); a[c] = v.x; a[c + 1] = v.y; }
+        band_trsv_fwd(cf, a, w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[3 * hf + c] = hf ? w[3 + c] : w[c];
+        if (!resident) {
+            double* h = g.band_L + (size_t)(k + m) * rowsz + 36 * m + 6 * rr + 3 * hf;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[c] = hf ? w[3 + c] : w[c];
+        }
+    };
+    // A_{k+m,k+j} -= W_{k+m,k} W_{k+j,k}^T: row rr, columns 3 hf .. of the block (twelve lanes a block)
+    struct UpdOperands { double wm[6], wj[18], cv[3]; };
+    auto update_load = [&](const int kk, const int m, const int j, const int rr, const int hf, UpdOperands& o) {
+        const double* Wm = ring_row(kk, m) + 36 * m + 6 * rr;
+        const double* Wj = ring_row(kk, j) + 36 * j + 18 * hf;             // rows 3 hf .. of W_{k+j,k}
+        const double* C = ring_row(kk, m) + 36 * (m - j) + 6 * rr + 3 * hf;
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) { const double2 v = *reinterpret_cast<const double2*>(Wm + c); o.wm[c] = v.x; o.wm[c + 1] = v.y; }
+#pragma unroll
+        for (int q = 0; q < 18; q += 2) { const double2 v = *reinterpret_cast<const double2*>(Wj + q); o.wj[q] = v.x; o.wj[q + 1] = v.y; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.cv[c] = C[c];
+    };
+    auto update_store = [&](const int kk, const int m, const int j, const int rr, const int hf, const UpdOperands& o) {
+        double* C = ring_row(kk, m) + 36 * (m - j) + 6 * rr + 3 * hf;
+        const double* l = o.wm; const double* gj = o.wj;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C[c] = o.cv[c] - (((l[0] * gj[6 * c] + l[1] * gj[6 * c + 1]) + (l[2] * gj[6 * c + 2] + l[3] * gj[6 * c + 3])) + (l[4] * gj[6 * c + 4] + l[5] * gj[6 * c + 5]));
+    };
+    // wave 0: the lower triangle of the pivot block at ring row kr into registers (issued before the barrier that ends half 1: the block's
+    // last update was this wave's own), then D_k = C_k C_k^T (every lane redundantly); the packed factor replaces the head of the block,
+    // column by column while the later pivots are still being computed
+    auto read_pivot = [&](const int kr, double a[21]) {
+        const double* slot = ring + (size_t)kr * rowsz;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) a[tri6(i, j)] = slot[6 * i + j];
+    };
+    auto factor_pivot = [&](const int k, const int kr, double a[21]) {
+        double* slot = ring + (size_t)kr * rowsz;
+        // (every lane stores the same values to the same addresses: no branch splits the chain into blocks the scheduler cannot mix)
+        const bool ok = band_chol6(a, [&](const int j) {
+#pragma unroll
+            for (int i = j; i < 6; ++i) slot[tri6(i, j)] = a[tri6(i, j)];
+        });
+        if (lane == 0) {
+            if (!ok) sflag[0] = 1;
+            if (!resident) {
+                double* h = g.band_L + (size_t)k * rowsz;
+#pragma unroll
+                for (int q = 0; q < 20; q += 2) reinterpret_cast<double2*>(h)[q >> 1] = make_double2(a[q], a[q + 1]);
+                h[20] = a[20];
+            }
+        }
+    };
+    // ---- the factor loop.  At the top of step k the factor C_k of the pivot is published and every block of column k is final, still
+    // unscaled (G).  The chain that bounds the kernel is wave 0's: two row solves, three block updates, one 6x6 Cholesky per column.
     int kk = 0;                                                // ring row of block row k
     constexpr int NPEND = (BAND_MAX_W * 36 + (BAND_T - 64) - 1) / (BAND_T - 64);
     double pend[NPEND];                                        // streaming form: the block row of S on its way into the ring (waves 1..3)
     int pend_row = -1;
     int enter_row = nrows0 % RR;                               // ring row of the next block row of S to enter (streaming: the row of block row k - 1)
-    if (wave == 0) invert_pivot(0, 0);
+    // a helper thread's first tile of the trailing update never changes (the table lists blocks by rows): out of the loop
+    int tile_m = 3, tile_j = 1;
+    if (wave != 0 && ((tid - 64) >> 2) < B * (B + 1) / 2 - 3) { tile_m = pij[2 * ((tid - 64) >> 2)]; tile_j = pij[2 * ((tid - 64) >> 2) + 1]; }
+    double cf[21];                                             // C_k: wave 0 keeps what it has just computed, the helpers read it back
+    if (wave == 0) { read_pivot(0, cf); factor_pivot(0, 0, cf); }
     BAND_SYNC();
+    // (a failed pivot does not leave the loop: its NaNs touch no address, the flag is read once after the loop — a read of it per step was
+    // an LDS round trip on the chain)
     for (int k = 0; k < Npf; ++k) {
-        if (sflag[0]) { if (tid == 0) st->solver_failed = 1; return; }
         const int nb = min(B, Npf - 1 - k);
-        const double* X = dinv + 36 * (k % 3);
-        double* Lcol = lk + (size_t)(k & 1) * rowsz;
+        if (wave != 0) load_factor(ring + (size_t)kk * rowsz, cf);
         // ---- half 1
         if (wave == 0) {
-            // groups of twelve lanes: 0: row 1 -> block (1,1); 1: row 2 -> block (2,1); 2: row 2 once more (not stored) -> block (2,2)
-            const int grp = lane / 12, m = grp == 0 ? 1 : 2, j = grp == 2 ? 2 : 1;
-            if (grp < 3 && m <= nb) {
-                double l[6];
-                scale_row(k, kk, m, (lane % 12) >> 1, lane & 1, X, Lcol, grp < 2, l);
-                update_block(kk, m, j, (lane % 12) >> 1, lane & 1, l);
+            // groups of twelve lanes: rows: 0 -> block row k + 1, 1 -> block row k + 2;  updates: 0 -> (1,1), 1 -> (2,1), 2 -> (2,2)
+            const int grp = lane / 12, u = lane - 12 * grp, rr = u >> 1, hf = u & 1;
+            if (grp < 2 && grp + 1 <= nb) trsm_row(k, kk, grp + 1, rr, hf, cf);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int m = grp == 0 ? 1 : 2, j = grp == 2 ? 2 : 1;
+            if (grp < 3 && m <= nb) { UpdOperands o; update_load(kk, m, j, rr, hf, o); update_store(kk, m, j, rr, hf, o); }
+            if (k + 1 < Npf) {
+                // D_{k+1} is final with this wave's own stores: its loads go out before the barrier (cf is dead until the factor replaces it)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                int k1 = kk + 1; if (k1 == RR) k1 = 0;
+                read_pivot(k1, cf);
             }
+#ifdef VISFS_BA_STAMPS
+            if (lane == 0 && k < 16) sstamp[6 + 6 * k] = wall_clock64();
+#endif
         } else {
             if (k > 0) {
                 // streaming form: the block row of S that entered the registers one step ago goes to its ring row, the loads of the next one are issued
@@ -3146,18 +3192,12 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
                     pend_row = enter_row;
                     if (++enter_row == RR) enter_row = 0;
                 }
-                // resident form: column k - 1's L (in its column buffer since the last step) goes to its place in the ring
-                if (resident) {
-                    const int nbp = min(B, Npf - k);               // blocks below the diagonal of column k - 1
-                    const double* Lp = lk + (size_t)((k - 1) & 1) * rowsz;
-                    int kp = kk - 1; if (kp < 0) kp = RR - 1;
-                    for (int t = tid - 64; t < 36 * nbp; t += BAND_T - 64) { const int m = t / 36 + 1; ring_row(kp, m)[t + 36] = Lp[t + 36]; }
-                }
             }
-            for (int t = tid - 64; t < 12 * (nb - 2); t += BAND_T - 64) {
-                double l[6];
-                scale_row(k, kk, 3 + t / 12, (t % 12) >> 1, t & 1, X, Lcol, true, l);
-            }
+            for (int t = tid - 64; t < 12 * (nb - 2); t += BAND_T - 64) trsm_row(k, kk, 3 + t / 12, (t % 12) >> 1, t & 1, cf);
+            if (wave == 3 && k > 0) { int kp = kk - 1; if (kp < 0) kp = RR - 1; fwd_step(k - 1, kp); }
+#ifdef VISFS_BA_STAMPS
+            if (tid == 192 && k < 16) sstamp[7 + 6 * k] = wall_clock64();
+#endif
         }
         BAND_SYNC();
 #ifdef VISFS_BA_STAMPS
@@ -3165,23 +3205,39 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
 #endif
         // ---- half 2
         if (wave == 0) {
-            if (k + 1 < Npf) { int k1 = kk + 1; if (k1 == RR) k1 = 0; invert_pivot(k + 1, k1); }
+            if (k + 1 < Npf) { int k1 = kk + 1; if (k1 == RR) k1 = 0; factor_pivot(k + 1, k1, cf); }
 #ifdef VISFS_BA_STAMPS
             if (lane == 0 && k < 16) sstamp[3 + 6 * k] = wall_clock64();
 #endif
         } else {
-            // the blocks (k + m, k + j), 3 <= m <= nb, 1 <= j <= m, a twelve-lane group each (the table lists them by rows: a prefix for short columns)
+            // the blocks (k + m, k + j), 3 <= m <= nb, 1 <= j <= m (the table lists them by rows: a prefix for short columns), a 3x3 tile
+            // a thread: 36 operands for 54 multiply-adds — the twelve-lane form of wave 0 reads 27 for 18, and with three helper waves
+            // at it the LDS pipe, not the arithmetic, set the length of this half (stamped: 920 ns -> see profiles/r04_band_chain.log)
             const int ntask = nb >= 3 ? nb * (nb + 1) / 2 - 3 : 0;
-            for (int t = tid - 64; t < 12 * ntask; t += BAND_T - 64) {
-                const int q = t / 12, u = t - 12 * q, rr = u >> 1, hf = u & 1;
-                const int m = pij[2 * q], j = pij[2 * q + 1];
-                const double* Lr = Lcol + 36 * m + 6 * rr;
-                double l[6];
+            for (int t = tid - 64; t < 4 * ntask; t += BAND_T - 64) {
+                const int q = t >> 2, ta = (t >> 1) & 1, tb = t & 1;
+                const bool first = t < BAND_T - 64;
+                const int m = first ? tile_m : (int)pij[2 * q], j = first ? tile_j : (int)pij[2 * q + 1];
+                const double* Wm = ring_row(kk, m) + 36 * m + 18 * ta;       // rows 3 ta .. of W_{k+m,k}
+                const double* Wj = ring_row(kk, j) + 36 * j + 18 * tb;       // rows 3 tb .. of W_{k+j,k}
+                double* C = ring_row(kk, m) + 36 * (m - j) + 18 * ta + 3 * tb;
+                double wm[18], wj[18], cv[9];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) l[c] = Lr[c];
-                update_block(kk, m, j, rr, hf, l);
+                for (int e = 0; e < 18; e += 2) { const double2 v = *reinterpret_cast<const double2*>(Wm + e); wm[e] = v.x; wm[e + 1] = v.y; }
+#pragma unroll
+                for (int e = 0; e < 18; e += 2) { const double2 v = *reinterpret_cast<const double2*>(Wj + e); wj[e] = v.x; wj[e + 1] = v.y; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cv[3 * r + c] = C[6 * r + c];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double* l = wm + 6 * r; const double* gj = wj + 6 * c;
+                        C[6 * r + c] = cv[3 * r + c] - (((l[0] * gj[0] + l[1] * gj[1]) + (l[2] * gj[2] + l[3] * gj[3])) + (l[4] * gj[4] + l[5] * gj[5]));
+                    }
             }
-            if (wave == 3 && k > 0) fwd_step(k - 1);
 #ifdef VISFS_BA_STAMPS
             if (tid == 64 && k < 16) sstamp[5 + 6 * k] = wall_clock64();
 #endif
@@ -3193,8 +3249,10 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     if (sflag[0]) { if (tid == 0) st->solver_failed = 1; return; }
     BAND_STAMP(110);
     // ---- backward substitution, one wavefront (the other waves only help to bring chunks of the factor back from HBM)
-    if (wave == 0) fwd_step(Npf - 1);                          // the last forward step: no blocks below
+    if (wave == 0) fwd_step(Npf - 1, (Npf - 1) % RR);           // the last forward step: no blocks below
     __syncthreads();
+    const bool fast_bwd = 6 * W <= 64;                         // a lane per accumulator of the window (B <= 9: every BASELINE window)
+    double zreg = 0.0;
     for (int k1 = Npf; k1 > 0;) {
         const int k0 = resident ? 0 : max(0, k1 - RR);
         if (!resident) {
@@ -3215,43 +3273,181 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
             }
             __syncthreads();
         }
-        if (wave == 0) {
-            int kr = (k1 - 1) % RR;
-            for (int k = k1 - 1; k >= k0; --k) {
-                // x_k is final (every row below has been taken out of it): z_j -= L_kj^T x_k for the blocks to the left
-                const double* rowk = ring + (size_t)kr * rowsz;
-                double xk[6];
+        if (fast_bwd) {
+            // ---- rows [k0, k1) of the factor, W~ = [.. W_kj .. C_k], become X_k W~ (X_k = C_k^-1: unit diagonal blocks): the backward
+            // recurrence u_j = y_j - sum_{k > j} (X_k W_kj)^T u_k then has NO triangular solve in its chain, and x_k = X_k^T u_k falls out in
+            // parallel afterwards.  All threads: X_k over the packed C_k (a thread a row), then a thread a column of a block.
+            for (int k = k0 + tid; k < k1; k += BAND_T) {
+                double* slot = ring + (size_t)(k % RR) * rowsz;
+                double c[21], x[21];
 #pragma unroll
-                for (int rr = 0; rr < 6; ++rr) xk[rr] = cvec[6 * k + rr];
+                for (int q = 0; q < 21; ++q) c[q] = slot[q];
+                // X_jj = 1 / C_jj (stored), X_ij = -X_ii sum_{q = j}^{i - 1} C_iq X_qj
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    x[tri6(j, j)] = c[tri6(j, j)];
+#pragma unroll
+                    for (int i = j + 1; i < 6; ++i) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = j; q < i; ++q) acc += c[tri6(i, q)] * x[tri6(q, j)];
+                        x[tri6(i, j)] = -c[tri6(i, i)] * acc;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 21; ++q) slot[q] = x[q];
+            }
+            __syncthreads();
+            if (k1 == Npf) BAND_STAMP(113);
+            // (a thread a half block: X_k is read once for three columns — a thread a column re-read it 2600 times a C2 solve and the
+            // pass was LDS-bound at 3.8 us)
+            for (int t = tid; t < (k1 - k0) * B * 2; t += BAND_T) {
+                const int r = t / (2 * B), e = t - 2 * B * r, m = (e >> 1) + 1, c0 = 3 * (e & 1), k = k0 + r;
+                if (m <= k) {
+                    double* row = ring + (size_t)(k % RR) * rowsz;
+                    double x[21], w[3][6];
+                    load_factor(row, x);
+                    double* blk = row + 36 * m + c0;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) w[c][i] = blk[6 * i + c];
+#pragma unroll
+                    for (int i = 5; i >= 0; --i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double acc = x[tri6(i, 0)] * w[c][0];
+#pragma unroll
+                            for (int q = 1; q <= i; ++q) acc += x[tri6(i, q)] * w[c][q];
+                            blk[6 * i + c] = acc;
+                        }
+                }
+            }
+            __syncthreads();
+            if (k1 == Npf) BAND_STAMP(114);
+        }
+        if (wave == 0 && fast_bwd) {
+            // Block j's six accumulators live in lanes 6 (j mod (B + 1)) + cc for as long as rows still reach it (rows j + 1 .. j + B): the
+            // chain of a step is twelve v_readlane (u_k to every lane) and six multiply-adds — no LDS round trip, no triangular solve.
+            // One wavefront issues an instruction every ~6 cycles whatever it is: the step is as long as its instruction list, so
+            // nothing is masked that need not be (lanes without a block compute garbage nobody reads; every address is a valid one).
+            // (The LDS form below, kept for bands wider than ten blocks, pays a store, a fence and a load per step.)
+            int kr = (k1 - 1) % RR;
+            const int slot = lane / 6, cc = lane - 6 * slot;
+            const bool lane_on = slot < W;
+            if (k1 == Npf) {                                        // the window of the last block row and that row itself
+                const int jm = (Npf - 1) - ((Npf - 1 - slot) % W + W) % W;     // the block j <= Npf - 1 with j mod W == slot
+                zreg = (lane_on && jm >= 0) ? cvec[6 * jm + cc] : 0.0;
+            }
+            // this lane's block in the window of row k: m = (k - slot) mod W (0: the row's own block), block j = k - m; m and k mod W
+            // step down with k (a modulo by a run-time W is some forty instructions).  The operands of the next step are loaded into
+            // the OTHER register set before this step's chain starts.
+            int mk = (((k1 - 1) - slot) % W + W) % W, ks = (k1 - 1) % W;
+            auto load_operands = [&](const int k, const int m, const int krow, double L[6], double& zin) {
+                const double* src = ring + (size_t)krow * rowsz + 36 * m + cc;       // (m == 0: the row's own block — values unused)
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) L[rr] = src[6 * rr];
+                // the block that takes the slot of block k once u_k is out: k - W, first reached by row k - 1
+                zin = cvec[max(0, 6 * (k - W) + cc)];
+            };
+            auto step = [&](const int k, const double L[6], const double zin) {
+                double uk[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) uk[c] = readlane_f64(zreg, 6 * ks + c);
+                double zn = zreg;
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) zn -= L[rr] * uk[rr];
+                if (mk == 0 && lane_on) cvec[6 * k + cc] = zreg;     // u_k
+                zreg = mk == 0 ? zin : zn;
+                if (--kr < 0) kr = RR - 1;
+                mk = mk == 0 ? W - 1 : mk - 1; ks = ks == 0 ? W - 1 : ks - 1;
+            };
+            double LA[6], zA, LB[6], zB;
+            load_operands(k1 - 1, mk, kr, LA, zA);
+            for (int k = k1 - 1; k >= k0; k -= 2) {
+                // (the operands of row k - 1 are loaded even when that row belongs to the next chunk or does not exist: the ring row is
+                // valid memory, the values are not used)
+                { int krn = kr - 1; if (krn < 0) krn = RR - 1; load_operands(k - 1, mk == 0 ? W - 1 : mk - 1, krn, LB, zB); }
+                step(k, LA, zA);
+                if (k - 1 < k0) break;
+                { int krn = kr - 1; if (krn < 0) krn = RR - 1; load_operands(k - 2, mk == 0 ? W - 1 : mk - 1, krn, LA, zA); }
+                step(k - 1, LB, zB);
+            }
+        } else if (wave == 0) {
+            int kr = (k1 - 1) % RR;
+            double cf[21];
+            load_factor(ring + (size_t)kr * rowsz, cf);
+            for (int k = k1 - 1; k >= k0; --k) {
+                // every row below has been taken out of z_k: x_k = C_k^-T z_k (every lane), then z_j -= W_kj^T x_k for the blocks to the left
+                const double* rowk = ring + (size_t)kr * rowsz;
+                int krn = kr - 1; if (krn < 0) krn = RR - 1;
+                double zk[6], xk[6], cfn[21];
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) zk[rr] = cvec[6 * k + rr];
+                load_factor(ring + (size_t)(k > k0 ? krn : kr) * rowsz, cfn);      // the next pivot's factor, off the chain
+                band_trsv_bwd(cf, zk, xk);
                 const int nbk = min(B, k);
                 for (int e = lane; e < 6 * nbk; e += 64) {
                     const int m = e / 6 + 1, cc = e - 6 * (m - 1);
-                    const double* L = rowk + 36 * m;           // L_kj, j = k - m
+                    const double* L = rowk + 36 * m;           // W_kj, j = k - m
                     double acc = cvec[6 * (k - m) + cc];
 #pragma unroll
                     for (int rr = 0; rr < 6; ++rr) acc -= L[6 * rr + cc] * xk[rr];
                     cvec[6 * (k - m) + cc] = acc;
                 }
+                if (lane < 6) {
+                    double xl = xk[0];
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) xl = lane == c ? xk[c] : xl;
+                    cvec[6 * k + lane] = xl;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                if (--kr < 0) kr = RR - 1;
+#pragma unroll
+                for (int q = 0; q < 21; ++q) cf[q] = cfn[q];
+                kr = krn;
             }
         }
         __syncthreads();
+        if (k1 == Npf) BAND_STAMP(115);
+        if (fast_bwd) {
+            // x_k = X_k^T u_k for the rows of this chunk (their X_k leave the ring with the next one), and K8 (pose oplus) with it
+            const int sel = st->sel;
+            for (int k = k0 + tid; k < k1; k += BAND_T) {
+                double x[21], u[6], dx[6];
+                load_factor(ring + (size_t)(k % RR) * rowsz, x);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) u[i] = cvec[6 * k + i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double acc = x[tri6(c, c)] * u[c];
+#pragma unroll
+                    for (int i = c + 1; i < 6; ++i) acc += x[tri6(i, c)] * u[i];
+                    dx[c] = acc;
+                    g.x[6 * k + c] = acc;
+                }
+                const int ip = g.free_pose[k];
+                pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+            }
+            __syncthreads();
+        }
         k1 = k0;
     }
     BAND_STAMP(111);
-    for (int t = tid; t < 6 * Npf; t += BAND_T) g.x[t] = cvec[t];
-    const int sel = st->sel;
-    for (int a = tid; a < Npf; a += BAND_T) {
-        const int ip = g.free_pose[a];
-        double dx[6];
+    if (!fast_bwd) {
+        for (int t = tid; t < 6 * Npf; t += BAND_T) g.x[t] = cvec[t];
+        const int sel = st->sel;
+        for (int a = tid; a < Npf; a += BAND_T) {
+            const int ip = g.free_pose[a];
+            double dx[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) dx[q] = cvec[6 * a + q];
-        pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+            for (int q = 0; q < 6; ++q) dx[q] = cvec[6 * a + q];
+            pose_oplus(g.pose[sel] + POSE_STRIDE * ip, dx, g.pose[sel ^ 1] + POSE_STRIDE * ip);
+        }
     }
     BAND_STAMP(112);
 #ifdef VISFS_BA_STAMPS
+    if (tid == 0) sstamp[121] = __builtin_readcyclecounter();
     __syncthreads();
     if (tid < 126) g.stamps[tid] = sstamp[tid];
 #endif
