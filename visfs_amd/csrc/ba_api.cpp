@@ -746,6 +746,18 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
                                 const bool want = e && e[0] == '1';
                                 return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && want; }();
+    // ... and where each stored block sits in the row lists: k_schur_finalize writes S a second time by scalar row for that kernel
+    const int cu_T = (int)((6 * (size_t)Npf + 63) / 64 * 64);
+    int cu_max_row = 0;
+    std::vector<int32_t> blk_slot(std::max(n_blk, 1), 255 | (255 << 8));
+    for (int a = 0; a < Npf; ++a) {
+        cu_max_row = std::max(cu_max_row, row_ptr[a + 1] - row_ptr[a]);
+        if (pcg_cu)
+            for (int n = row_ptr[a]; n < row_ptr[a + 1]; ++n) {
+                const int b = row_blk[n] >> 1, k = n - row_ptr[a];
+                if (row_blk[n] & 1) blk_slot[b] = (blk_slot[b] & 0xff) | (k << 8); else blk_slot[b] = (blk_slot[b] & ~0xff) | k;
+            }
+    }
     // direct solver (Optimizer/Solver 0, 1, 3 and every solve of the Ceres branch): S of a sliding window is block-banded — the banded
     // factorisation in one workgroup (k_band_chol) when the band is narrow enough, the dense blocked Cholesky otherwise (VISFS_BA_BAND=0 forces it)
     int band_B = -1, band_rows = 0, band_lds = 0;
@@ -804,6 +816,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.row_ptr = A.take<int32_t>(Npf + 1);
         g.row_col = A.take<int32_t>(std::max<size_t>(row_col.size(), 1));
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
+        g.blk_slot = A.take<int32_t>(std::max(n_blk, 1));
         g.pcg1_code = pcg1 ? A.take<int32_t>((size_t)Npf * Npf) : nullptr;
         g.band_code = band_B >= 0 ? A.take<int32_t>(band_code.size()) : nullptr;
         g.run_desc = run_path ? A.take<int4>(rp.desc.size()) : nullptr;
@@ -847,6 +860,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.bp = A.take<double>(std::max<size_t>(n6, 1));
         g.lin_part = A.take<double>((size_t)n_parts * 2);
         g.S = A.take<double>((size_t)std::max(n_blk, 1) * 36);
+        g.S_rows = A.take<double>(pcg_cu ? (size_t)cu_max_row * 6 * cu_T : 1);      // (inside the span the upload clears: slots a row does not use read as zero)
         g.bs = A.take<double>(std::max<size_t>(n6, 1));
         g.Minv = A.take<double>((size_t)std::max(Npf, 1) * 36);
         g.x = A.take<double>(std::max<size_t>(n6, 1));
@@ -918,6 +932,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         if (!blk_odo.empty()) std::memcpy(const_cast<int32_t*>(hg.blk_odo), blk_odo.data(), blk_odo.size() * 4);
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
+        if (n_blk) std::memcpy(const_cast<int32_t*>(hg.blk_slot), blk_slot.data(), (size_t)n_blk * 4);
         if (pcg1) std::memcpy(const_cast<int32_t*>(hg.pcg1_code), pcg1_code.data(), pcg1_code.size() * 4);
         if (band_B >= 0) std::memcpy(const_cast<int32_t*>(hg.band_code), band_code.data(), band_code.size() * 4);
         if (run_path) { std::memcpy(const_cast<int4*>(hg.run_desc), rp.desc.data(), rp.desc.size() * sizeof(int4)); std::memcpy(const_cast<int32_t*>(hg.run_k0), rp.k0.data(), rp.k0.size() * 4); }
@@ -939,7 +954,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     { const char* e = std::getenv("VISFS_BA_FIN_PCG"); const char* gv = std::getenv("VISFS_BA_PCG_GATHER");
       dg.fin_pcg = (pcg1 && !pcg_cu && !small_solve_fits_npf && (e && e[0] == '1') && !(gv && std::atoi(gv) != 1)) ? 1 : 0; }
     dg.n_runs = rp.n; dg.run_lr = rp.LR; dg.run_m = rp.M; dg.run_cap = rp.cap; dg.run_wmax = rp.wmax; dg.run_lds_bytes = (int32_t)rp.lds;
-    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.pcg_lds_bytes = (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.cu_T = cu_T; dg.pcg_lds_bytes = pcg_cu ? (int32_t)pcg_cu_lds_bytes(Npf, max_row) : (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.stereo_baseline = opt.baseline;
@@ -2408,6 +2423,7 @@ static int stage_fetch_impl(visfs_ba_handle* h, int32_t which, double* dst, size
         case VISFS_BA_BUF_POINT_TRIAL: src = g.pt[sel ^ 1]; m = (size_t)g.Nl * 3; break;
         case VISFS_BA_BUF_HPP: case VISFS_BA_BUF_S: m = n6 * n6; break;
         case VISFS_BA_BUF_POSE_TRIAL: m = (size_t)g.Np * 7; break;
+        case 101: src = g.pcg_cu ? g.S_rows : nullptr; m = g.pcg_cu ? (size_t)g.pcg_max_row * 6 * g.cu_T : 0; if (!src) return bad(h, "not a k_pcg_cu window"); break;     // diagnostic: S by scalar row
         case 100: {   // diagnostic: raw PCG stamps (only meaningful in a -DVISFS_BA_STAMPS build)
             if (n_doubles < 128) return bad(h, "destination too small");
             HIP_TRY(h, hipMemcpyAsync(dst, g.stamps, 128 * 8, hipMemcpyDeviceToHost, w.stream));

@@ -121,6 +121,7 @@ struct DeviceGraph {
     int32_t pcg_max_row;    // longest block row of S (blocks)
     int32_t pcg_rows_per_wg; // block rows per PCG workgroup (1 up to 256 free poses)
     int32_t pcg_cu;         // 1: the reduced system is solved by ONE workgroup (k_pcg_cu: S in registers, no cross-workgroup hand-off)
+    int32_t cu_T;           // ... its scalar rows rounded up to whole wavefronts: the row stride of S_rows
     int32_t pcg_lds_bytes;
     int32_t chol_np;        // padded order of the dense reduced camera matrix (direct solver)
     int32_t band_B;         // direct solver: block half-bandwidth of S (max j - i over the stored blocks) when the banded Cholesky
@@ -197,6 +198,7 @@ struct DeviceGraph {
     const int32_t* row_ptr;     // [Npf+1] adjacency of the block rows of S (for the mat-vec)
     const int32_t* row_col;     // [..] column block
     const int32_t* row_blk;     // [..] stored block id * 2 + transposed
+    const int32_t* blk_slot;    // [n_blk] k_pcg_cu windows: position of stored block (i, j) in block row i's list | position in block row j's list << 8
     const int32_t* band_code;   // [Npf][band_B + 1] stored block id of S(I - d, I) (the lower block (I, I - d) is its transpose), -1: no such block
     const int32_t* pcg1_code;   // [Npf][Npf] stored block id * 2 + transposed of S(i, a), -1: no block — only for <= 64 free poses with PCG
                                 //   (k_pcg1: one wavefront per block row); nullptr otherwise
@@ -221,6 +223,8 @@ struct DeviceGraph {
 
     // ---- per trial ----
     double* S;                  // [n_blk][36]
+    double* S_rows;             // k_pcg_cu windows: S once more, BY SCALAR ROW — entry c of the k-th block of scalar row t at [(6 k + c) cu_T + t]: a
+                                // wavefront's load of one entry is 512 contiguous bytes (k_schur_finalize writes both; unused slots stay zero from the upload)
     double* bs;                 // [Npf][6]
     double* Minv;               // [Npf][36]
     double* x;                  // [Npf][6]   pose increment

@@ -1748,6 +1748,11 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
                 base += L.odo_blk[120 * (size_t)(code >> 1) + 72 + ((code & 1) ? (c * 6 + r) : lane)];
             }
             if (PUB) st_pub(g.S + 36 * (size_t)b + lane, base - part); else g.S[36 * (size_t)b + lane] = base - part;
+            if (!PUB && g.pcg_cu) {                           // k_pcg_cu reads S by scalar row: entry (r, c) belongs to row 6 i + r and, transposed, to row 6 j + c
+                const int sl = g.blk_slot[b];
+                g.S_rows[((size_t)(sl & 255) * 6 + c) * g.cu_T + 6 * i + r] = base - part;
+                g.S_rows[((size_t)(sl >> 8) * 6 + r) * g.cu_T + 6 * j + c] = base - part;
+            }
         }
         if (PUB) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1763,6 +1768,7 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     if (lane < 36) {
         val = pin ? (r == c ? 1.0 : 0.0) : (hv + (r == c ? damp_of(g, lambda, hv, g.s2p, 6 * (size_t)i + r) : 0.0) - part);
         if (PUB) st_pub(g.S + 36 * (size_t)b + lane, val); else g.S[36 * (size_t)b + lane] = val;
+        if (!PUB && g.pcg_cu) g.S_rows[((size_t)(g.blk_slot[b] & 255) * 6 + c) * g.cu_T + 6 * i + r] = val;
         g.Hpp[36 * (size_t)i + lane] = hv;
     } else if (lane < 42) {
         g.bp[6 * (size_t)i + (lane - 36)] = hv;
@@ -2441,131 +2447,162 @@ __global__ __launch_bounds__(64) void k_pcg1(const Src src) {
 
 // ---- K6, reduced systems that fit ONE compute unit: no cross-workgroup hand-off at all
 // A hand-off between workgroups costs ~1.5 us per PCG iteration on this chip whatever the placement (stamped in k_pcg1: the same on
-// one XCD through its L2 as across XCDs, profiles/r02_pcg1_gather_variants.log) — two thirds of an iteration.  When every block row
-// of S has at most 3 * CU_K blocks and 3 threads per scalar row fit one workgroup (<= 56 free poses), ONE workgroup solves the whole
-// system: thread (row, h) keeps a third of its row's non-zeros in REGISTERS (CU_K six-value slices, transposed blocks read
-// transposed once), d lives in LDS, and an iteration is CU_K x 6 multiply-adds per thread, two shuffles to join the thirds, and
-// two workgroup reductions (wave butterfly + per-wave partials in fixed order) separated by barriers.  Same recurrences, tolerance
-// and residual carry-over as k_pcg ([g2o-upstream] LinearSolverPCG::solve); S, b_s and Minv come from k_schur_finalize.
-constexpr int CU_K = 7;                // blocks per thread: block rows of up to 21 blocks (C2 / C3: 19)
-constexpr int CU_KR = 6;               // ... of which in registers; the last slice lives in LDS (the kernel runs at 128 VGPRs: 16 waves per CU)
-constexpr int CU_RPW = 21;             // scalar rows per wavefront (63 of its 64 lanes)
-constexpr int CU_MAX_N6 = 16 * CU_RPW; // 336 scalar rows = 56 free poses in 16 wavefronts
+// one XCD through its L2 as across XCDs, profiles/r02_pcg1_gather_variants.log) — half of a k_pcg1 iteration.  When the system has at
+// most 56 free poses and block rows of at most 21 blocks, ONE workgroup solves it, a THREAD PER SCALAR ROW (round 4): the thread keeps
+// its row of S — up to CU_KR blocks in registers, the rest in LDS slices it alone reads — and its row of Minv, d and r live in LDS, and
+// an iteration is one pass over the row, two workgroup sums and four barriers among five or six wavefronts.
+// Why a thread a row: one wavefront issues an instruction every 6-8 cycles whatever it is (profiles/r04_fp64_chain_micro.log), so
+// a kernel is as long as the longest instruction list on a SIMD.  Round 2's form (three threads a row, sixteen wavefronts) halved the
+// multiply-adds per thread but every wavefront paid the whole of the sums and barriers: 2.9 us an iteration of which 1.8 in the two
+// sums (profiles/r04_pcg_cu_stamps.log).  Same recurrences, tolerance and residual carry-over as k_pcg ([g2o-upstream]
+// LinearSolverPCG::solve); S, b_s and Minv come from k_schur_finalize.  Every sum has a fixed order.
+constexpr int CU_K = 21;               // blocks in a block row of S at most
+constexpr int CU_KR = 13;              // ... of which in registers (78 values); the others in LDS, [slice][c][thread]: conflict-free 8-byte reads
+constexpr int CU_MAX_N6 = 336;         // 56 free poses = six wavefronts
+constexpr int CU_MAX_T = 384;
+size_t pcg_cu_lds_bytes(const int npf, const int max_row) {
+    const int T = (6 * npf + 63) / 64 * 64;
+    return (size_t)std::max(0, max_row - CU_KR) * 6 * T * sizeof(double);
+}
 
 template <class Src>
-__global__ __launch_bounds__(1024) void k_pcg_cu(const Src src) {
+__global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
     const DeviceGraph& g = graph_of(src);
     LmState* st = state_of(src, g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n6 = 6 * g.Npf, T = (n6 + 63) & ~63;            // (a batched launch may be wider than this window: its own width lays the slices out)
+    const bool act = tid < n6;
+    const int row = act ? tid : 0, bi = row / 6, r6 = row - 6 * bi;
+    // (the first loads of the set-up go out with the gate's: a gated-off launch reads a few words for nothing)
+    const int rb = g.row_ptr[bi], nb = g.row_ptr[bi + 1] - rb;
+    double Mv[6];
+    {
+        const double2* M = reinterpret_cast<const double2*>(g.Minv + 36 * (size_t)bi + 6 * r6);
+        const double2 m0 = M[0], m1 = M[1], m2 = M[2];
+        Mv[0] = m0.x; Mv[1] = m0.y; Mv[2] = m1.x; Mv[3] = m1.y; Mv[4] = m2.x; Mv[5] = m2.y;
+    }
+    double rr = g.bs[row];
+    const double res_in = st->pcg_res_in;
     if (!(st->mode & MODE_TRIAL)) return;
+#ifdef VISFS_BA_STAMPS
+    __shared__ unsigned long long cstamp[64];
+#define CU_STAMP(slot) do { if (threadIdx.x == 0 && (slot) < 64) cstamp[(slot)] = wall_clock64(); } while (0)
+#else
+#define CU_STAMP(slot) do { } while (0)
+#endif
+    CU_STAMP(0);
+    extern __shared__ __attribute__((aligned(16))) double cu_slices[];      // [max_row - CU_KR][T][6]: a thread's slice is 48 contiguous bytes — three conflict-free 16-byte reads
     __shared__ __attribute__((aligned(16))) double sd[CU_MAX_N6 + 8], sr[CU_MAX_N6 + 8];
-    __shared__ __attribute__((aligned(16))) double sM[CU_MAX_N6 * 6];      // Minv rows
-    __shared__ double sPa[16], sPb[16];
-    __shared__ double sSl[(CU_K - CU_KR) * 6 * 1024];                       // [slice][c][thread]: conflict-free 8-byte reads
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const int n6 = 6 * g.Npf;
-    const int row = wave * CU_RPW + lane / 3, h = lane % 3;
-    const bool act = lane < 63 && row < n6;
-    const bool owner = act && h == 0;
-    const int bi = act ? row / 6 : 0, r6 = act ? row % 6 : 0;
-    // ---- set-up: this thread's third of row `row` of S (blocks h, h + 3, ... of the block row), the Minv row and b_s
-    double Sv[CU_K][6];
+    __shared__ __attribute__((aligned(16))) double sPa[8], sPb[8];
+    const int tslot = min(tid, T - 1);
+    if (tid < 8) { sPa[tid] = 0.0; sPb[tid] = 0.0; }          // (wavefronts a launch does not have add nothing)
+    // ---- set-up: the thread's row of S from S_rows — entry c of the row's k-th block is 8 bytes a lane, 512 contiguous bytes a
+    // wavefront (the 16-byte gathers out of the block-major S touched ~30 cache lines an instruction: 6 of the 7 us of the set-up,
+    // profiles/r04_pcg_cu_stamps.log); slots the row does not use were zeroed by the upload.  Nothing depends on the row's list but
+    // the column offsets: every load of the set-up is in flight at once.
+    const int nsl = max(0, g.pcg_max_row - CU_KR);            // LDS slices of this launch (uniform)
+    double Sv[CU_KR][6];
     int coff[CU_K];
     {
-        // every load below is unconditional (indices clamped into the row's list, values masked afterwards): 42 independent
-        // loads in flight per thread instead of a chain of predicated ones
-        const int rb = g.row_ptr[bi], nb = g.row_ptr[bi + 1] - rb;
-        int col[CU_K], code[CU_K];
+        const double* Sr = g.S_rows + min(tid, g.cu_T - 1);
+        const size_t NT = (size_t)g.cu_T;
 #pragma unroll
         for (int k = 0; k < CU_K; ++k) {
-            const int n = h + 3 * k, nc = n < nb ? n : nb - 1;          // (a free pose's block row holds at least its diagonal block)
-            col[k] = g.row_col[rb + nc]; code[k] = g.row_blk[rb + nc];
+            const int nc = k < nb ? k : nb - 1;               // (a free pose's block row holds at least its diagonal block)
+            coff[k] = g.row_col[rb + nc];
         }
 #pragma unroll
         for (int k = 0; k < CU_K; ++k) {
-            const double* Sb = g.S + 36 * (size_t)(code[k] >> 1);
-            const bool tr = (code[k] & 1) != 0;       // the stored block is (col, bi): its column r6 is this row
-            const int base = tr ? r6 : 6 * r6, step = tr ? 6 : 1;
+            if (k < CU_KR) {
+                const bool slot = k < g.pcg_max_row;          // (uniform: S_rows ends with the longest row's last slot)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) Sv[k][c] = Sb[base + step * c];
+                for (int c = 0; c < 6; ++c) { const double v = Sr[(6 * (size_t)(slot ? k : 0) + c) * NT]; Sv[k < CU_KR ? k : 0][c] = slot ? v : 0.0; }
+            } else if (k - CU_KR < nsl) {
+                double v[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] = Sr[(6 * (size_t)k + c) * NT];
+                if (tid < T) {
+                    double2* sl = reinterpret_cast<double2*>(cu_slices + ((size_t)(k - CU_KR) * T + tid) * 6);       // own writes, own reads: no barrier needed
+                    sl[0] = make_double2(v[0], v[1]); sl[1] = make_double2(v[2], v[3]); sl[2] = make_double2(v[4], v[5]);
+                }
+            }
+            coff[k] = (act && k < nb) ? 6 * coff[k] : 0;
         }
-#pragma unroll
-        for (int k = 0; k < CU_K; ++k) {
-            const bool has = act && (h + 3 * k) < nb;
-            coff[k] = has ? 6 * col[k] : 0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Sv[k][c] = has ? Sv[k][c] : 0.0;
-        }
-#pragma unroll
-        for (int k = CU_KR; k < CU_K; ++k)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) sSl[((k - CU_KR) * 6 + c) * 1024 + tid] = Sv[k][c];     // own writes, own reads: no barrier needed
     }
-    double rr = 0.0, dd = 0.0, xx = 0.0;
-    if (owner) {
-        rr = g.bs[row];
-        const double* M = g.Minv + 36 * (size_t)bi + 6 * r6;
+    if (!act) {
+        rr = 0.0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) sM[6 * row + c] = M[c];
-        sr[row] = rr;
+        for (int c = 0; c < 6; ++c) Mv[c] = 0.0;
     }
-    // sum over the workgroup, every thread gets it: wave butterfly, per-wave partials added in wave order (fixed)
+    double dd = 0.0, xx = 0.0;
+    if (act) sr[row] = rr;
+    // sum over the workgroup, every thread gets it: wave butterfly, then the eight per-wave partials (zeros for wavefronts that do not
+    // exist) read together and added in a fixed order — a loop over the launch's wave count read them one LDS round trip at a time
     auto wg_sum = [&](const double v, double* part) -> double {
         const double ws = wave_sum(v);
         if (lane == 0) part[wave] = ws;
         __syncthreads();
-        double t = part[0];
-        for (int w = 1; w < nw; ++w) t += part[w];
-        return t;
+        const double2* p2 = reinterpret_cast<const double2*>(part);
+        const double2 a = p2[0], b = p2[1], c = p2[2], d = p2[3];
+        return ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
     };
-    auto minv_row = [&]() -> double {                 // (Minv r)[row] from the LDS copies (own writes of sM; sr behind a barrier)
-        const double* m = sM + 6 * row; const double* rv = sr + 6 * bi;
-        return ((((m[0] * rv[0] + m[1] * rv[1]) + m[2] * rv[2]) + m[3] * rv[3]) + m[4] * rv[4]) + m[5] * rv[5];
+    auto minv_row = [&]() -> double {                 // (Minv r)[row]: r of the row's block from LDS (behind a barrier)
+        const double2* rv = reinterpret_cast<const double2*>(sr + 6 * bi);
+        const double2 a0 = rv[0], a1 = rv[1], a2 = rv[2];
+        return ((((Mv[0] * a0.x + Mv[1] * a0.y) + Mv[2] * a1.x) + Mv[3] * a1.y) + Mv[4] * a2.x) + Mv[5] * a2.y;
     };
     __syncthreads();
-    if (owner) dd = minv_row();
-    double dn = wg_sum(owner ? rr * dd : 0.0, sPa);
+    dd = minv_row();
+    double dn = wg_sum(rr * dd, sPa);
     double d0 = 1e-6 * dn;
-    {
-        const double res_in = st->pcg_res_in;
-        if (res_in > 0.0 && res_in > d0) d0 = res_in;
-    }
-    if (owner) sd[row] = dd;
+    if (res_in > 0.0 && res_in > d0) d0 = res_in;
+    if (act) sd[row] = dd;
     __syncthreads();
+    CU_STAMP(1);
     int iter = 0;
     while (true) {
         if (dn <= d0 || iter >= n6 || !(dn == dn)) break;
-        // ---- q = S d: a third of the row per thread, joined on the row's first lane
-        double acc = 0.0;
+        // ---- q = S d: the whole row on its thread, four partial sums (fixed association)
+        double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-        for (int k = 0; k < CU_K; ++k) {
-            const double* dv = sd + coff[k];
-            double sv[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) sv[c] = (k < CU_KR) ? Sv[k][c] : sSl[((k - CU_KR) * 6 + c) * 1024 + tid];
-            acc += ((((sv[0] * dv[0] + sv[1] * dv[1]) + sv[2] * dv[2]) + sv[3] * dv[3]) + sv[4] * dv[4]) + sv[5] * dv[5];
-            // (the kernel sits at its 128-register budget with the row slices resident: keep the LDS reads of at most two slices
-            // in flight instead of letting all seven be hoisted, which spilled slices of S to scratch inside this loop)
-            if (k & 1) asm volatile("" ::: "memory");
+        for (int k = 0; k < CU_KR; ++k) {
+            const double2* dv = reinterpret_cast<const double2*>(sd + coff[k]);
+            const double2 a0 = dv[0], a1 = dv[1], a2 = dv[2];
+            acc[k & 3] += ((((Sv[k][0] * a0.x + Sv[k][1] * a0.y) + Sv[k][2] * a1.x) + Sv[k][3] * a1.y) + Sv[k][4] * a2.x) + Sv[k][5] * a2.y;
         }
-        const double a1 = __shfl_down(acc, 1, 64), a2 = __shfl_down(acc, 2, 64);
-        const double q = (acc + a1) + a2;             // meaningful on h == 0
-        const double dq = wg_sum(owner ? dd * q : 0.0, sPb);
+#pragma unroll
+        for (int k = CU_KR; k < CU_K; ++k) {
+            if (k - CU_KR < nsl) {                            // (uniform)
+                const double2* dv = reinterpret_cast<const double2*>(sd + coff[k]);
+                const double2 a0 = dv[0], a1 = dv[1], a2 = dv[2];
+                const double2* sl = reinterpret_cast<const double2*>(cu_slices + ((size_t)(k - CU_KR) * T + tslot) * 6);
+                const double2 s0 = sl[0], s1 = sl[1], s2 = sl[2];
+                acc[k & 3] += ((((s0.x * a0.x + s0.y * a0.y) + s1.x * a1.x) + s1.y * a1.y) + s2.x * a2.x) + s2.y * a2.y;
+            }
+        }
+        const double q = act ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0;
+        if (iter < 8) CU_STAMP(2 + 4 * iter);
+        const double dq = wg_sum(dd * q, sPb);
+        if (iter < 8) CU_STAMP(3 + 4 * iter);
         const double alpha = dn / dq;
-        if (owner) { xx += alpha * dd; rr -= alpha * q; sr[row] = rr; }
+        xx += alpha * dd; rr -= alpha * q;
+        if (act) sr[row] = rr;
         __syncthreads();
-        double z = 0.0;
-        if (owner) z = minv_row();
-        const double dnn = wg_sum(owner ? rr * z : 0.0, sPa);
+        const double z = minv_row();
+        if (iter < 8) CU_STAMP(4 + 4 * iter);
+        const double dnn = wg_sum(rr * z, sPa);
         const double beta = dnn / dn;
-        if (owner) { dd = z + beta * dd; sd[row] = dd; }
+        dd = z + beta * dd;
+        if (act) sd[row] = dd;
         __syncthreads();
+        if (iter < 8) CU_STAMP(5 + 4 * iter);
         dn = dnn;
         iter += 1;
     }
     // x is final: K8 (oplus) by the first row of every block; thread 0 publishes the statistics
-    if (owner) { g.x[row] = xx; sr[row] = xx; }
+    if (act) { g.x[row] = xx; sr[row] = xx; }
     __syncthreads();
-    if (owner && r6 == 0) {
+    if (act && r6 == 0) {
         double dx[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) dx[c] = sr[row + c];
@@ -2579,6 +2616,12 @@ __global__ __launch_bounds__(1024) void k_pcg_cu(const Src src) {
         st->pcg_total += iter;
         if (iter > st->pcg_max) st->pcg_max = iter;
     }
+#ifdef VISFS_BA_STAMPS
+    CU_STAMP(40);
+    if (tid == 0) cstamp[41] = (unsigned long long)iter;
+    __syncthreads();
+    if (tid < 64) g.stamps[tid] = cstamp[tid];
+#endif
 }
 
 // ================================================================= K6 (direct): blocked Cholesky of the reduced camera matrix
@@ -4668,7 +4711,7 @@ static void launch_schur_finalize_src(const Src& src, const LaunchDims& d, int B
 }
 template <class Src>
 static void launch_pcg_src(const Src& src, const LaunchDims& d, int B, hipStream_t s) {
-    if (d.pcg_cu) { TIMED_LAUNCH((k_pcg_cu<Src>), dim3(1, B), dim3(64 * ((6 * d.pcg_rows + CU_RPW - 1) / CU_RPW)), 0, s, src); return; }
+    if (d.pcg_cu) { ensure_lds(k_pcg_cu<Src>, (size_t)d.pcg_lds); TIMED_LAUNCH((k_pcg_cu<Src>), dim3(1, B), dim3((6 * d.pcg_rows + 63) / 64 * 64), (size_t)d.pcg_lds, s, src); return; }
     if (d.pcg_one_wave) {
         // default: variant 1 (six 16-byte loads per sweep, one sweep in flight) — 21.4 us per C2 solve and 65.6 k it/s in 16-window
         // batches against 21.2-25.5 / 59.4 k for variant 0 and 20.9 / 61.6 k for variant 2 (profiles/r02_pcg1_gather_variants.log)
@@ -4930,7 +4973,7 @@ bool small_path_fits(const DeviceGraph& g) {
     return g.Np <= SM_MAX_POSES && 6 * g.Npf <= SM_MAX_N6 && g.Npf >= 1 && 4 * g.n_chunks <= SM_MAX_WCHUNKS && g.No <= SM_MAX_OBS && g.n_sch <= SM_MAX_SCH && g.sch_chunk == SCH_CHUNK;
 }
 
-bool pcg_cu_fits(int npf, int max_row) { return npf >= 1 && 6 * npf <= CU_MAX_N6 && max_row <= 3 * CU_K; }
+bool pcg_cu_fits(int npf, int max_row) { return npf >= 1 && 6 * npf <= CU_MAX_N6 && max_row <= CU_K && pcg_cu_lds_bytes(npf, max_row) <= 140 * 1024; }
 
 bool small_solve_fits(const DeviceGraph& g) { return g.Npf >= 1 && 6 * g.Npf <= SM_MAX_N6; }
 

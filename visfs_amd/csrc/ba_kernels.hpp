@@ -41,6 +41,7 @@ void launch_phase_end(const DeviceGraph& g, int phase_just_done, int mark, int n
 size_t band_lds_bytes(int npf, int B, int rows);                       // dynamic LDS of the banded direct solver (k_band_chol) with `rows` block rows resident
 constexpr int BAND_LDS_BUDGET = 156 * 1024;
 bool band_plan(int npf, int B, int* rows, int* lds_bytes);             // false: the band is too wide for k_band_chol (dense blocked Cholesky instead)
+size_t pcg_cu_lds_bytes(int npf, int max_row);                       // dynamic LDS of k_pcg_cu: the slices of S that do not fit the registers
 bool pcg_cu_fits(int npf, int max_row);                               // the reduced system fits the single-workgroup PCG (k_pcg_cu)
 bool small_solve_fits(const DeviceGraph& g);                         // 6 Npf <= 64: S is finalised and solved by one workgroup
 void launch_small_solve(const DeviceGraph& g, int solver, hipStream_t s);   // k_schur_finalize + solver + K8 in one launch
