@@ -182,6 +182,69 @@ def test_the_three_pcg_kernels_agree(olib, monkeypatch, cfg):
         assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10, name
 
 
+@pytest.mark.parametrize("n_kf", [12, 33, 57])
+def test_single_workgroup_pcg_at_the_edges_of_its_range(olib, monkeypatch, n_kf):
+    """k_pcg_cu, a thread per scalar row (round 4): 11 free poses (two wavefronts, every block in registers), 32 (exactly three full
+    wavefronts: no idle lane to hide a slip), 56 (the most it takes: six wavefronts, block rows beyond the register part in LDS slices).
+    Against the four-wave kernel: same iteration counts, results equal to rounding."""
+    from test_gpu_parity import _solve_in_mode
+    w = synth.make_window("custom", n_kf=n_kf, n_lm=40 * n_kf, n_obs=400 * n_kf, seed=400 + n_kf)
+    runs = {}
+    for name, env in (("cu", dict(VISFS_BA_PCG_CU="1")), ("four_wave", dict(VISFS_BA_PCG_CU="0", VISFS_BA_PCG1="0"))):
+        info, rc, st, out = _solve_in_mode(monkeypatch, w, env, iterations=20, solver=2)
+        assert rc == abi.OK
+        assert info["solver_kernel"] == (4 if name == "cu" else 2), (name, info["solver_kernel"])
+        runs[name] = (st, out)
+    (st0, out0), (st1, out1) = runs["four_wave"], runs["cu"]
+    assert list(st0.iterations_run) == list(st1.iterations_run) and list(st0.trials_run) == list(st1.trials_run)
+    assert st0.pcg_iterations == st1.pcg_iterations
+    assert np.array_equal(out0[2], out1[2])
+    assert rel_err(out1[0], out0[0]) < 1e-10 and rel_err(out1[1], out0[1]) < 1e-10
+
+
+def test_single_workgroup_pcg_in_a_batch_of_unequal_windows(olib, monkeypatch):
+    """One batched k_pcg_cu launch is as wide as its widest member and carries the LDS of its hungriest: members of 13, 29, 49 and 56 free
+    poses (different wavefront counts, with and without LDS slices) each get the bytes of their own solve as a batch of one."""
+    from visfs_amd import backend
+    monkeypatch.setenv("VISFS_BA_PCG_CU", "1")
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("custom", n_kf=k, n_lm=40 * k, n_obs=400 * k, seed=500 + k) for k in (14, 57, 30, 50, 14, 57)]
+    s = backend.Solver(prm)
+    singles = [s.solve_batch([abi.WindowBuffers(w)])[0] for w in ws]
+    got = s.solve_batch([abi.WindowBuffers(w) for w in ws])
+    s.close()
+    for a, b in zip(singles, got):
+        assert a.struct.status == b.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and a.outliers() == b.outliers()
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run)
+
+
+@pytest.mark.parametrize("solver", [2, 0])
+def test_a_lone_mid_size_window_is_chunked_in_two_passes_and_says_so(olib, monkeypatch, solver):
+    """The one way a window's bits depend on how it was submitted (ba_api.cpp, sch_passes): a window of 1 024 .. 6 144 Schur chunks solved
+    through the single-window entry points adds two co-observation pairs per lane before the wave's reduction (+4-5 % for a lone C2, -4..-7 %
+    inside a batched launch: profiles/r01_v8_schur_passes.log), a batch member one.  The two solves agree to rounding with the same LM
+    trajectory; under VISFS_BA_SCH_PASSES=1 they are the same bytes.  (Batches of any size, cut or sharded any way, always agree with the
+    batch of one: test_a_window_s_result_never_depends_on_the_size_of_its_batch, test_c5_*.)"""
+    from visfs_amd import backend
+    prm = abi.default_params(iterations=10, solver=solver)
+    w = synth.make_window("custom", n_kf=50, n_lm=2000, n_obs=20000, seed=550)
+    def both():
+        s = backend.Solver(prm)
+        rc, a = s.solve_window(abi.WindowBuffers(w))
+        b = s.solve_batch([abi.WindowBuffers(w)])[0]
+        s.close()
+        assert rc == b.struct.status == abi.OK
+        assert list(a.struct.iterations_run) == list(b.struct.iterations_run) and a.outliers() == b.outliers()
+        return a, b
+    a, b = both()
+    et, er = synth.pose_errors(b.pose_Twr_out[:50], a.pose_Twr_out[:50])
+    assert et < 1e-10 and er < 1e-10
+    monkeypatch.setenv("VISFS_BA_SCH_PASSES", "1")
+    a, b = both()
+    assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out)
+
+
 def test_batch_sharded_over_handles_equals_one_handle(olib):
     """visfs_ba_solve_batch_sharded: config 5 inside one process — the windows in contiguous blocks over several handles (one per GPU
     on a node; two on this one-GPU box), each block solved by visfs_ba_solve_batch on its own host thread.  Results are those of one
@@ -207,8 +270,8 @@ def test_batch_sharded_over_handles_equals_one_handle(olib):
 
 def test_a_window_s_result_never_depends_on_the_size_of_its_batch(olib, monkeypatch):
     """the PCG kernel of a window must not follow the number of OTHER windows submitted with it.  A 16-window batch, its two
-    sharded halves and sixteen single solves give the same bytes.  k_pcg_cu (the whole PCG in one workgroup: +3..+10 % throughput
-    from 16 C2 windows on, mat-vec sums in a different order) is opt-in (VISFS_BA_PCG_CU=1): it then equals single-window solves to
+    sharded halves and sixteen single solves give the same bytes.  k_pcg_cu (the whole PCG in one workgroup: +7 % throughput
+    at 8 C2 windows, +16 % at 16 — profiles/r04_pcg_cu_ab.log —, mat-vec sums in a different order) is opt-in (VISFS_BA_PCG_CU=1): it then equals single-window solves to
     rounding, with identical iteration counts and outlier sets."""
     from visfs_amd import backend
     prm = abi.default_params(iterations=10, solver=2)

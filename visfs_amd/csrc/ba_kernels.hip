@@ -2465,6 +2465,21 @@ size_t pcg_cu_lds_bytes(const int npf, const int max_row) {
     return (size_t)std::max(0, max_row - CU_KR) * 6 * T * sizeof(double);
 }
 
+// a0 b0 + a1 b1 + ... + a5 b5 as ONE stated chain of fused multiply-adds.  Written out because `a0 * b0 + a1 * b1` under
+// -ffp-contract=fast may fuse EITHER product (the other is rounded on its own), and the One / Many instantiations of a kernel did
+// choose differently: a batch member differed from its single-window solve in the last bit (test_single_workgroup_pcg_in_a_batch_of_
+// unequal_windows).  Every bit-identity claim of this file rests on sums whose association AND fusion are spelled out.
+__device__ __forceinline__ double dot6(const double a0, const double a1, const double a2, const double a3, const double a4, const double a5,
+                                       const double b0, const double b1, const double b2, const double b3, const double b4, const double b5) {
+    double v = a0 * b0;
+    v = __builtin_fma(a1, b1, v); v = __builtin_fma(a2, b2, v); v = __builtin_fma(a3, b3, v); v = __builtin_fma(a4, b4, v); v = __builtin_fma(a5, b5, v);
+    return v;
+}
+// ... and as three chains of two, joined in a fixed order (the banded Cholesky's block updates: a shorter dependent chain)
+__device__ __forceinline__ double dot6_pairs(const double* __restrict__ a, const double* __restrict__ b) {
+    const double t0 = __builtin_fma(a[1], b[1], a[0] * b[0]), t1 = __builtin_fma(a[3], b[3], a[2] * b[2]), t2 = __builtin_fma(a[5], b[5], a[4] * b[4]);
+    return (t0 + t1) + t2;
+}
 template <class Src>
 __global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
     const DeviceGraph& g = graph_of(src);
@@ -2549,7 +2564,7 @@ __global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
     auto minv_row = [&]() -> double {                 // (Minv r)[row]: r of the row's block from LDS (behind a barrier)
         const double2* rv = reinterpret_cast<const double2*>(sr + 6 * bi);
         const double2 a0 = rv[0], a1 = rv[1], a2 = rv[2];
-        return ((((Mv[0] * a0.x + Mv[1] * a0.y) + Mv[2] * a1.x) + Mv[3] * a1.y) + Mv[4] * a2.x) + Mv[5] * a2.y;
+        return dot6(Mv[0], Mv[1], Mv[2], Mv[3], Mv[4], Mv[5], a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
     };
     __syncthreads();
     dd = minv_row();
@@ -2568,7 +2583,7 @@ __global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
         for (int k = 0; k < CU_KR; ++k) {
             const double2* dv = reinterpret_cast<const double2*>(sd + coff[k]);
             const double2 a0 = dv[0], a1 = dv[1], a2 = dv[2];
-            acc[k & 3] += ((((Sv[k][0] * a0.x + Sv[k][1] * a0.y) + Sv[k][2] * a1.x) + Sv[k][3] * a1.y) + Sv[k][4] * a2.x) + Sv[k][5] * a2.y;
+            acc[k & 3] += dot6(Sv[k][0], Sv[k][1], Sv[k][2], Sv[k][3], Sv[k][4], Sv[k][5], a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
         }
 #pragma unroll
         for (int k = CU_KR; k < CU_K; ++k) {
@@ -2577,7 +2592,7 @@ __global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
                 const double2 a0 = dv[0], a1 = dv[1], a2 = dv[2];
                 const double2* sl = reinterpret_cast<const double2*>(cu_slices + ((size_t)(k - CU_KR) * T + tslot) * 6);
                 const double2 s0 = sl[0], s1 = sl[1], s2 = sl[2];
-                acc[k & 3] += ((((s0.x * a0.x + s0.y * a0.y) + s1.x * a1.x) + s1.y * a1.y) + s2.x * a2.x) + s2.y * a2.y;
+                acc[k & 3] += dot6(s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
             }
         }
         const double q = act ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0;
@@ -2585,14 +2600,14 @@ __global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
         const double dq = wg_sum(dd * q, sPb);
         if (iter < 8) CU_STAMP(3 + 4 * iter);
         const double alpha = dn / dq;
-        xx += alpha * dd; rr -= alpha * q;
+        xx = __builtin_fma(alpha, dd, xx); rr = __builtin_fma(-alpha, q, rr);
         if (act) sr[row] = rr;
         __syncthreads();
         const double z = minv_row();
         if (iter < 8) CU_STAMP(4 + 4 * iter);
         const double dnn = wg_sum(rr * z, sPa);
         const double beta = dnn / dn;
-        dd = z + beta * dd;
+        dd = __builtin_fma(beta, dd, z);
         if (act) sd[row] = dd;
         __syncthreads();
         if (iter < 8) CU_STAMP(5 + 4 * iter);
@@ -3148,7 +3163,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
         const double* l = o.wm; const double* gj = o.wj;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            C[c] = o.cv[c] - (((l[0] * gj[6 * c] + l[1] * gj[6 * c + 1]) + (l[2] * gj[6 * c + 2] + l[3] * gj[6 * c + 3])) + (l[4] * gj[6 * c + 4] + l[5] * gj[6 * c + 5]));
+            C[c] = o.cv[c] - dot6_pairs(l, gj + 6 * c);
     };
     // wave 0: the lower triangle of the pivot block at ring row kr into registers (issued before the barrier that ends half 1: the block's
     // last update was this wave's own), then D_k = C_k C_k^T (every lane redundantly); the packed factor replaces the head of the block,
@@ -3278,7 +3293,7 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const double* l = wm + 6 * r; const double* gj = wj + 6 * c;
-                        C[6 * r + c] = cv[3 * r + c] - (((l[0] * gj[0] + l[1] * gj[1]) + (l[2] * gj[2] + l[3] * gj[3])) + (l[4] * gj[4] + l[5] * gj[5]));
+                        C[6 * r + c] = cv[3 * r + c] - dot6_pairs(l, gj);
                     }
             }
 #ifdef VISFS_BA_STAMPS
