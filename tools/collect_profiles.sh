@@ -5,7 +5,7 @@
 # PMC passes (separate runs, --kernel-trace only) and three SQ counter passes.  Outputs go to gpurun_out/<tag>_*; copy what should be
 # judged into profiles/.   usage: tools/collect_profiles.sh r03_v1
 set -e -o pipefail
-TAG=${1:-r04_v1}
+TAG=${1:-r04_v2}
 OUT=$PWD/gpurun_out
 RAW=/tmp/visfs_prof_$TAG            # rocprofv3's raw traces (hundreds of MB): only summaries travel back (gpurun merges <= 64 MiB of gpurun_out/)
 rm -rf "$RAW"; mkdir -p "$OUT" "$RAW"
@@ -33,6 +33,11 @@ timeout -k 10 300 python3 bench.py --config WB --solver 0 --steps 20 --warmup 3 
 step "batches on one GPU"
 for B in 8 16; do
   timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu $B --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x$B.json" 2>> "$OUT/${TAG}_c2_bench.err"
+done
+step "the single-workgroup PCG (opt-in): one window and batches"
+VISFS_BA_PCG_CU=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --config5 off > "$OUT/${TAG}_bench_C2_pcg_cu.json" 2>> "$OUT/${TAG}_c2_bench.err"
+for B in 8 16; do
+  VISFS_BA_PCG_CU=1 timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu $B --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x${B}_pcg_cu.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
 step "per-frame call path"
 timeout -k 10 300 python3 tools/e2e_breakdown.py > "$OUT/${TAG}_e2e_breakdown.log" 2>&1
