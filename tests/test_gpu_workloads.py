@@ -396,6 +396,12 @@ def test_banded_cholesky_on_odd_shapes(olib):
     for w, kw in ((ragged_window(seed=7), {}), (hard_window(seed=5), {}), (synth.make_window("C3", n_kf=24, n_lm=400, n_obs=3200), {})):
         ox, gx, _, _ = _direct_trial(olib, w, {"VISFS_BA_BAND": "1", "VISFS_BA_SMALL_SOLVE": "0"}, iterations=10, solver=0, **kw)
         assert rel_err(gx, ox) < 1e-9
+    # tracks of 16 key-frames: block half-bandwidth 15 — the trailing update runs several rounds of tiles per thread and the backward
+    # substitution takes the LDS form (more than ten blocks per row do not fit one wavefront's register window); resident and streaming
+    w = synth.make_window("custom", n_kf=30, n_lm=200, n_obs=3200, seed=12)
+    for env in ({"VISFS_BA_BAND": "1"}, {"VISFS_BA_BAND": "1", "VISFS_BA_BAND_ROWS": "19"}):
+        ox, gx, _, _ = _direct_trial(olib, w, env, iterations=10, solver=0)
+        assert rel_err(gx, ox) < 1e-9
     # a streaming window that is shorter than the band allows at the bottom of the matrix
     w = synth.make_window("custom", n_kf=40, n_lm=600, n_obs=6000, seed=11)
     ox, gx, _, _ = _direct_trial(olib, w, {"VISFS_BA_BAND": "1", "VISFS_BA_BAND_ROWS": "12"}, iterations=10, solver=0)
