@@ -3061,14 +3061,19 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
     __syncthreads();
     {
         const int total = nslots0 * 18;                        // double2 elements: (q, q + 1) of a block never straddle two blocks
-        constexpr int U = 12;
+        // every load unconditional (element and block id clamped, the value masked afterwards): the block ids of a pass are read from LDS
+        // together, then all its global loads are in flight at once — a resident C2 band is ONE pass of 35 loads per thread (predicated
+        // loads behind their own LDS read of the block id were twelve serial round trips a pass, three passes: 6.8 us of the kernel)
+        constexpr int U = 36;
         for (int t0 = tid; t0 < total; t0 += BAND_T * U) {
             double2 v[U];
+            int bid[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int t = min(t0 + BAND_T * u, total - 1); bid[u] = scode[t / 18]; }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + BAND_T * u;
-                v[u] = make_double2(0.0, 0.0);
-                if (t < total) { const int sl = t / 18, h = t - 18 * sl, b = scode[sl]; if (b >= 0) v[u] = reinterpret_cast<const double2*>(g.S + 36 * (size_t)b)[h]; }
+                const int t = min(t0 + BAND_T * u, total - 1), h = t - 18 * (t / 18);
+                v[u] = reinterpret_cast<const double2*>(g.S + 36 * (size_t)max(bid[u], 0))[h];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -3076,7 +3081,8 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
                 if (t < total) {
                     const int sl = t / 18, h = t - 18 * sl, q = 2 * h, r0 = q / 6, c0 = q - 6 * r0;     // stored entry (r0, c0) and (r0, c0 + 1)
                     double* dst = ring + 36 * (size_t)sl;
-                    dst[6 * c0 + r0] = v[u].x; dst[6 * (c0 + 1) + r0] = v[u].y;                        // transposed
+                    const bool has = bid[u] >= 0;
+                    dst[6 * c0 + r0] = has ? v[u].x : 0.0; dst[6 * (c0 + 1) + r0] = has ? v[u].y : 0.0;      // transposed
                 }
             }
         }
@@ -3384,7 +3390,51 @@ __global__ __launch_bounds__(BAND_T) void k_band_chol(const Src src) {
             __syncthreads();
             if (k1 == Npf) BAND_STAMP(114);
         }
-        if (wave == 0 && fast_bwd) {
+        if (wave == 0 && fast_bwd && resident && W == 10) {
+            // The chain below for the band every BASELINE window has (ten blocks per row), whole factor resident: one PERIOD of the slot
+            // rotation unrolled, so that the lane a step reads, the lanes that retire and the pointer steps are constants — of the ~55
+            // instructions of a generic step 33 were such bookkeeping (215 ns a step; one wavefront: an instruction per 6-8 cycles).
+            // Block j sits in slot (j + shift) mod 10 with the last block row in slot 9.
+            const int cc = lane % 6, slot = (lane / 6) % 10;      // (lanes 60 .. 63 shadow slot 0: same loads, same sums, the same stores)
+            {
+                const int jm = Npf - 1 - (9 - slot);                // slot s holds block Npf - 10 + s at the start
+                zreg = jm >= 0 ? cvec[6 * jm + cc] : 0.0;
+            }
+            int k = Npf - 1;
+            // this lane's column of block (k, k - m), m = (9 - slot) at the first step (m == 0: the row's own block — values unused)
+            const double* src = ring + (size_t)k * rowsz + 36 * ((9 - slot + 10) % 10) + cc;
+            const double* zsrc = cvec + cc;
+            double Lb[2][6], zb[2];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) Lb[0][rr] = src[6 * rr];
+            zb[0] = zsrc[6 * max(k - 10, 0)];
+            bool more = true;
+            while (more) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int ks = 9 - i;                           // (a constant once unrolled) the slot of block k
+                    const int cur = i & 1, nxt = cur ^ 1;
+                    // the next step's operands, off the chain: m steps down with k, the retiring slot restarts at m = 9
+                    const double* srcn = src - (rowsz + 36) + (slot == ks ? rowsz : 0);
+                    {
+                        const double* sp = k > 0 ? srcn : src;      // (row -1 does not exist: re-read this one, unused)
+#pragma unroll
+                        for (int rr = 0; rr < 6; ++rr) Lb[nxt][rr] = sp[6 * rr];
+                        zb[nxt] = zsrc[6 * max(k - 11, 0)];
+                    }
+                    double uk[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) uk[c] = readlane_f64(zreg, 6 * ks + c);
+                    double zn = zreg;
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) zn -= Lb[cur][rr] * uk[rr];
+                    if (slot == ks) cvec[6 * k + cc] = zreg;       // u_k
+                    zreg = slot == ks ? zb[cur] : zn;
+                    src = srcn;
+                    if (--k < 0) { more = false; break; }
+                }
+            }
+        } else if (wave == 0 && fast_bwd) {
             // Block j's six accumulators live in lanes 6 (j mod (B + 1)) + cc for as long as rows still reach it (rows j + 1 .. j + B): the
             // chain of a step is twelve v_readlane (u_k to every lane) and six multiply-adds — no LDS round trip, no triangular solve.
             // One wavefront issues an instruction every ~6 cycles whatever it is: the step is as long as its instruction list, so
