@@ -315,7 +315,7 @@ typedef struct visfs_ba_graph_info {
     int32_t solver_kernel;        /* which kernel solves the reduced system (the symbol a kernel trace shows for the VISFS_BA_K_PCG / _DIRECT class):
                                    * 1 k_pcg1 (PCG, one wavefront per block row), 2 k_pcg (PCG, four waves per row), 3 k_pcg, several rows per
                                    * workgroup, 4 k_pcg_cu (PCG, one workgroup), 5 k_small_solve, 6 k_chol_* (blocked dense Cholesky),
-                                   * 7 k_band_chol (block-banded LDL^T factorisation in one workgroup) */
+                                   * 7 k_band_chol (block-banded Cholesky factorisation in one workgroup) */
     int32_t band_blocks;          /* direct solver: block half-bandwidth of S when k_band_chol serves the window, -1 otherwise */
     int32_t graph_replayed;       /* 1: the LAST visfs_ba_optimize of this resident graph ran as a hipGraph replay of its launch sequence (only
                                    * re-optimisations of the same resident graph are ever replayed; a per-frame visfs_ba_solve_window never is) */
