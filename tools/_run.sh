@@ -1,18 +1,10 @@
 set -o pipefail
-O=gpurun_out; mkdir -p $O; export PYTHONPATH=$PWD
-rm -f $O/r04_w_ab.log
-for rep in 1 2; do
-for V in v1 v2 v3; do
-  export VISFS_BA_LIB=$PWD/visfs_amd/lib/libvisfs_ba_hip_$V.so
-  echo "== $V" >> $O/r04_w_ab.log
-  timeout -k 10 200 python bench.py --solver 0 --steps 40 --warmup 5 --no-cpu-baseline --config5 off >> $O/r04_w_ab.log 2>&1
-  timeout -k 10 200 python bench.py --solver 0 --config C4 --steps 20 --warmup 3 --no-cpu-baseline --config5 off >> $O/r04_w_ab.log 2>&1
+O=$PWD/gpurun_out; mkdir -p $O; export PYTHONPATH=$PWD TMPDIR=/tmp
+ROOT=$PWD
+cd /tmp
+rocprofv3 -L 2>/dev/null | grep -i "icache\|SQC_" | head -20 > $O/r04_icache_counters_avail.log
+for CFG in PROD C2; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/ic_$CFG -o pmc -- python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --config5 off > /dev/null 2> $O/r04_icache_$CFG.err
+  python3 $ROOT/tools/pmc_summary.py $(find /tmp/ic_$CFG -name "*counter_collection.csv") > $O/r04_icache_$CFG.json 2>> $O/r04_icache_$CFG.err
 done
-done
-grep -h '"value"\|^==' $O/r04_w_ab.log | python -c "
-import sys, json
-for ln in sys.stdin:
-    if ln.startswith('=='): print(ln.strip()); continue
-    d = json.loads(ln); r = d.get('roofline') or {}
-    print(' ', d['config']['workload'][:4], 'value', d['value'], 'dom', r.get('kernel_symbol'), r.get('avg_launch_us'))
-"
+head -c 600 $O/r04_icache_counters_avail.log; tail -3 $O/r04_icache_PROD.err | cut -c1-300
