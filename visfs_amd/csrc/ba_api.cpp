@@ -817,6 +817,9 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.row_col = A.take<int32_t>(std::max<size_t>(row_col.size(), 1));
         g.row_blk = A.take<int32_t>(std::max<size_t>(row_blk.size(), 1));
         g.blk_slot = A.take<int32_t>(std::max(n_blk, 1));
+        g.fin_exp = A.take<int32_t>(std::max(n_blk, 1));
+        g.sch_blk = A.take<int32_t>(std::max(n_sch, 1));
+        g.diag_blk = A.take<int32_t>(std::max(Npf, 1));
         g.pcg1_code = pcg1 ? A.take<int32_t>((size_t)Npf * Npf) : nullptr;
         g.band_code = band_B >= 0 ? A.take<int32_t>(band_code.size()) : nullptr;
         g.run_desc = run_path ? A.take<int4>(rp.desc.size()) : nullptr;
@@ -870,6 +873,7 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         g.trial_part = A.take<double>((size_t)n_parts * 2);
         g.trial_gran = A.take<unsigned long long>((size_t)n_parts * 4);
         g.fin_flag = A.take<uint32_t>((size_t)std::max(n_blk, 1));
+        g.fin_cnt = A.take<uint32_t>((size_t)std::max(n_blk, 1));
         g.aux_part = A.take<double>((size_t)n_parts);
         g.dl_part = A.take<double>(ceres && prm.trust_region == 1 ? (size_t)n_parts * 4 : 1);
         g.s2l = A.take<double>((size_t)std::max(Nl, 1) * 3);
@@ -933,6 +937,16 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
         std::memcpy(const_cast<int32_t*>(hg.row_ptr), row_ptr.data(), (size_t)(Npf + 1) * 4);
         if (!row_col.empty()) { std::memcpy(const_cast<int32_t*>(hg.row_col), row_col.data(), row_col.size() * 4); std::memcpy(const_cast<int32_t*>(hg.row_blk), row_blk.data(), row_blk.size() * 4); }
         if (n_blk) std::memcpy(const_cast<int32_t*>(hg.blk_slot), blk_slot.data(), (size_t)n_blk * 4);
+        {
+            int32_t* fe = const_cast<int32_t*>(hg.fin_exp); int32_t* db = const_cast<int32_t*>(hg.diag_blk);
+            for (int b = 0; b < n_blk; ++b) {
+                const int a = blk_i[b];
+                const bool dgb = (a == blk_j[b]);
+                fe[b] = (blk_chunk_ptr[b + 1] - blk_chunk_ptr[b]) | ((dgb ? pose_chunk_ptr[a + 1] - pose_chunk_ptr[a] : 0) << 16);
+                if (dgb) db[a] = b;
+            }
+            if (n_sch) std::memcpy(const_cast<int32_t*>(hg.sch_blk), sch_blk.data(), (size_t)n_sch * 4);
+        }
         if (pcg1) std::memcpy(const_cast<int32_t*>(hg.pcg1_code), pcg1_code.data(), pcg1_code.size() * 4);
         if (band_B >= 0) std::memcpy(const_cast<int32_t*>(hg.band_code), band_code.data(), band_code.size() * 4);
         if (run_path) { std::memcpy(const_cast<int4*>(hg.run_desc), rp.desc.data(), rp.desc.size() * sizeof(int4)); std::memcpy(const_cast<int32_t*>(hg.run_k0), rp.k0.data(), rp.k0.size() * 4); }
@@ -954,7 +968,13 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     { const char* e = std::getenv("VISFS_BA_FIN_PCG"); const char* gv = std::getenv("VISFS_BA_PCG_GATHER");
       dg.fin_pcg = (pcg1 && !pcg_cu && !small_solve_fits_npf && (e && e[0] == '1') && !(gv && std::atoi(gv) != 1)) ? 1 : 0; }
     dg.n_runs = rp.n; dg.run_lr = rp.LR; dg.run_m = rp.M; dg.run_cap = rp.cap; dg.run_wmax = rp.wmax; dg.run_lds_bytes = (int32_t)rp.lds;
-    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; dg.pcg_cu = pcg_cu ? 1 : 0; dg.cu_T = cu_T; dg.pcg_lds_bytes = pcg_cu ? (int32_t)pcg_cu_lds_bytes(Npf, max_row) : (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
+    dg.n_sch = n_sch; dg.sch_chunk = sch_chunk; dg.pcg_lds_minv = lds_minv; dg.pcg_lds_srow = lds_srow; dg.pcg_max_row = max_row; dg.pcg_rows_per_wg = pcg_rpw; { // fin_arrive (opt-in, VISFS_BA_FIN_ARRIVE=1): needs every stored block to own at least one gather chunk (somebody has to arrive) and counts that fit 16 bits
+      const char* e = std::getenv("VISFS_BA_FIN_ARRIVE");
+      bool ok = e && e[0] == '1' && !w.batch_member && !ceres && !run_path && !small_solve_fits_npf && n_blk > 0;
+      for (int b = 0; ok && b < n_blk; ++b) ok = blk_chunk_ptr[b + 1] > blk_chunk_ptr[b] && blk_chunk_ptr[b + 1] - blk_chunk_ptr[b] < 65536;
+      for (int a = 0; ok && a < Npf; ++a) ok = pose_chunk_ptr[a + 1] - pose_chunk_ptr[a] < 32768;
+      dg.fin_arrive = ok ? 1 : 0; }
+    dg.pcg_cu = pcg_cu ? 1 : 0; dg.cu_T = cu_T; dg.pcg_lds_bytes = pcg_cu ? (int32_t)pcg_cu_lds_bytes(Npf, max_row) : (int32_t)pcg_lds; dg.chol_np = (int32_t)chol_np;
     dg.band_B = band_B; dg.band_rows = band_rows; dg.band_lds_bytes = band_lds;
     dg.fx = gr->fx; dg.fy = gr->fy; dg.cx = gr->cx; dg.cy = gr->cy; dg.bf = gr->bf;
     dg.stereo_baseline = opt.baseline;
@@ -1076,7 +1096,7 @@ void enqueue_unit(visfs_ba_handle* h, Workspace& w, bool first) {
     if (w.small_solve) { ProfScope p(w, solver == 2 ? VISFS_BA_K_PCG : VISFS_BA_K_DIRECT, true); launch_small_solve(w.g, solver, w.stream); }
     else {
         const bool fin_on_board = solver == 2 && w.g.fin_pcg && w.g.pcg1_code != nullptr && !w.g.pcg_cu;       // k_pcg1<FIN>: the finalisation rides on the PCG launch
-        if (!fin_on_board) { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }
+        if (!fin_on_board && !w.g.fin_arrive) { ProfScope p(w, VISFS_BA_K_SCHUR_FINALIZE, true); launch_schur_finalize(w.g, w.stream); }     // (fin_arrive: done inside k_schur_partial)
         if (solver == 2) { ProfScope p(w, VISFS_BA_K_PCG, true); launch_pcg(w.g, w.stream); }
         else { ProfScope p(w, VISFS_BA_K_DIRECT); launch_direct(w.g, w.stream); }
     }

@@ -233,6 +233,11 @@ struct DeviceGraph {
     uint32_t* fin_flag;         // [n_blk] fused finalisation + PCG launch (k_pcg1<FIN>): block b's S / b_s / Minv are complete when this holds the
                                 //   unit's tag (damped solves of this optimise call so far + 1); zeroed by k_reset
     int32_t fin_pcg;            // 1: k_schur_finalize rides as the prologue of the k_pcg1 launch (one launch less per damped solve)
+    uint32_t* fin_cnt;          // [n_blk] fin_arrive: arrivals at block b in the current launch of k_schur_partial (zero between launches)
+    const int32_t* fin_exp;     // [n_blk] ... how many to expect: gather chunks of b | pose-major chunks of its pose << 16 (diagonal blocks)
+    const int32_t* sch_blk;     // [n_sch] stored block of a gather chunk
+    const int32_t* diag_blk;    // [Npf]   stored block id of (a, a)
+    int32_t fin_arrive;         // 1: the LAST wavefront of k_schur_partial to arrive at a block finalises it (k_schur_finalize is not launched)
     double* dxl;                // [Nl][3]    landmark increment
     double* trial_part;         // [n_lin_a + 1][2]  (robust chi2 at trial state, scale contribution)
     // Optimizer/Framework=1: Jacobi scaling squared, fixed at iteration zero (k_ceres_lin_finalize): the damping of variable i is

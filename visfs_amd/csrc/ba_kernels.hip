@@ -267,13 +267,18 @@ __device__ __forceinline__ int upper_idx(int r, int c) { return r * 6 - (r * (r 
 
 // Entry q (< 36: Hpp(r,c); 36..41: b_p) of a free pose: fixed-order sum of its pose-major chunk partials [c0, c1)
 // and of the odometry edges incident to it (entries [o0, o1) of pose_odo).
+// (COH: the partials were written by other wavefronts of THIS launch — write-through stores — and are read past this CU's caches)
+__device__ __forceinline__ double ld_coherent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool COH = false>
 __device__ __forceinline__ double hpp_entry_r(const DeviceGraph& g, const LinBuf& L, int q, int c0, int c1, int o0, int o1) {
     double v = 0.0;
     if (q < 36) {
         const int r = q / 6, c = q % 6;
         const int u = r <= c ? upper_idx(r, c) : upper_idx(c, r);
 #pragma unroll 4
-        for (int ch = c0; ch < c1; ++ch) v += L.hpp_part[27 * (size_t)ch + u];
+        for (int ch = c0; ch < c1; ++ch) v += COH ? ld_coherent(L.hpp_part + 27 * (size_t)ch + u) : L.hpp_part[27 * (size_t)ch + u];
         for (int n = o0; n < o1; ++n) {
             const int code = g.pose_odo[n];
             v += L.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 36 : 0) + q];
@@ -281,7 +286,7 @@ __device__ __forceinline__ double hpp_entry_r(const DeviceGraph& g, const LinBuf
     } else {
         const int r = q - 36;
 #pragma unroll 4
-        for (int ch = c0; ch < c1; ++ch) v += L.hpp_part[27 * (size_t)ch + 21 + r];
+        for (int ch = c0; ch < c1; ++ch) v += COH ? ld_coherent(L.hpp_part + 27 * (size_t)ch + 21 + r) : L.hpp_part[27 * (size_t)ch + 21 + r];
         for (int n = o0; n < o1; ++n) {
             const int code = g.pose_odo[n];
             v += L.odo_blk[120 * (size_t)(code >> 1) + ((code & 1) ? 114 : 108) + r];
@@ -1287,6 +1292,10 @@ __device__ __forceinline__ void schur_pair(const DeviceGraph& g, const LinBuf& L
 
 // One wavefront, one chunk (<= 64 pairs of one block, MULTI: <= DeviceGraph::sch_chunk): shared by k_schur_partial and the
 // fused small-window kernel.
+__device__ __forceinline__ void st_pub(double* p, const double v);
+// fin_arrive (round 4, VERDICT r03 item 9 as asked): the wavefront that completes a block's partials finalises the block — defined behind schur_block
+template <bool ROLEB>
+__device__ __forceinline__ void fin_arrive_at(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane);
 template <bool MULTI, bool CERES = false>
 __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& L, const int ch, const int lane, const double lambda, const double* __restrict__ pose,
                                             const int4 dsc, const int4 pr) {
@@ -1325,8 +1334,13 @@ __device__ __forceinline__ void schur_chunk(const DeviceGraph& g, const LinBuf& 
     }
     // element index inside a half: 0..17 → block entry (row 3*half + idx/6, col idx%6); 18..20 → b_s entry 3*half + (idx-18)
     double* out = g.sch_part + 42 * (size_t)ch;
-    if (len0 >= 1) out[off0 < 18 ? off0 : 36 + (off0 - 18)] = keep0;
-    if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
+    if (g.fin_arrive) {       // (read by another wavefront of this launch: write-through)
+        if (len0 >= 1) st_pub(out + (off0 < 18 ? off0 : 36 + (off0 - 18)), keep0);
+        if (len1 >= 1) st_pub(out + (off1 < 18 ? 18 + off1 : 39 + (off1 - 18)), keep1);
+    } else {
+        if (len0 >= 1) out[off0 < 18 ? off0 : 36 + (off0 - 18)] = keep0;
+        if (len1 >= 1) out[off1 < 18 ? 18 + off1 : 39 + (off1 - 18)] = keep1;
+    }
 }
 
 template <bool MULTI>
@@ -1360,7 +1374,13 @@ __device__ __forceinline__ void roleb_chunk(const DeviceGraph& g, const LmState*
     ReduceScatter<27, 32>::run(acc, lane, off, len);
     if (len >= 1) redb[wave * 27 + off] = acc[0];
     __syncthreads();
-    if (tid < 27) L.hpp_part[27 * (size_t)c + tid] = redb[tid] + redb[27 + tid] + redb[54 + tid] + redb[81 + tid];
+    if (Src::batched || !g.fin_arrive) {
+        if (tid < 27) L.hpp_part[27 * (size_t)c + tid] = redb[tid] + redb[27 + tid] + redb[54 + tid] + redb[81 + tid];
+        return;
+    }
+    if (wave != 0) return;
+    if (tid < 27) st_pub(L.hpp_part + 27 * (size_t)c + tid, redb[tid] + redb[27 + tid] + redb[54 + tid] + redb[81 + tid]);
+    fin_arrive_at<true>(g, L, const_cast<LmState*>(st), g.diag_blk[a], lane);
 }
 
 // ROLEB (single window, fused speculative unit): the workgroups behind this window's share of the chunk list are the pose-major role of
@@ -1400,6 +1420,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 4) void k_schur_partial(const Src 
     if (!(st->mode & MODE_TRIAL)) return;
     const LinSel<Src> lsel(g, st->lin_sel); const LinBuf& L = lsel.get();
     schur_chunk<MULTI, CERES>(g, L, ch, lane, st->lambda, g.pose[st->sel], dsc, pr);
+    if (!Src::batched && !CERES && g.fin_arrive) fin_arrive_at<ROLEB>(g, L, const_cast<LmState*>(st), g.sch_blk[ch], lane);
 }
 
 // ================================================================= K5, round 4: Schur complement by RUNS OF LANDMARKS
@@ -1712,7 +1733,7 @@ __device__ __forceinline__ double run_partial_sum(const DeviceGraph& g, const in
 __device__ __forceinline__ void st_pub(double* p, const double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <bool PUB = false>
+template <bool PUB = false, bool ARR = false>
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane, const int4 bd, const int4 be, const double part_in = 0.0,
                                             const unsigned pub_tag = 0u) {
     if (!PUB) {   // zero the granules: n_blk >= Npf waves x 64 lanes cover 4 * 6 Npf words in one pass.
@@ -1738,7 +1759,7 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
     } else if (lane < 42) {
         // (unroll 8 measured slower than 4: a C2 block has ~5 two-pass chunks, most of them would run in the remainder loop)
 #pragma unroll 4
-        for (int ch = bd.x; ch < bd.y; ++ch) part += g.sch_part[42 * (size_t)ch + lane];
+        for (int ch = bd.x; ch < bd.y; ++ch) part += ARR ? ld_coherent(g.sch_part + 42 * (size_t)ch + lane) : g.sch_part[42 * (size_t)ch + lane];
     }
     if (!diag) {
         if (lane < 36) {
@@ -1760,7 +1781,7 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
         }
         return;
     }
-    const double hv = (lane < 42) ? hpp_entry_r(g, L, lane, be.z, be.w, bd.z, bd.w) : 0.0;
+    const double hv = (lane < 42) ? hpp_entry_r<ARR>(g, L, lane, be.z, be.w, bd.z, bd.w) : 0.0;
     const bool on_diag = lane < 36 && r == c;
     const unsigned long long nz = __ballot(on_diag && hv != 0.0);
     const bool pin = (nz == 0ull);
@@ -1791,6 +1812,26 @@ __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& 
 __device__ __forceinline__ void schur_block(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
     // (the fused small-window kernel: pair-list gather only)
     schur_block<false>(g, L, st, b, lane, g.blk_desc[2 * b], g.blk_desc[2 * b + 1]);     // (first chunk, last + 1, first odometry entry, last + 1), (i, j, first pose-major chunk of i, last + 1)
+}
+
+// fin_arrive: a wavefront of k_schur_partial has just stored (write-through) one of block b's partials — a gather chunk's, or, for a
+// diagonal block in a launch that carries the pose-major role, a pose chunk's.  It drains its stores and counts itself in; the one that
+// completes the count (gather chunks + the pose chunks that really ran: lin_b_pending) finalises the block right there — the sums in
+// index order as k_schur_finalize forms them, every partial read past the caches — and leaves the counter at zero for the next launch.
+// Blocks finish at different times, so all but the last finalisations hide behind chunks that are still being gathered; the launch of
+// k_schur_finalize (5.6 us + a boundary at C2) is gone.  Contract kept: every block's wave clears its share of the PCG's hand-off words,
+// and S, b_s, Minv of all rows are complete at this kernel's end.
+template <bool ROLEB>
+__device__ __forceinline__ void fin_arrive_at(const DeviceGraph& g, const LinBuf& L, LmState* st, const int b, const int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0u;
+    if (lane == 0) old = __hip_atomic_fetch_add(g.fin_cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    const int e = g.fin_exp[b];
+    const unsigned expect = (unsigned)(e & 0xffff) + ((ROLEB && st->lin_b_pending) ? (unsigned)(e >> 16) : 0u);
+    if (old + 1u != expect) return;
+    if (lane == 0) g.fin_cnt[b] = 0u;
+    schur_block<false, true>(g, L, st, b, lane, g.blk_desc[2 * b], g.blk_desc[2 * b + 1]);
 }
 
 // RUNS (the Schur complement came from k_schur_runs): one WORKGROUP per stored block — a block collects one partial per run whose span
@@ -3987,6 +4028,7 @@ __global__ __launch_bounds__(256) void k_reset(const Src src, const int max_iter
         for (int t = gid; t < g.Nl * 3; t += stride) { const double v = g.pt0[t]; g.pt[0][t] = v; g.pt[1][t] = v; }
     }
     for (int t = gid; t < g.No; t += stride) { g.obs_level[t] = 0; g.obs_outlier[t] = 0; g.obs_chi2_out[t] = 0.0; }
+    if (g.fin_arrive) for (int t = gid; t < g.n_blk; t += stride) g.fin_cnt[t] = 0u;
     if (g.fin_pcg) {
         // the fused finalisation + PCG launch: its flags and hand-off words start every optimise call at zero (tags count the call's units)
         for (int t = gid; t < g.n_blk; t += stride) g.fin_flag[t] = 0u;
