@@ -84,6 +84,9 @@ def main():
                          "(blockIdx.y = window), 'streams' = one host thread + HIP stream per window")
     ap.add_argument("--handles", type=int, default=1, help="with --windows-per-gpu B > 1 in launch mode: split the B resident windows over this many handles "
                     "(each its own stream and host thread, B / handles windows sharing every launch of a handle)")
+    ap.add_argument("--tuning", choices=("auto", "latency", "throughput"), default="auto",
+                    help="visfs_ba_set_tuning of the handles: auto = throughput for handles that hold a batch of resident windows (BASELINE config 5: the PCG "
+                         "of a window in one workgroup), latency for a window on its own (the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config5", choices=("auto", "on", "off"), default="auto",
                     help="also measure BASELINE config 5's per-GPU share in the same run (8 resident C2-size windows per GPU sharing every launch, "
@@ -122,13 +125,14 @@ def main():
     B = args.windows_per_gpu
     solvers, descs, gbs = [], [], []
     batched = B > 1 and args.batch_mode == "launch"
+    tuning = {"latency": abi.TUNE_LATENCY, "throughput": abi.TUNE_THROUGHPUT}.get(args.tuning, abi.TUNE_THROUGHPUT if batched else abi.TUNE_LATENCY)
     for b in range(B):
         w = synth.make_window(args.config, window_index=rank * B + b)
         wb = abi.WindowBuffers(w)
         gb, used, oref, mono = abi.pack_window_with(lib.visfs_ba_pack_window, prm, wb)    # host graph build (product code)
         gbs.append(gb)
         if not batched or b == 0:
-            s = backend.Solver(prm, device=dev)
+            s = backend.Solver(prm, device=dev, tuning=tuning)
             s.upload(gb)                                                                  # inputs resident in HBM
             solvers.append(s)
             descs.append(s.describe())
@@ -136,7 +140,7 @@ def main():
     if batched:
         per = (B + H - 1) // H
         for k in range(1, H):
-            solvers.append(backend.Solver(prm, device=dev))
+            solvers.append(backend.Solver(prm, device=dev, tuning=tuning))
         for k in range(H):
             solvers[k].batch_upload(gbs[k * per:(k + 1) * per])                           # the handle's windows resident side by side
 
@@ -262,6 +266,7 @@ def main():
                                + f", {B} window(s) per GPU",
                    "windows_per_gpu": B, "solver": args.solver, "iterations_per_solve": int(total_iters / (args.steps * world * B)),
                    "pcg_iterations_per_solve": int(last.pcg_iterations) if last is not None else 0,
+                   "tuning": "throughput" if tuning == abi.TUNE_THROUGHPUT else "latency",
                    "parallelism": f"{world} rank(s) x {B} independent window(s), no data-path collective"
                                   + (f"; windows of a rank share every launch (blockIdx.y = window)" if batched else "")
                                   + (f"; {H} handles (streams / host threads) of {(B + H - 1) // H} windows each" if batched and H > 1 else "")},
@@ -336,7 +341,8 @@ def config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, sy
     for b in range(per_gpu):
         w = synth.make_window("C5", window_index=rank * per_gpu + b)
         gbs.append(abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))[0])
-    s = backend.Solver(prm, device=dev)
+    tuning = abi.TUNE_LATENCY if args.tuning == "latency" else abi.TUNE_THROUGHPUT       # (a handle that holds a batch: visfs_ba_set_tuning)
+    s = backend.Solver(prm, device=dev, tuning=tuning)
     s.batch_upload(gbs)
 
     def step():
@@ -357,6 +363,7 @@ def config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, sy
     total = vdist.reduce_sum(iters, world, red_dev)
     local = torch.from_numpy(np.stack([s.batch_download(b)[0] for b in range(per_gpu)], 0))
     rec = {"workload": f"{per_gpu} resident C2-size windows per GPU x {world} GPU(s) = {per_gpu * world} windows, Schur + PCG, Iterations=20, batched launches",
+           "tuning": "throughput" if tuning == abi.TUNE_THROUGHPUT else "latency",
            "value": round(total / elapsed, 2), "unit": "BA iterations/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 4), "scaling": "weak"}
     if world > 1:
         ids = vdist.gather_results(torch.tensor([[float(rank)]], dtype=torch.float64), world, red_dev).cpu().numpy().ravel()
@@ -368,7 +375,7 @@ def config5_record(args, lib, rank, world, dev, red_dev, bar_dev, vdist, abi, sy
         for r in range(world):
             w = synth.make_window("C5", window_index=r * per_gpu)
             gb = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))[0]
-            s1 = backend.Solver(prm, device=dev)
+            s1 = backend.Solver(prm, device=dev, tuning=tuning)
             s1.batch_upload([gb]); s1.batch_reset(); s1.batch_optimize(); ref = s1.batch_download(0)[0]
             s1.close()
             same = same and bool(np.array_equal(ref, allp[r * per_gpu]))
@@ -400,7 +407,8 @@ def gather_and_check(args, prm, lib, solvers, batched, B, rank, world, dev, red_
     for r in range(world):
         w = synth.make_window(args.config, window_index=r * B)
         gb, *_ = abi.pack_window_with(lib.visfs_ba_pack_window, prm, abi.WindowBuffers(w))
-        s = backend.Solver(prm, device=dev)
+        tuning = {"latency": abi.TUNE_LATENCY, "throughput": abi.TUNE_THROUGHPUT}.get(args.tuning, abi.TUNE_THROUGHPUT if batched else abi.TUNE_LATENCY)
+        s = backend.Solver(prm, device=dev, tuning=tuning)
         if batched:
             s.batch_upload([gb]); s.batch_reset(); s.batch_optimize(); ref = s.batch_download(0)[0]
         else:

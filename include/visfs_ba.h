@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VISFS_BA_ABI_VERSION 7
+#define VISFS_BA_ABI_VERSION 8
 
 /* ---- status codes ------------------------------------------------------- */
 /* The reference signals failure by returning an EMPTY pose map
@@ -195,6 +195,18 @@ const char* visfs_ba_last_error(const visfs_ba_handle* h);
  * wrong architecture, or a stream / pinned-memory allocation failure — with the HIP error text. */
 const char* visfs_ba_create_error(void);
 int visfs_ba_abi_version(void);
+
+/* What a handle is tuned for (ABI 8).  The reference has no counterpart: one VISFS::Optimizer::Optimizer serves one Estimator
+ * (corelib/include/Optimizer/Optimizer.h:29-56), one window per call.  LATENCY (the default): a window on its own is solved as fast as it can
+ * be — reduced systems of up to 64 free poses run the PCG as one wavefront per block row on as many compute units.  THROUGHPUT: for a handle
+ * that is mostly given BATCHES (visfs_ba_solve_batch, visfs_ba_batch_*; BASELINE config 5), windows of up to 56 free poses run their PCG in ONE
+ * workgroup each: +7 % at 8 resident 50-key-frame windows, +13 % at 16, -4 % for a lone window.  The choice belongs to the handle, never to the
+ * size of a batch: a window's result is the same bytes whether it is solved alone or with others THROUGH THE SAME HANDLE; the two tunings agree
+ * to rounding with identical iteration counts.  Applies to the uploads that follow (resident graphs keep what they were uploaded with).
+ * The environment variable VISFS_BA_PCG_CU=0|1, when set, overrides every handle (diagnostics). */
+#define VISFS_BA_TUNE_LATENCY    0
+#define VISFS_BA_TUNE_THROUGHPUT 1
+int visfs_ba_set_tuning(visfs_ba_handle* h, int32_t tuning);
 
 /* Replaces one call of `Optimizer::localOptimize` (Optimizer.cpp:58-364): pack
  * (graph build :100-223), upload, both optimise phases on the GPU (:261-318),

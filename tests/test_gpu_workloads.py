@@ -245,6 +245,41 @@ def test_a_lone_mid_size_window_is_chunked_in_two_passes_and_says_so(olib, monke
     assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out)
 
 
+def test_a_handle_tuned_for_throughput_runs_its_windows_on_the_single_workgroup_pcg(olib, monkeypatch):
+    """ABI 8, visfs_ba_set_tuning: the PCG kernel follows the HANDLE (THROUGHPUT: k_pcg_cu for every window of <= 56 free poses it uploads
+    afterwards), never the size of a batch — through one handle a window is the same bytes alone, as a batch of one and among others; the
+    two tunings agree to rounding with identical iteration counts; VISFS_BA_PCG_CU=0|1 overrides every handle."""
+    from visfs_amd import backend
+    monkeypatch.delenv("VISFS_BA_PCG_CU", raising=False)
+    prm = abi.default_params(iterations=10, solver=2)
+    ws = [synth.make_window("custom", n_kf=14, n_lm=300, n_obs=2400, seed=620 + i) for i in range(6)]
+    st = backend.Solver(prm, tuning=abi.TUNE_THROUGHPUT)
+    alone = [st.solve_window(abi.WindowBuffers(w)) for w in ws]
+    ones = [st.solve_batch([abi.WindowBuffers(w)])[0] for w in ws]
+    among = st.solve_batch([abi.WindowBuffers(w) for w in ws])
+    gb, *_ = abi.pack_window_with(st.lib.visfs_ba_pack_window, prm, abi.WindowBuffers(ws[0]))
+    st.upload(gb); assert st.describe()["solver_kernel"] == 4                      # k_pcg_cu
+    st.set_tuning(abi.TUNE_LATENCY); st.upload(gb); assert st.describe()["solver_kernel"] == 1     # later uploads follow the new tuning
+    st.close()
+    sl = backend.Solver(prm)
+    lat = [sl.solve_window(abi.WindowBuffers(w)) for w in ws]
+    sl.upload(gb); assert sl.describe()["solver_kernel"] == 1                      # k_pcg1: the default
+    sl.close()
+    differ = 0
+    for (rc, a), b, c, (rcl, l) in zip(alone, ones, among, lat):
+        assert rc == rcl == b.struct.status == c.struct.status == abi.OK
+        assert np.array_equal(a.pose_Twr_out, b.pose_Twr_out) and np.array_equal(b.pose_Twr_out, c.pose_Twr_out) and a.outliers() == c.outliers()
+        assert list(a.struct.iterations_run) == list(l.struct.iterations_run) and a.outliers() == l.outliers()
+        et, er = synth.pose_errors(a.pose_Twr_out[:14], l.pose_Twr_out[:14])
+        assert et < 1e-9 and er < 1e-9
+        differ += int(not np.array_equal(a.pose_Twr_out, l.pose_Twr_out))
+    assert differ > 0                                                               # a different kernel really ran
+    monkeypatch.setenv("VISFS_BA_PCG_CU", "0")
+    so = backend.Solver(prm, tuning=abi.TUNE_THROUGHPUT)
+    so.upload(gb); assert so.describe()["solver_kernel"] == 1                      # the environment overrides the handle
+    so.close()
+
+
 def test_batch_sharded_over_handles_equals_one_handle(olib):
     """visfs_ba_solve_batch_sharded: config 5 inside one process — the windows in contiguous blocks over several handles (one per GPU
     on a node; two on this one-GPU box), each block solved by visfs_ba_solve_batch on its own host thread.  Results are those of one

@@ -34,10 +34,10 @@ step "batches on one GPU"
 for B in 8 16; do
   timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu $B --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x$B.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
-step "the single-workgroup PCG (opt-in): one window and batches"
-VISFS_BA_PCG_CU=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --config5 off > "$OUT/${TAG}_bench_C2_pcg_cu.json" 2>> "$OUT/${TAG}_c2_bench.err"
+step "the two handle tunings (visfs_ba_set_tuning): batches on the latency tuning, one window on the throughput tuning"
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --config5 off --tuning throughput > "$OUT/${TAG}_bench_C2_tuned_throughput.json" 2>> "$OUT/${TAG}_c2_bench.err"
 for B in 8 16; do
-  VISFS_BA_PCG_CU=1 timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu $B --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_C5x${B}_pcg_cu.json" 2>> "$OUT/${TAG}_c2_bench.err"
+  timeout -k 10 300 python3 bench.py --config C5 --windows-per-gpu $B --steps 10 --warmup 2 --no-cpu-baseline --tuning latency > "$OUT/${TAG}_bench_C5x${B}_tuned_latency.json" 2>> "$OUT/${TAG}_c2_bench.err"
 done
 step "per-frame call path"
 timeout -k 10 300 python3 tools/e2e_breakdown.py > "$OUT/${TAG}_e2e_breakdown.log" 2>&1

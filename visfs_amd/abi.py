@@ -8,7 +8,8 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
+TUNE_LATENCY, TUNE_THROUGHPUT = 0, 1            # visfs_ba_set_tuning
 MAX_TRACE = 64
 
 # status codes (include/visfs_ba.h)

@@ -24,7 +24,7 @@ EXPORTS = [
     "visfs_ba_graph_download", "visfs_ba_graph_free_poses", "visfs_ba_stage_linearize",
     "visfs_ba_stage_trial", "visfs_ba_stage_fetch", "visfs_ba_graph_describe", "visfs_ba_profile_enable",
     "visfs_ba_profile_read", "visfs_ba_batch_upload", "visfs_ba_batch_reset", "visfs_ba_batch_optimize", "visfs_ba_batch_download",
-    "visfs_ba_create_error", "visfs_ba_hook_lm_script", "visfs_ba_hook_ceres_script", "visfs_ba_hook_dogleg_script", "visfs_ba_hook_dogleg_combine", "visfs_ba_solve_batch_sharded", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
+    "visfs_ba_create_error", "visfs_ba_set_tuning", "visfs_ba_hook_lm_script", "visfs_ba_hook_ceres_script", "visfs_ba_hook_dogleg_script", "visfs_ba_hook_dogleg_combine", "visfs_ba_solve_batch_sharded", "visfs_ba_stage_commit", "visfs_ba_stage_begin_phase", "visfs_ba_stage_mark_outliers",
 ]
 
 _lib = None
@@ -51,6 +51,8 @@ def load_library():
     lib.visfs_ba_last_error.argtypes = [C.c_void_p]
     lib.visfs_ba_last_error.restype = C.c_char_p
     lib.visfs_ba_create_error.restype = C.c_char_p
+    lib.visfs_ba_set_tuning.argtypes = [C.c_void_p, C.c_int32]
+    lib.visfs_ba_set_tuning.restype = C.c_int
     lib.visfs_ba_solve_window.argtypes = [C.c_void_p, C.POINTER(abi.Window), C.POINTER(abi.Result)]
     lib.visfs_ba_solve_window.restype = C.c_int
     lib.visfs_ba_solve_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.Window)), C.POINTER(C.POINTER(abi.Result))]
@@ -111,7 +113,7 @@ def _p(a):
 class Solver:
     """One `visfs_ba_handle` (one GPU, one stream) — the analogue of a VISFS::Optimizer::Optimizer instance."""
 
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, tuning=None):
         self.lib = load_library()
         self.params = params if params is not None else abi.default_params()
         h = C.c_void_p()
@@ -120,6 +122,12 @@ class Solver:
             raise BackendError(f"visfs_ba_create failed with status {rc}: {self.lib.visfs_ba_create_error().decode()}")
         self.h = h
         self.gb = None
+        if tuning is not None:
+            self.set_tuning(tuning)
+
+    def set_tuning(self, tuning):
+        """abi.TUNE_LATENCY (default) / abi.TUNE_THROUGHPUT (a handle that is mostly given batches): applies to later uploads."""
+        self._check(self.lib.visfs_ba_set_tuning(self.h, int(tuning)), "set_tuning")
 
     def close(self):
         if getattr(self, "h", None):

@@ -198,6 +198,7 @@ struct BatchScratch {
 struct visfs_ba_handle {
     visfs_ba_params prm;
     int device = 0;
+    int tuning = VISFS_BA_TUNE_LATENCY;            // visfs_ba_set_tuning: THROUGHPUT selects the single-workgroup PCG for the uploads that follow
     std::string err;
     Workspace ws;
     std::vector<Workspace*> batch;
@@ -740,11 +741,11 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     // One window: slower than k_pcg1 (34.7 vs 21.6 us per solve at C2, profiles/r02_pcg_cu_vs_handoff.log).  Many windows sharing every
     // launch: nothing spins and no hand-off is paid — 16 C2 windows 68.0 -> 70.6 k it/s, 32 windows 66.6 -> 74.3 k, but 8 windows
     // 58.8 -> 55.6 k (profiles/r02_v3_pcg_cu_batches.log).  Its mat-vec sums associate differently from k_pcg1's, so a window's result
-    // would depend on how many OTHER windows were submitted with it if the kernel followed the batch size: it is opt-in
-    // (VISFS_BA_PCG_CU=1), never chosen from the batch — every window is bit-identical to
-    // its single-window solve however a batch is cut or sharded.
+    // would depend on how many OTHER windows were submitted with it if the kernel followed the batch size: it follows the HANDLE
+    // (visfs_ba_set_tuning(THROUGHPUT), ABI 8; VISFS_BA_PCG_CU=0|1 overrides), never the batch — every window is bit-identical to
+    // its solve as a batch of one through the same handle however a batch is cut or sharded.
     const bool pcg_cu = [&]() { const char* e = std::getenv("VISFS_BA_PCG_CU"); int mr = 0; for (int a = 0; a < Npf; ++a) mr = std::max(mr, row_ptr[a + 1] - row_ptr[a]);
-                                const bool want = e && e[0] == '1';
+                                const bool want = e ? e[0] == '1' : h->tuning == VISFS_BA_TUNE_THROUGHPUT;      // (the environment overrides every handle)
                                 return prm.solver == 2 && pcg_cu_fits(Npf, mr) && 6 * Npf > 64 && want; }();
     // ... and where each stored block sits in the row lists: k_schur_finalize writes S a second time by scalar row for that kernel
     const int cu_T = (int)((6 * (size_t)Npf + 63) / 64 * 64);
@@ -1990,7 +1991,7 @@ int batch_optimize_group(visfs_ba_handle* h, const std::vector<int>& members) {
                 try {
                     (void)hipSetDevice(h->device);
                     visfs_ba_handle local;                        // per-thread error string; shares params / device
-                    local.prm = h->prm; local.device = h->device;
+                    local.prm = h->prm; local.device = h->device; local.tuning = h->tuning;
                     rc[k] = batch_optimize(&local, h->part_scratch[k - 1], h->batch, part[k], h->part_stream[k - 1]);
                     errs[k] = local.err;
                 } catch (...) { rc[k] = VISFS_BA_ERR_DEVICE; }
@@ -2013,6 +2014,13 @@ int batch_optimize_group(visfs_ba_handle* h, const std::vector<int>& members) {
 extern "C" {
 
 int visfs_ba_abi_version(void) { return VISFS_BA_ABI_VERSION; }
+
+int visfs_ba_set_tuning(visfs_ba_handle* h, int32_t tuning) {
+    if (!h) return VISFS_BA_ERR_BAD_ARGUMENT;
+    if (tuning != VISFS_BA_TUNE_LATENCY && tuning != VISFS_BA_TUNE_THROUGHPUT) return bad(h, "unknown tuning");
+    h->tuning = tuning;
+    return VISFS_BA_OK;
+}
 
 void visfs_ba_default_params(visfs_ba_params* p) {
     // Parameters.h:184-191
@@ -2156,7 +2164,7 @@ int visfs_ba_solve_batch(visfs_ba_handle* h, int32_t n, const visfs_ba_window* c
                     try {
                         (void)hipSetDevice(h->device);
                         visfs_ba_handle local;            // per-thread error string; shares params / device
-                        local.prm = h->prm; local.device = h->device;
+                        local.prm = h->prm; local.device = h->device; local.tuning = h->tuning;
                         for (; i < n; i += lanes) fn(local, i);
                         if (!local.err.empty()) errs[t] = local.err;
                     } catch (...) {                       // nothing may escape a thread: mark this lane's remaining windows failed

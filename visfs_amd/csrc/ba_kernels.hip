@@ -2523,6 +2523,10 @@ __device__ __forceinline__ double dot6_pairs(const double* __restrict__ a, const
 }
 template <class Src>
 __global__ __launch_bounds__(CU_MAX_T) void k_pcg_cu(const Src src) {
+    // No implicit fusion in this body: every multiply-add that is meant to be fused is written as one (dot6, __builtin_fma).  Under
+    // -ffp-contract=fast the product of `r * d` was fused into the first add of the wave sum in one instantiation and not in the other:
+    // a window solved through visfs_ba_solve_window (One) and as a batch of one (Many) differed in the last bit.
+#pragma clang fp contract(off)
     const DeviceGraph& g = graph_of(src);
     LmState* st = state_of(src, g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
