@@ -1,8 +1,20 @@
 # scratch: the command of the last ad-hoc GPU run (gpurun -- 'bash tools/_run.sh'); the round's collections are tools/collect_profiles.sh and tools/_soak.sh
 set -o pipefail
 O=gpurun_out; mkdir -p $O; export PYTHONPATH=$PWD
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/r04_final_pytest_gpu.log 2>&1; echo "tests rc=$?" >> $O/r04_final_pytest_gpu.log
-tail -4 $O/r04_final_pytest_gpu.log
-grep -q "rc=0" $O/r04_final_pytest_gpu.log || exit 1
-( timeout -k 10 200 python3 tools/soak_batch.py 1500 1800 12 > $O/r04_soak_batch.log 2>&1; echo "rc=$?" >> $O/r04_soak_batch.log; tail -2 $O/r04_soak_batch.log )
-bash tools/collect_profiles.sh r04_v2 > $O/r04_v2_collect.log 2>&1; tail -2 $O/r04_v2_collect.log
+rm -f $O/r04_z_ab.log
+run_set() {
+  timeout -k 10 200 python bench.py --config C5 --windows-per-gpu 8 --steps 10 --warmup 2 --no-cpu-baseline --config5 off >> $O/r04_z_ab.log 2>&1
+  timeout -k 10 200 python bench.py --config C5 --windows-per-gpu 16 --steps 10 --warmup 2 --no-cpu-baseline --config5 off >> $O/r04_z_ab.log 2>&1
+  timeout -k 10 200 python bench.py --config C5 --windows-per-gpu 8 --solver 0 --steps 10 --warmup 2 --no-cpu-baseline --config5 off >> $O/r04_z_ab.log 2>&1
+}
+for rep in 1 2; do
+echo "== default" >> $O/r04_z_ab.log; run_set
+echo "== VISFS_BA_DECIDE_FUSED=1" >> $O/r04_z_ab.log; VISFS_BA_DECIDE_FUSED=1 run_set
+done
+grep -h '"value"\|^==' $O/r04_z_ab.log | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('=='): print(ln.strip()); continue
+    d = json.loads(ln)
+    print(' ', d['config']['workload'][:4], d['config']['windows_per_gpu'], 'solver', d['config']['solver'], 'value', d['value'])
+"

@@ -1018,7 +1018,8 @@ int ws_upload(visfs_ba_handle* h, Workspace& w, const visfs_ba_graph* gr, const 
     // removing any of it: 16 x C2 80.3 k -> 74.4 k it/s, 8 x C2 66.9 k -> 65.8 k.  So the gated unit stays the default for batch members
     // (VISFS_BA_BATCH_SPEC=1 selects the fused unit: tests, A/B runs).
     if (w.batch_member) { const char* e = std::getenv("VISFS_BA_BATCH_SPEC"); if (!w.spec_fused || !(e && e[0] == '1')) { w.spec = false; w.spec_fused = false; } }
-    // default: on for a window on its own, off for batch members until measured (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
+    // default: on for a window on its own, off for batch members — measured in round 4 (profiles/r04_batch_decide_fused_ab.log): 8 windows
+    // 71.1 -> 68.7 k it/s, 16 windows 90.3 -> 83.7 k with the decision on board k_backsub<Many> (VISFS_BA_DECIDE_FUSED=1 forces it on for both)
     { const char* e = std::getenv("VISFS_BA_DECIDE_FUSED"); w.fused_decide = (e ? (e[0] != '0') : !w.batch_member) && !ceres; }
     w.direct_ready = prm.solver == 2 && !ceres && Npf >= 1 && !w.small_solve && (band_B >= 0 || chol_np <= 2048);
     w.solver_now = -1;
